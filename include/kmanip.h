@@ -1,0 +1,199 @@
+/*
+ * kmanip.h -- C ABI of the MI355X-native batched gym-kmanip hot path.
+ *
+ * The reference (kscalelabs/gym-kmanip) has no FFI: its backend seam is the Python object
+ * returned by `env_sim.new(gym_env)` (reference gym_kmanip/env_base.py:192-200), on which
+ * KManipEnv only ever calls k_reset() (env_base.py:221), k_step(action) (env_base.py:242),
+ * k_render(cam) (env_base.py:217) and k_close() (env_base.py:266).  This header is what a
+ * third backend (`env_hip.new`) binds with ctypes; every entry point cites the reference
+ * interface it replaces.  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; device buffers are passed as void* device
+ *     pointers, the stream as void* (hipStream_t) -- NULL = the null stream.
+ *   - every function returns 0 on success, nonzero on error; kmanip_last_error() gives text.
+ *   - numerical blow-up of one env is DATA (bit 1 of its done byte), not an error.
+ *   - one handle <-> one device; calls on a handle are serialised by the caller
+ *     (the reference is single-threaded and non-re-entrant: ik_mujoco.py:34,67).
+ *
+ * Arithmetic type: float64 on device, like the reference (MuJoCo mjtNum = double,
+ * gym_kmanip/__init__.py:50 OBS_DTYPE = float64).  Actions are float32 (__init__.py:51).
+ */
+#ifndef KMANIP_H
+#define KMANIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KM_MAX_LINKS   20   /* 1-DoF robot links == robot dofs == nu == q_len (10 solo, 20 dual/torso) */
+#define KM_MAX_ARMS    2    /* arm 0 = right ("eer"), arm 1 = left ("eel")                         */
+#define KM_MAX_IK      7    /* IK unknowns per arm (7 solo/dual, 6 torso)                          */
+#define KM_MAX_SPHERES 4    /* finger sphere colliders                                             */
+#define KM_NQ_CUBE     7
+#define KM_NV_CUBE     6
+
+/* action-key columns in the flat [num_envs, act_dim] float32 action matrix; key order is the
+ * insertion order of the action Dict space, reference env_base.py:151-188 */
+enum {
+  KM_ACT_EEL_POS = 0, KM_ACT_EEL_ORN, KM_ACT_EER_POS, KM_ACT_EER_ORN,
+  KM_ACT_GRIP_L, KM_ACT_GRIP_R, KM_ACT_QPOS_R, KM_ACT_QPOS_L, KM_ACT_NKEYS
+};
+
+enum { KM_JNT_HINGE = 0, KM_JNT_SLIDE = 1 };
+
+/* done byte */
+#define KM_DONE_TRUNCATED 1u  /* step_idx reached max_episode_steps (TimeLimit, __init__.py:28,247) */
+#define KM_DONE_DIVERGED  2u  /* NaN / |qacc| > 1e10 (dm_control raises PhysicsError instead)       */
+
+/* contact-mask bits (uint32 per env), bit-exact parity target */
+#define KM_CON_CUBE_TABLE(c)   (1u << (c))          /* c = 0..7 cube corner vs table plane (<=4 kept) */
+#define KM_CON_FINGER_CUBE(s)  (1u << (8 + (s)))    /* s = sphere index                               */
+#define KM_CON_FINGER_TABLE(s) (1u << (12 + (s)))
+
+typedef struct KModelDesc {
+  /* ---- sizes */
+  int32_t nlink;                 /* robot 1-DoF links; nq = nlink + 7, nv = nlink + 6, nu = nlink */
+  int32_t narm;                  /* arms present in act_list (0..2)                                */
+  int32_t nsphere;
+  int32_t act_dim;               /* columns of the action matrix                                   */
+  int32_t obs_dim;               /* 2*nlink + 7                                                    */
+  int32_t max_episode_steps;     /* 64, __init__.py:28                                             */
+  int32_t n_sub_steps;           /* control_timestep / timestep = 10, __init__.py:30, env_sim.py:210 */
+  int32_t solver_iterations;     /* PGS sweeps cap (MuJoCo default 100)                            */
+  int32_t touch_reward_enabled;  /* 0 reproduces the reference's dead touch/lift terms (SURVEY finding 4) */
+  int32_t auto_reset;            /* 1: envs whose done byte is set are reset inside kmanip_step    */
+  int32_t act_col[KM_ACT_NKEYS]; /* first column of each action key, -1 if the key is absent       */
+  int32_t pad0_;
+
+  /* ---- kinematic tree (link i <-> dof i <-> qpos i <-> actuator i), parents before children */
+  int32_t link_parent[KM_MAX_LINKS];       /* -1 = fixed to world                                  */
+  int32_t jnt_type[KM_MAX_LINKS];
+  int32_t forcelimited[KM_MAX_LINKS];
+  int32_t pad1_[KM_MAX_LINKS];
+  double  link_pos[KM_MAX_LINKS][3];       /* pose in parent link frame (world if parent == -1)    */
+  double  link_quat[KM_MAX_LINKS][4];      /* wxyz                                                 */
+  double  jnt_axis[KM_MAX_LINKS][3];       /* local                                                */
+  double  jnt_range[KM_MAX_LINKS][2];
+  double  frictionloss[KM_MAX_LINKS];
+  double  kp[KM_MAX_LINKS];
+  double  ctrlrange[KM_MAX_LINKS][2];
+  double  forcerange[KM_MAX_LINKS][2];
+  double  mass[KM_MAX_LINKS];              /* surrogate inertials (build-owned)                    */
+  double  com[KM_MAX_LINKS][3];            /* link frame                                           */
+  double  inertia[KM_MAX_LINKS][3];        /* diagonal, link-frame axes, about com                 */
+  double  q_home[KM_MAX_LINKS];            /* float32-rounded, __init__.py:53-122                  */
+
+  /* ---- arms: arm 0 = right, arm 1 = left */
+  int32_t arm_present[KM_MAX_ARMS];
+  int32_t arm_nq[KM_MAX_ARMS];
+  int32_t arm_q_id[KM_MAX_ARMS][KM_MAX_IK + 1]; /* q_id_r_mask / q_id_l_mask, __init__.py:125-136  */
+  int32_t arm_grip_id[KM_MAX_ARMS][2];          /* ctrl_id_*_grip                                  */
+  int32_t arm_site_link[KM_MAX_ARMS];
+  int32_t arm_mode[KM_MAX_ARMS];                /* 0 = none, 1 = EE-delta + IK, 2 = joint-delta    */
+  int32_t arm_has_grip[KM_MAX_ARMS];
+  int32_t pad2_[2];
+  double  arm_site_pos[KM_MAX_ARMS][3];         /* site pose in its link frame                     */
+  double  arm_site_quat[KM_MAX_ARMS][4];
+
+  /* ---- colliders (surrogates): finger spheres, table plane z, cube box */
+  int32_t sphere_link[KM_MAX_SPHERES];
+  double  sphere_pos[KM_MAX_SPHERES][3];
+  double  sphere_radius[KM_MAX_SPHERES];
+  double  table_z;
+
+  /* ---- cube (free body), scene.xml:17-21 */
+  double  cube_mass;
+  double  cube_inertia[3];
+  double  cube_half[3];
+  double  cube_frictionloss;
+  double  cube_quat0[4];
+  double  cube_spawn_lo[3];                     /* __init__.py:164-170                             */
+  double  cube_spawn_hi[3];
+
+  /* ---- contact parameters after MuJoCo's pair mixing */
+  double  con_cube_solref[2];                   /* pairs involving the cube (condim 4)             */
+  double  con_cube_solimp[5];
+  double  con_cube_friction[3];                 /* tangential, torsional, rolling                  */
+  double  con_def_solref[2];                    /* finger-table pairs (condim 3), joint limits, friction loss */
+  double  con_def_solimp[5];
+  double  con_def_friction[3];
+
+  /* ---- options / constants */
+  double  timestep;                             /* 0.002 (MuJoCo default, no <option> in any XML)  */
+  double  gravity[3];
+  double  solver_tolerance;                     /* 1e-8                                            */
+  double  ik_res_rad, ik_res_reg_prev, ik_res_reg_home, ik_jac_rad, ik_jac_reg; /* __init__.py:37-41 */
+  double  ee_pos_delta[3], ee_orn_delta[3];     /* __init__.py:174-187                             */
+  double  q_pos_delta;                          /* __init__.py:196                                 */
+  double  ee_s_min, ee_s_max, ee_s_delta;       /* __init__.py:199-201                             */
+  double  max_q_vel;                            /* pi, __init__.py:31                              */
+  double  epsilon;                              /* 1e-6, __init__.py:192                           */
+  double  reward_vel_penalty, reward_grip_dist, reward_touch_cube, reward_lift_cube; /* :205-208  */
+} KModelDesc;
+
+typedef struct KHandle_* KHandle;
+
+/* sizeof(KModelDesc) as compiled into the library (host bindings check their mirror). */
+int kmanip_model_desc_size(void);
+
+/* Replaces env_sim.new(gym_env) (reference env_sim.py:206-211): build `num_envs` simulated envs
+ * on HIP device `device`.  `env_id_offset` is the global index of local env 0 (multi-GPU
+ * sharding: RNG streams are keyed by the GLOBAL env id so results do not depend on the shard
+ * layout).  The library owns model, state and scratch. */
+int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t seed,
+                  int64_t env_id_offset, KHandle* out);
+
+/* Replaces KManipEnvSim.k_reset (env_sim.py:190-194) -> KManipTask.initialize_episode
+ * (env_sim.py:23-36): reset envs whose mask byte is nonzero (NULL = all) to the home pose,
+ * zero velocity and a fresh cube spawn; writes their observation rows.  mask/obs are device
+ * pointers: mask uint8[num_envs], obs double[num_envs, obs_dim] (may be NULL). */
+int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stream);
+
+/* Replaces KManipEnvSim.k_step (env_sim.py:196-200): one control step for every env =
+ * KManipTask.before_step (env_sim.py:38-108, incl. ik_mujoco.ik) + physics.step(10)
+ * + get_reward (env_sim.py:148-179) + get_observation (env_sim.py:110-146).
+ * act_dev float[num_envs, act_dim]; obs_dev double[num_envs, obs_dim];
+ * reward_dev double[num_envs]; done_dev uint8[num_envs] (KM_DONE_* bits).  All device memory,
+ * owned by the caller. */
+int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward_dev,
+                uint8_t* done_dev, void* stream);
+
+/* State access for parity tests / checkpointing (state is
+ * (qpos, qvel, ctrl, qacc_warmstart, time)); HOST pointers, env-major
+ * [num_envs, nq|nv|nu|nv], step_idx int32[num_envs]; any pointer may be NULL. Synchronous. */
+int kmanip_get_state(KHandle h, double* qpos, double* qvel, double* ctrl, double* qacc_warm,
+                     int32_t* step_idx);
+int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const double* ctrl,
+                     const double* qacc_warm, const int32_t* step_idx);
+
+/* Per-env diagnostics of the last kmanip_step (HOST pointers, may be NULL):
+ * contact_mask uint32 (KM_CON_* bits, from the trailing mj_step1), ik_nfev int32[num_envs, 2],
+ * ik_status int32[num_envs, 2]. Synchronous. */
+int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status);
+
+/* Kernel-only timing of the most recent kmanip_step launch sequence, in milliseconds, measured
+ * with HIP events recorded on the launch stream (bench.py roofline leg). Synchronises. */
+int kmanip_last_step_ms(KHandle h, float* ms);
+int kmanip_enable_timing(KHandle h, int enable);
+
+/* Standalone batched IK (ik_mujoco.ik, reference ik_mujoco.py:100-155) for parity tests:
+ * qpos HOST double[n, nq] (in: current; out: qpos after the IK's last evaluation),
+ * goal_pos double[n,3], goal_quat double[n,4] (wxyz), arm 0/1; q_out double[n, arm_nq]
+ * (the clipped result.x that the reference writes into ctrl). Synchronous. */
+int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos,
+              const double* goal_quat, double* q_out, int32_t* nfev, int32_t* status);
+
+int kmanip_num_envs(KHandle h);
+const char* kmanip_last_error(KHandle h);   /* h may be NULL: error of the last failed create */
+const char* kmanip_version(void);
+
+/* Replaces KManipEnvSim.k_close (env_sim.py:202-203). */
+void kmanip_destroy(KHandle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMANIP_H */

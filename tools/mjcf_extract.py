@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Extract a build-owned, mesh-free model spec from the reference MJCF (read as DATA).
+
+Runs only in the build container (needs /root/reference).  The JSON it writes under
+gym_kmanip_amd/assets/ is what ships: kinematic tree, joint ranges, actuators, sites, cube,
+cameras (numbers from the reference XML, cited below) PLUS the build's documented surrogates
+for what the reference checkout lacks (link inertials and collision shapes live in STL meshes
+that are git-ignored upstream: SURVEY.md finding 1).
+
+Reference data read (file:line are the places the numbers come from):
+  gym_kmanip/assets/_env_solo_arm.xml:1-18, _env_dual_arm.xml:1-27, _env_torso.xml:1-21
+  gym_kmanip/assets/arm_r_body.xml:1-76, arm_l_body.xml:1-76, torso_body.xml:1-182
+  gym_kmanip/assets/arm_r.xml:45-56, arm_l.xml:45-56, torso.xml:112-135 (actuators)
+  gym_kmanip/assets/scene.xml:14-21 (table, cube)
+
+Fixed (joint-less) bodies are folded into their moving parent, so every "link" in the output
+has exactly one 1-DoF joint and link index == dof index == qpos index (the cube's free joint
+comes last, as in the reference where scene.xml is included last).
+"""
+import json
+import math
+import os
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+REF_ASSETS = "/root/reference/gym_kmanip/assets"
+OUT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gym_kmanip_amd", "assets")
+
+
+# ---------------------------------------------------------------- quaternion helpers (wxyz)
+def qmul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([
+        aw * bw - ax * bx - ay * by - az * bz,
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw,
+    ])
+
+
+def qrot(q, v):
+    w, x, y, z = q
+    R = np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ])
+    return R @ np.asarray(v, dtype=float)
+
+
+def qconj(q):
+    return np.array([q[0], -q[1], -q[2], -q[3]])
+
+
+def euler_xyz_intrinsic(e):
+    """MuJoCo default eulerseq="xyz" (intrinsic): R = Rx(a) Ry(b) Rz(c)."""
+    a, b, c = e
+    qx = np.array([math.cos(a / 2), math.sin(a / 2), 0, 0])
+    qy = np.array([math.cos(b / 2), 0, math.sin(b / 2), 0])
+    qz = np.array([math.cos(c / 2), 0, 0, math.sin(c / 2)])
+    return qmul(qmul(qx, qy), qz)
+
+
+def fvec(s, n=None):
+    v = [float(t) for t in s.split()]
+    if n is not None:
+        assert len(v) == n, (s, n)
+    return np.array(v)
+
+
+def body_frame(el):
+    pos = fvec(el.get("pos", "0 0 0"), 3)
+    if el.get("quat") is not None:
+        q = fvec(el.get("quat"), 4)
+        q = q / np.linalg.norm(q)
+    elif el.get("euler") is not None:
+        q = euler_xyz_intrinsic(fvec(el.get("euler"), 3))
+    else:
+        q = np.array([1.0, 0, 0, 0])
+    return pos, q
+
+
+# ---------------------------------------------------------------- include expansion
+def load_expanded(path):
+    root = ET.parse(path).getroot()
+    _expand(root, os.path.dirname(path))
+    return root
+
+
+def _expand(el, base):
+    i = 0
+    children = list(el)
+    for ch in children:
+        if ch.tag == "include":
+            inc = ET.parse(os.path.join(base, ch.get("file"))).getroot()
+            _expand(inc, base)
+            idx = list(el).index(ch)
+            el.remove(ch)
+            for k, sub in enumerate(list(inc)):
+                el.insert(idx + k, sub)
+        else:
+            _expand(ch, base)
+        i += 1
+
+
+# ---------------------------------------------------------------- surrogate rules (build-owned)
+# The reference's link masses/inertias come from absent STL meshes.  Surrogate: mass by servo
+# class encoded in the joint name (MyActuator-class x8/x6/x4), a thin solid cylinder (r = 3 cm)
+# spanning from the joint origin to the farthest child attachment, isotropised so that the
+# tensor is frame independent.  These numbers are the build's, not the reference's.
+MASS_BY_CLASS = [("slider", 0.05), ("x8", 1.0), ("x6", 0.7), ("x4", 0.4)]
+LINK_RADIUS = 0.03
+MIN_LINK_LEN = 0.04
+FINGER_RADIUS = 0.010       # one sphere collider per gripper finger
+FINGER_OPEN_OFFSET = 0.035  # finger centre sits this far (along +slide axis) from the EE site at q=0
+TABLE_TOP_Z = 0.5           # table body origin z (scene.xml:14); surrogate = plane z = 0.5
+
+
+def link_mass(joint_name):
+    for key, m in MASS_BY_CLASS:
+        if key in joint_name:
+            return m
+    raise ValueError(joint_name)
+
+
+def build(env_xml, name):
+    root = load_expanded(os.path.join(REF_ASSETS, env_xml))
+    wb_list = root.findall("worldbody")
+    links = []
+    sites = {}
+    cameras = []
+    bodies_by_name = {}
+    cube = None
+    table = None
+
+    def walk(el, parent_link, rel_pos, rel_quat):
+        """el: <body>; (rel_pos, rel_quat): pose of el's PARENT frame in parent_link's frame."""
+        nonlocal cube, table
+        pos, quat = body_frame(el)
+        p = rel_pos + qrot(rel_quat, pos)
+        q = qmul(rel_quat, quat)
+        joints = el.findall("joint")
+        bname = el.get("name")
+        if bname == "cube":
+            inert = el.find("inertial")
+            g = el.find("geom")
+            j = joints[0]
+            cube = {
+                "pos0": p.tolist(), "quat0": q.tolist(),
+                "mass": float(inert.get("mass")),
+                "diaginertia": fvec(inert.get("diaginertia"), 3).tolist(),
+                "half_size": fvec(g.get("size"), 3).tolist(),
+                "frictionloss": float(j.get("frictionloss", "0")),
+                "condim": int(g.get("condim", "3")),
+                "friction": fvec(g.get("friction"), 3).tolist(),
+                "solref": fvec(g.get("solref"), 2).tolist(),
+                "solimp": fvec(g.get("solimp")).tolist(),
+            }
+            return
+        if bname == "table":
+            table = {"pos": p.tolist()}
+            return
+        if len(joints) == 0:
+            # fixed body: fold into parent link
+            me_link, me_p, me_q = parent_link, p, q
+        else:
+            assert len(joints) == 1
+            j = joints[0]
+            assert fvec(j.get("pos", "0 0 0"), 3).tolist() == [0, 0, 0]
+            idx = len(links)
+            links.append({
+                "name": bname,
+                "parent": parent_link,
+                "pos": p.tolist(), "quat": q.tolist(),
+                "joint": {
+                    "name": j.get("name"),
+                    "type": j.get("type", "hinge"),
+                    "axis": fvec(j.get("axis", "0 0 1"), 3).tolist(),
+                    "range": fvec(j.get("range"), 2).tolist(),
+                    "limited": j.get("limited", "false") == "true",
+                    "frictionloss": float(j.get("frictionloss", "0")),
+                },
+                "_attach": [],
+            })
+            if parent_link >= 0:
+                links[parent_link]["_attach"].append(p.tolist())
+            me_link, me_p, me_q = idx, np.zeros(3), np.array([1.0, 0, 0, 0])
+        bodies_by_name[bname] = (me_link, me_p.copy(), me_q.copy())
+        for s in el.findall("site"):
+            sp, sq = body_frame(s)
+            sites[s.get("name")] = {
+                "link": me_link,
+                "pos": (me_p + qrot(me_q, sp)).tolist(),
+                "quat": qmul(me_q, sq).tolist(),
+            }
+            if me_link >= 0 and len(joints) == 0:
+                links[me_link]["_attach"].append((me_p + qrot(me_q, sp)).tolist())
+        for c in el.findall("camera"):
+            cp, cq = body_frame(c)
+            cameras.append({
+                "name": c.get("name"), "link": me_link,
+                "pos": (me_p + qrot(me_q, cp)).tolist(),
+                "fovy": float(c.get("fovy", "45")),
+                "mode": c.get("mode", "fixed"), "target": c.get("target"),
+            })
+        for ch in el.findall("body"):
+            walk(ch, me_link, me_p, me_q)
+
+    for wb in wb_list:
+        for c in wb.findall("camera"):
+            cp, _ = body_frame(c)
+            cameras.append({"name": c.get("name"), "link": -1, "pos": cp.tolist(),
+                            "fovy": float(c.get("fovy", "45")), "mode": c.get("mode", "fixed"),
+                            "target": c.get("target")})
+        for b in wb.findall("body"):
+            walk(b, -1, np.zeros(3), np.array([1.0, 0, 0, 0]))
+
+    # actuators: actuator i must drive joint i (the reference indexes qpos with ctrl ids,
+    # env_sim.py:45,55)
+    acts = root.find("actuator").findall("position") if root.find("actuator") is not None else []
+    all_acts = []
+    for a_el in root.findall("actuator"):
+        all_acts += a_el.findall("position")
+    assert len(all_acts) == len(links), (len(all_acts), len(links))
+    for i, (a, l) in enumerate(zip(all_acts, links)):
+        assert a.get("joint") == l["joint"]["name"], (i, a.get("joint"), l["joint"]["name"])
+        l["actuator"] = {
+            "kp": float(a.get("kp")),
+            "ctrlrange": fvec(a.get("ctrlrange"), 2).tolist(),
+            "forcerange": fvec(a.get("forcerange"), 2).tolist() if a.get("forcelimited") == "true" else None,
+        }
+
+    # target bodies of cameras / sites folded to (link, pos)
+    targets = {}
+    for k, (lk, p, q) in bodies_by_name.items():
+        targets[k] = {"link": lk, "pos": p.tolist(), "quat": q.tolist()}
+    targets["table"] = {"link": -1, "pos": table["pos"], "quat": [1, 0, 0, 0]}
+
+    # ---- surrogate inertials
+    for l in links:
+        att = l.pop("_attach")
+        far = np.zeros(3)
+        for a_ in att:
+            if np.linalg.norm(a_) > np.linalg.norm(far):
+                far = np.array(a_)
+        length = max(np.linalg.norm(far), MIN_LINK_LEN)
+        if np.linalg.norm(far) < 1e-9:
+            com = np.array([0.0, 0.0, -0.5 * MIN_LINK_LEN])
+        else:
+            com = 0.5 * far
+        m = link_mass(l["joint"]["name"])
+        inertia = m * (3 * LINK_RADIUS ** 2 + length ** 2) / 12.0
+        l["inertial"] = {"mass": m, "com": com.tolist(), "diaginertia": [inertia] * 3}
+
+    # ---- surrogate finger colliders: one sphere per slider link, placed relative to the EE site
+    spheres = []
+    for i, l in enumerate(links):
+        if l["joint"]["type"] != "slide":
+            continue
+        par = l["parent"]
+        # EE site sharing this hand: the site whose link is the slider's parent or a sibling
+        # subtree of that parent (torso: site hangs off the x4_2 sibling link).
+        best = None
+        for sname, s in sites.items():
+            if not sname.endswith("_site_pos"):
+                continue
+            lk = s["link"]
+            sp = np.array(s["pos"])
+            # express site in slider-parent frame at zero configuration
+            while lk != par and lk >= 0:
+                sp = np.array(links[lk]["pos"]) + qrot(np.array(links[lk]["quat"]), sp)
+                lk = links[lk]["parent"]
+            if lk == par:
+                best = (sname, sp)
+        assert best is not None, l["name"]
+        sname, sp = best
+        rel = qrot(qconj(np.array(l["quat"])), sp - np.array(l["pos"]))  # site in slider frame @ q=0
+        centre = np.array([rel[0], rel[1], rel[2] + FINGER_OPEN_OFFSET])
+        spheres.append({"name": "finger_" + l["joint"]["name"].split("_hand_")[-1] + ("_r" if "right" in l["joint"]["name"] else "_l"),
+                        "link": i, "pos": centre.tolist(), "radius": FINGER_RADIUS,
+                        "site": sname})
+
+    spec = {
+        "name": name,
+        "source": env_xml,
+        "nlink": len(links),
+        "links": links,
+        "sites": sites,
+        "targets": targets,
+        "cameras": cameras,
+        "cube": cube,
+        "table": {"pos": table["pos"], "plane_z": TABLE_TOP_Z},
+        "spheres": spheres,
+        "option": {"timestep": 0.002, "gravity": [0, 0, -9.81]},
+        "surrogate_note": "link inertials, finger spheres and the table plane are build-owned "
+                          "surrogates (reference meshes absent); see tools/mjcf_extract.py",
+    }
+    return spec
+
+
+def main():
+    os.makedirs(OUT_DIR, exist_ok=True)
+    for xml, name in [("_env_solo_arm.xml", "solo_arm"), ("_env_dual_arm.xml", "dual_arm"),
+                      ("_env_torso.xml", "torso")]:
+        spec = build(xml, name)
+        out = os.path.join(OUT_DIR, name + ".json")
+        with open(out, "w") as f:
+            json.dump(spec, f, indent=1)
+        print(name, "links", spec["nlink"], "sites", list(spec["sites"]), "spheres",
+              [(s["name"], s["link"], np.round(s["pos"], 4).tolist()) for s in spec["spheres"]])
+
+
+if __name__ == "__main__":
+    sys.exit(main())
