@@ -1,0 +1,179 @@
+"""Oracle self-consistency for the MuJoCo-restated half (no reference numbers exist: SURVEY 8c):
+CRBA vs kinetic energy, bias vs potential gradient, Philox KAT, constraint sanity, trajectory
+fixture regression, reward/obs packing against a NumPy restatement of env_sim.py:110-179."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ENVS3, GOLDEN
+from gym_kmanip_amd import model as K
+from gym_kmanip_amd.model import compile_model
+from oracle import ik_scipy as S
+from oracle.oracle import Oracle
+
+
+def _state(cm, rng, spread=0.3):
+    nl = cm.nlink
+    qpos = np.zeros(cm.nq)
+    qpos[:nl] = np.array(cm.spec.q_pos_home, dtype=float) + rng.normal(0, spread, nl)
+    qpos[nl:nl + 3] = [0.2, 0.5, 0.8]
+    q = rng.normal(size=4); qpos[nl + 3:] = q / np.linalg.norm(q)
+    return qpos
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_crba_and_gravity_bias(env):
+    cm = compile_model(env); o = Oracle(cm, 1); nl = cm.nlink
+    arm = S.NumpyArm(cm.asset); L = cm.asset["links"]
+    rng = np.random.default_rng(0)
+
+    def coms(q):
+        xp, xq, _ = arm.fk(q)
+        return np.array([xp[i] + S.quat2mat(xq[i]) @ np.array(L[i]["inertial"]["com"]) for i in range(nl)]), xq
+
+    def kinetic(q, v, eps=1e-6):
+        c1, q1 = coms(q + eps * v); c0, q0 = coms(q - eps * v)
+        T = 0.0
+        for i in range(nl):
+            vc = (c1[i] - c0[i]) / (2 * eps)
+            dq = S.qmul(q1[i], np.array([q0[i][0], -q0[i][1], -q0[i][2], -q0[i][3]]))
+            w = 2 * dq[1:] / (2 * eps) * np.sign(dq[0])
+            T += 0.5 * L[i]["inertial"]["mass"] * vc @ vc + 0.5 * L[i]["inertial"]["diaginertia"][0] * w @ w
+        return T
+
+    def potential(q):
+        c, _ = coms(q)
+        return sum(L[i]["inertial"]["mass"] * 9.81 * c[i, 2] for i in range(nl))
+
+    for _ in range(3):
+        qpos = _state(cm, rng)
+        d = o.dynamics(qpos, np.zeros(cm.nv), qpos[:nl])
+        M = d["M"][:nl, :nl]
+        assert np.abs(M - M.T).max() < 1e-12 and np.linalg.eigvalsh(M).min() > 0
+        v = rng.normal(size=nl)
+        assert abs(0.5 * v @ M @ v - kinetic(qpos[:nl], v)) < 1e-7
+        g = np.array([(potential(qpos[:nl] + 1e-6 * e) - potential(qpos[:nl] - 1e-6 * e)) / 2e-6 for e in np.eye(nl)])
+        assert np.abs(d["bias"][:nl] - g).max() < 1e-6
+        # cube block: diag mass/inertia, gravity
+        assert np.allclose(np.diag(d["M"])[nl:], [0.05] * 3 + [0.002] * 3)
+        assert np.allclose(d["bias"][nl:nl + 3], [0, 0, 0.05 * 9.81])
+
+
+def test_coriolis_power_balance():
+    """d/dt (T) = qvel . (tau - g) for the unconstrained arm: checks velocity-product bias terms via
+    qacc_smooth = M^-1 (tau - bias): qvel . (M qacc + bias - tau) == 0 and dT/dt numerically."""
+    cm = compile_model("KManipSoloArm"); o = Oracle(cm, 1); nl = cm.nlink
+    rng = np.random.default_rng(5)
+    qpos = _state(cm, rng); qvel = np.zeros(cm.nv); qvel[:nl] = rng.normal(0, 2, nl)
+    d0 = o.dynamics(qpos, qvel, qpos[:nl])
+    M = d0["M"][:nl, :nl]
+    # energy E = T + V must be conserved by (qacc with tau=0): dE/dt = v.(M a) + 0.5 v.Mdot v + v.g = 0
+    d_no_v = o.dynamics(qpos, np.zeros(cm.nv), qpos[:nl])
+    g = d_no_v["bias"][:nl]; c = d0["bias"][:nl] - g   # Coriolis/centrifugal
+    eps = 1e-6
+    qp = qpos.copy(); qp[:nl] += eps * qvel[:nl]; qm = qpos.copy(); qm[:nl] -= eps * qvel[:nl]
+    Mdot = (o.dynamics(qp, np.zeros(cm.nv), qp[:nl])["M"][:nl, :nl] - o.dynamics(qm, np.zeros(cm.nv), qm[:nl])["M"][:nl, :nl]) / (2 * eps)
+    v = qvel[:nl]
+    assert abs(v @ c - 0.5 * v @ Mdot @ v) < 1e-5 * max(1.0, abs(v @ c))
+
+
+def test_philox_kat():
+    kat = np.load(os.path.join(GOLDEN, "philox_kat.npz"))["kat"]
+    o = Oracle(compile_model("KManipSoloArm"), 1)
+    for row in kat:
+        assert np.array_equal(o.philox(row[:4], row[4:6]), row[6:])
+
+
+def test_reset_matches_initialize_episode():
+    cm = compile_model("KManipDualArm"); o = Oracle(cm, 8, seed=3, env_id_offset=40)
+    o.reset()
+    qpos, qvel, ctrl, warm, step = o.get_state()
+    nl = cm.nlink
+    assert np.array_equal(qpos[:, :nl], np.tile(np.array(cm.spec.q_pos_home, dtype=np.float64), (8, 1)))
+    assert np.array_equal(ctrl, qpos[:, :nl]) and not qvel.any() and not step.any()
+    lo, hi = K.CUBE_SPAWN_RANGE[:, 0], K.CUBE_SPAWN_RANGE[:, 1]
+    assert (qpos[:, nl:nl + 3] >= lo).all() and (qpos[:, nl:nl + 3] < hi).all()
+    assert len(np.unique(qpos[:, nl])) == 8                      # independent streams
+    assert np.array_equal(qpos[:, nl + 3:], np.tile([1.0, 0, 0, 0], (8, 1)))
+    # shard-independent: env 44 of a differently sharded oracle == env 4 here
+    o2 = Oracle(cm, 1, seed=3, env_id_offset=44); o2.reset()
+    assert np.array_equal(o2.get_state()[0][0], qpos[4])
+    # warmstart = unactuated forward acceleration; cube in free fall
+    assert np.allclose(warm[:, nl:nl + 3], [0, 0, -9.81], atol=0.25)
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_obs_reward_packing(env):
+    """NumPy restatement of env_sim.py:110-146 and :148-179 on the stepped state."""
+    cm = compile_model(env, auto_reset=False); o = Oracle(cm, 3, seed=1)
+    o.reset()
+    rng = np.random.default_rng(2)
+    arm = S.NumpyArm(cm.asset)
+    rg = np.array([l["joint"]["range"] for l in cm.asset["links"]], dtype=float)
+    for k in range(3):
+        obs, rew, done = o.step(rng.uniform(-1, 1, (3, cm.act_dim)).astype(np.float32))
+    qpos, qvel, ctrl, warm, step = o.get_state()
+    nl = cm.nlink
+    for e in range(3):
+        q_pos = np.clip((qpos[e, :nl] - rg[:, 0]) / (rg[:, 1] - rg[:, 0]), -1, 1)
+        q_vel = np.clip(qvel[e] / K.MAX_Q_VEL, -1, 1)[:nl]
+        cube = np.clip((qpos[e, -7:-4] - K.CUBE_SPAWN_RANGE[:, 0]) / (K.CUBE_SPAWN_RANGE[:, 1] - K.CUBE_SPAWN_RANGE[:, 0]), -1, 1)
+        exp = np.concatenate([q_pos, q_vel, cube, qpos[e, -4:]])
+        assert np.abs(obs[e] - exp).max() < 1e-15
+        xp, xq, _ = arm.fk(qpos[e])
+        r = -K.REWARD_VEL_PENALTY * np.linalg.norm(qvel[e])
+        for side in ["l", "r"]:
+            if "grip_" + side in cm.spec.act_list:
+                p, _ = arm.site("ee%s_site_pos" % side, xp, xq)
+                r += K.REWARD_GRIP_DIST * (1 / (np.linalg.norm(qpos[e, nl:nl + 3] - p) + K.EPSILON))
+        assert abs(rew[e] - r) < 1e-13
+    assert (step == 3).all() and not done.any()
+
+
+def test_constraint_rows_sanity():
+    """Cube resting on the table: 4 corner contacts x 6 pyramid edges + friction-loss rows; normal
+    acceleration of the converged solve supports the cube (|qacc_z| << g)."""
+    cm = compile_model("KManipSoloArm"); o = Oracle(cm, 1); nl = cm.nlink
+    qpos = np.zeros(cm.nq); qpos[:nl] = cm.spec.q_pos_home
+    qpos[nl:nl + 3] = [0.2, 0.6, 0.5 + 0.02 - 1e-4]; qpos[nl + 3] = 1
+    d = o.dynamics(qpos, np.zeros(cm.nv), qpos[:nl])
+    n_floss = 2 + 6
+    assert d["nefc"] == n_floss + 4 * 6
+    assert (d["R"] > 0).all()
+    assert abs(d["qacc_smooth"][nl + 2] + 9.81) < 1e-9
+    assert abs(d["qacc"][nl + 2]) < 2.0
+    # joint limit row appears when a joint is pushed past its range
+    qpos[1] = -0.01
+    assert o.dynamics(qpos, np.zeros(cm.nv), qpos[:nl])["nefc"] == n_floss + 1 + 4 * 6
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_trajectory_fixture_regression(env):
+    """The committed 66-step trajectories (incl. the auto-reset at step 64) replay bit-for-bit-ish on
+    this machine's build of the oracle (guards the oracle itself against accidental edits)."""
+    g = np.load(os.path.join(GOLDEN, "traj_%s.npz" % env))
+    cm = compile_model(env, auto_reset=True)
+    o = Oracle(cm, g["act"].shape[1], seed=int(g["seed"]), env_id_offset=int(g["env_id_offset"]))
+    obs0 = o.reset()
+    assert np.abs(obs0 - g["obs0"]).max() < 1e-12
+    for k in range(g["act"].shape[0]):
+        obs, rew, done = o.step(g["act"][k])
+        qpos, qvel, ctrl, warm, step = o.get_state()
+        assert np.abs(qpos - g["qpos"][k]).max() < 1e-7, k
+        assert np.abs(qvel - g["qvel"][k]).max() < 1e-5, k
+        assert np.abs(obs - g["obs"][k]).max() < 1e-6 and np.abs(rew - g["rew"][k]).max() < 1e-6
+        assert np.array_equal(done, g["done"][k])
+        assert np.array_equal(o.get_diag()[0], g["mask"][k])
+    assert g["done"][63].all() and not g["done"][62].any()
+
+
+def test_multithreaded_batch_equals_serial():
+    cm = compile_model("KManipSoloArm"); rng = np.random.default_rng(0)
+    a = Oracle(cm, 16, seed=5); b = Oracle(cm, 16, seed=5)
+    a.reset(); b.reset()
+    for k in range(3):
+        act = rng.uniform(-1, 1, (16, 7)).astype(np.float32)
+        oa = a.step(act, nthreads=1); ob = b.step(act, nthreads=4)
+        for x, y in zip(oa, ob):
+            assert np.array_equal(x, y)

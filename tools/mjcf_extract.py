@@ -114,6 +114,11 @@ def _expand(el, base):
 MASS_BY_CLASS = [("slider", 0.05), ("x8", 1.0), ("x6", 0.7), ("x4", 0.4)]
 LINK_RADIUS = 0.03
 MIN_LINK_LEN = 0.04
+# The reference XML has no armature/damping and kp = 1000 position servos integrated with explicit
+# Euler at dt = 2 ms: that is only stable if every actuated direction has inertia > kp*dt^2/4 = 1e-3.
+# The thin-cylinder tensor alone is below that for the wrist links, so each hinge link gets an extra
+# isotropic term standing in for the (unknown) mesh bulk + reflected rotor inertia of a geared servo.
+HINGE_EXTRA_INERTIA = 0.01
 FINGER_RADIUS = 0.010       # one sphere collider per gripper finger
 FINGER_OPEN_OFFSET = 0.035  # finger centre sits this far (along +slide axis) from the EE site at q=0
 TABLE_TOP_Z = 0.5           # table body origin z (scene.xml:14); surrogate = plane z = 0.5
@@ -253,6 +258,8 @@ def build(env_xml, name):
             com = 0.5 * far
         m = link_mass(l["joint"]["name"])
         inertia = m * (3 * LINK_RADIUS ** 2 + length ** 2) / 12.0
+        if l["joint"]["type"] != "slide":
+            inertia += HINGE_EXTRA_INERTIA
         l["inertial"] = {"mass": m, "com": com.tolist(), "diaginertia": [inertia] * 3}
 
     # ---- surrogate finger colliders: one sphere per slider link, placed relative to the EE site
