@@ -1,0 +1,291 @@
+// kmanip_api.hip -- host side of the C ABI declared in include/kmanip.h.
+// Owns the device model, the struct-of-arrays env state and the launch sequence of one control step:
+//   k_prepare (ctrl float32 round trip, qpos_ik = qpos)  ->  k_before_step (decode + IK)  ->  k_step (physics,
+//   reward, obs, done, auto-reset).  No CPU fallback exists: every entry point fails loudly without a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kmanip_device.hpp"
+
+#define KM_VERSION "kmanip-hip 0.1 (gfx950, f64)"
+
+static thread_local std::string g_create_error;
+
+struct KHandle_ {
+  KModelDesc desc;
+  KDeviceModel* dmodel = nullptr;
+  KDeviceState st{};
+  int device = 0;
+  int num_envs = 0;
+  std::string err;
+  std::vector<hipEvent_t> ev;   // 3 events per timed step
+  bool timing = false;
+  int timed_steps = 0;
+  std::vector<void*> allocs;
+};
+
+#define HIPCHK(h, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+      return (int)e_ ? (int)e_ : -1;                                                        \
+    }                                                                                       \
+  } while (0)
+
+static int validate(const KModelDesc* d, std::string& err) {
+  if (d->nlink != 10 && d->nlink != 20) { err = "nlink must be 10 or 20 (KManipSoloArm / DualArm / Torso)"; return -1; }
+  if (d->nsphere < 0 || d->nsphere > KM_MAX_SPHERES || d->nsphere > 2 * (d->nlink / 10)) { err = "too many finger spheres"; return -1; }
+  if (d->obs_dim != 2 * d->nlink + 7) { err = "obs_dim != 2*nlink+7"; return -1; }
+  if (d->n_sub_steps < 1 || d->solver_iterations < 0) { err = "bad n_sub_steps / solver_iterations"; return -1; }
+  for (int i = 0; i < d->nlink; i++)
+    if (d->link_parent[i] >= i || d->link_parent[i] < -1) { err = "links must be ordered parents-first"; return -1; }
+  int nik = 0;
+  for (int a = 0; a < KM_MAX_ARMS; a++) {
+    if (!d->arm_present[a]) continue;
+    if (d->arm_nq[a] != 6 && d->arm_nq[a] != 7) { err = "arm_nq must be 6 or 7"; return -1; }
+    if (nik && nik != d->arm_nq[a]) { err = "both arms must have the same number of IK unknowns"; return -1; }
+    nik = d->arm_nq[a];
+  }
+  return 0;
+}
+
+// ancestor masks and IK chains (derived data, kept out of the ABI struct)
+static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
+  memset(x, 0, sizeof(*x));
+  for (int i = 0; i < d->nlink; i++) {
+    uint32_t mk = 0;
+    for (int j = i; j >= 0; j = d->link_parent[j]) mk |= 1u << j;
+    x->anc_mask[i] = mk;
+  }
+  for (int a = 0; a < KM_MAX_ARMS; a++) {
+    if (!d->arm_present[a]) continue;
+    int chain[KM_MAX_LINKS], n = 0;
+    for (int j = d->arm_site_link[a]; j >= 0; j = d->link_parent[j]) chain[n++] = j;
+    if (n > KM_MAX_CHAIN) { err = "IK chain longer than KM_MAX_CHAIN"; return -1; }
+    x->chain_len[a] = n;
+    for (int k = 0; k < n; k++) {
+      int l = chain[n - 1 - k];
+      x->chain_link[a][k] = l;
+      int xi = -1;
+      for (int i = 0; i < d->arm_nq[a]; i++) if (d->arm_q_id[a][i] == l) xi = i;
+      x->chain_xidx[a][k] = xi;
+      // the kernels rely on: unknown i sits at chain position i, fixed joints (if any) come after
+      if ((k < d->arm_nq[a]) != (xi == k)) { err = "IK mask must be the leading links of the site's chain, in order"; return -1; }
+    }
+  }
+  return 0;
+}
+
+extern "C" {
+
+int kmanip_model_desc_size(void) { return (int)sizeof(KModelDesc); }
+const char* kmanip_version(void) { return KM_VERSION; }
+
+int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t seed, int64_t env_id_offset, KHandle* out) {
+  if (!desc || !out || num_envs <= 0) { g_create_error = "kmanip_create: bad arguments"; return -1; }
+  KHandle_* h = new (std::nothrow) KHandle_();
+  if (!h) { g_create_error = "out of memory"; return -1; }
+  h->desc = *desc;
+  h->device = device;
+  h->num_envs = num_envs;
+  KDeviceModel hm;
+  hm.d = *desc;
+  if (validate(desc, h->err) != 0 || build_aux(desc, &hm.x, h->err) != 0) { g_create_error = h->err; delete h; return -2; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0 || device >= ndev) {
+    g_create_error = std::string("kmanip_create: no usable HIP device (") + hipGetErrorString(e) + "); this library has no CPU path";
+    delete h; return -3;
+  }
+#define CR(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e2); kmanip_destroy(h); return -4; } } while (0)
+  CR(hipSetDevice(device));
+  const int nl = desc->nlink, nv = nl + 6, nq = nl + 7;
+  const size_t N = (size_t)num_envs;
+  auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
+    hipError_t r = hipMalloc(p, bytes);
+    if (r == hipSuccess) { h->allocs.push_back(*p); r = hipMemset(*p, 0, bytes); }
+    return r;
+  };
+  CR(dalloc((void**)&h->dmodel, sizeof(KDeviceModel)));
+  CR(hipMemcpy(h->dmodel, &hm, sizeof(KDeviceModel), hipMemcpyHostToDevice));
+  CR(dalloc((void**)&h->st.qpos, sizeof(double) * nq * N));
+  CR(dalloc((void**)&h->st.qvel, sizeof(double) * nv * N));
+  CR(dalloc((void**)&h->st.ctrl, sizeof(double) * nl * N));
+  CR(dalloc((void**)&h->st.warm, sizeof(double) * nv * N));
+  CR(dalloc((void**)&h->st.qpos_ik, sizeof(double) * nl * N));
+  CR(dalloc((void**)&h->st.step_idx, sizeof(int32_t) * N));
+  CR(dalloc((void**)&h->st.episode, sizeof(int32_t) * N));
+  CR(dalloc((void**)&h->st.contact_mask, sizeof(uint32_t) * N));
+  CR(dalloc((void**)&h->st.ik_nfev, sizeof(int32_t) * 2 * N));
+  CR(dalloc((void**)&h->st.ik_status, sizeof(int32_t) * 2 * N));
+  // episode counter starts at -1 so that the first reset is episode 0 (matches the oracle's ko_reset(..., 0))
+  CR(hipMemset(h->st.episode, 0xFF, sizeof(int32_t) * N));
+  h->st.num_envs = num_envs;
+  h->st.env_id_offset = env_id_offset;
+  h->st.seed = seed;
+#undef CR
+  *out = h;
+  return 0;
+}
+
+void kmanip_destroy(KHandle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  delete h;
+}
+
+const char* kmanip_last_error(KHandle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+int kmanip_num_envs(KHandle h) { return h ? h->num_envs : 0; }
+
+int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stream) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));
+  kmanip_launch_reset(h->dmodel, h->desc, h->st, mask_dev, 0, obs_dev, (hipStream_t)stream);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, void* stream) {
+  if (!h || !act_dev || !obs_dev || !reward_dev || !done_dev) { if (h) h->err = "kmanip_step: null buffer"; return -1; }
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
+  hipEvent_t* ev = tm ? &h->ev[3 * (size_t)h->timed_steps] : nullptr;
+  if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
+  kmanip_launch_ik(h->dmodel, h->desc, h->st, act_dev, s);
+  if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
+  kmanip_launch_step(h->dmodel, h->desc, h->st, obs_dev, reward_dev, done_dev, s);
+  if (tm) { HIPCHK(h, hipEventRecord(ev[2], s)); h->timed_steps++; }
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int kmanip_enable_timing(KHandle h, int enable) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (enable && h->ev.empty()) {
+    h->ev.resize(3 * KM_TIMING_SLOTS, nullptr);
+    for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
+  }
+  h->timing = enable != 0;
+  h->timed_steps = 0;
+  return 0;
+}
+int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, int32_t* nsteps) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  double a = 0, b = 0;
+  for (int k = 0; k < h->timed_steps; k++) {
+    float m1 = 0, m2 = 0;
+    HIPCHK(h, hipEventElapsedTime(&m1, h->ev[3 * k], h->ev[3 * k + 1]));
+    HIPCHK(h, hipEventElapsedTime(&m2, h->ev[3 * k + 1], h->ev[3 * k + 2]));
+    a += m1; b += m2;
+  }
+  if (ik_ms_sum) *ik_ms_sum = a;
+  if (dyn_ms_sum) *dyn_ms_sum = b;
+  if (nsteps) *nsteps = h->timed_steps;
+  h->timed_steps = 0;
+  return 0;
+}
+
+// env-major host <-> component-major device transposes
+static int pull(KHandle h, const double* dev, double* host, int ncomp) {
+  if (!host) return 0;
+  const size_t N = (size_t)h->num_envs;
+  std::vector<double> tmp(N * ncomp);
+  HIPCHK(h, hipMemcpy(tmp.data(), dev, sizeof(double) * N * ncomp, hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < N; e++) for (int k = 0; k < ncomp; k++) host[e * ncomp + k] = tmp[(size_t)k * N + e];
+  return 0;
+}
+static int push(KHandle h, double* dev, const double* host, int ncomp) {
+  if (!host) return 0;
+  const size_t N = (size_t)h->num_envs;
+  std::vector<double> tmp(N * ncomp);
+  for (size_t e = 0; e < N; e++) for (int k = 0; k < ncomp; k++) tmp[(size_t)k * N + e] = host[e * ncomp + k];
+  HIPCHK(h, hipMemcpy(dev, tmp.data(), sizeof(double) * N * ncomp, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int kmanip_get_state(KHandle h, double* qpos, double* qvel, double* ctrl, double* qacc_warm, int32_t* step_idx) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  const int nl = h->desc.nlink;
+  int rc = 0;
+  if ((rc = pull(h, h->st.qpos, qpos, nl + 7))) return rc;
+  if ((rc = pull(h, h->st.qvel, qvel, nl + 6))) return rc;
+  if ((rc = pull(h, h->st.ctrl, ctrl, nl))) return rc;
+  if ((rc = pull(h, h->st.warm, qacc_warm, nl + 6))) return rc;
+  if (step_idx) HIPCHK(h, hipMemcpy(step_idx, h->st.step_idx, sizeof(int32_t) * h->num_envs, hipMemcpyDeviceToHost));
+  return 0;
+}
+int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const double* ctrl, const double* qacc_warm,
+                     const int32_t* step_idx) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  const int nl = h->desc.nlink;
+  int rc = 0;
+  if ((rc = push(h, h->st.qpos, qpos, nl + 7))) return rc;
+  if ((rc = push(h, h->st.qvel, qvel, nl + 6))) return rc;
+  if ((rc = push(h, h->st.ctrl, ctrl, nl))) return rc;
+  if ((rc = push(h, h->st.warm, qacc_warm, nl + 6))) return rc;
+  if (step_idx) HIPCHK(h, hipMemcpy(h->st.step_idx, step_idx, sizeof(int32_t) * h->num_envs, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  const size_t N = (size_t)h->num_envs;
+  if (contact_mask) HIPCHK(h, hipMemcpy(contact_mask, h->st.contact_mask, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
+  std::vector<int32_t> tmp(2 * N);
+  if (ik_nfev) {
+    HIPCHK(h, hipMemcpy(tmp.data(), h->st.ik_nfev, sizeof(int32_t) * 2 * N, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < N; e++) { ik_nfev[2 * e] = tmp[e]; ik_nfev[2 * e + 1] = tmp[N + e]; }
+  }
+  if (ik_status) {
+    HIPCHK(h, hipMemcpy(tmp.data(), h->st.ik_status, sizeof(int32_t) * 2 * N, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < N; e++) { ik_status[2 * e] = tmp[e]; ik_status[2 * e + 1] = tmp[N + e]; }
+  }
+  return 0;
+}
+
+int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos, const double* goal_quat, double* q_out,
+              int32_t* nfev, int32_t* status) {
+  if (!h || arm < 0 || arm >= KM_MAX_ARMS || !h->desc.arm_present[arm] || n <= 0) { if (h) h->err = "kmanip_ik: bad arguments"; return -1; }
+  HIPCHK(h, hipSetDevice(h->device));
+  const int nq = h->desc.nlink + 7, nik = h->desc.arm_nq[arm];
+  double *dq = nullptr, *dgp = nullptr, *dgq = nullptr, *dqo = nullptr;
+  int32_t *dnf = nullptr, *dst = nullptr;
+  HIPCHK(h, hipMalloc((void**)&dq, sizeof(double) * n * nq));
+  HIPCHK(h, hipMalloc((void**)&dgp, sizeof(double) * n * 3));
+  HIPCHK(h, hipMalloc((void**)&dgq, sizeof(double) * n * 4));
+  HIPCHK(h, hipMalloc((void**)&dqo, sizeof(double) * n * nik));
+  HIPCHK(h, hipMalloc((void**)&dnf, sizeof(int32_t) * n));
+  HIPCHK(h, hipMalloc((void**)&dst, sizeof(int32_t) * n));
+  HIPCHK(h, hipMemcpy(dq, qpos, sizeof(double) * n * nq, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dgp, goal_pos, sizeof(double) * n * 3, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dgq, goal_quat, sizeof(double) * n * 4, hipMemcpyHostToDevice));
+  kmanip_launch_ik_standalone(h->dmodel, h->desc, arm, n, dq, dgp, dgq, dqo, dnf, dst, nullptr);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(qpos, dq, sizeof(double) * n * nq, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(q_out, dqo, sizeof(double) * n * nik, hipMemcpyDeviceToHost));
+  if (nfev) HIPCHK(h, hipMemcpy(nfev, dnf, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(h, hipMemcpy(status, dst, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dq); (void)hipFree(dgp); (void)hipFree(dgq); (void)hipFree(dqo); (void)hipFree(dnf); (void)hipFree(dst);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// kmanip_device.hpp -- device-side helpers shared by the IK and dynamics kernels (gfx950, wave64).
+// Arithmetic type is double: the reference computes in float64 (MuJoCo mjtNum, OBS_DTYPE
+// gym_kmanip/__init__.py:50) and MI355X runs FP64 FMA at half the FP32 vector rate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kmanip.h"
+
+#define KM_MAX_CHAIN 8
+#define MJ_MINVAL 1e-15
+#define MJ_MINIMP 0.0001
+#define MJ_MAXIMP 0.9999
+
+// Host-precomputed lookup data that is derived from KModelDesc (kept out of the ABI struct).
+struct KModelAux {
+  uint32_t anc_mask[KM_MAX_LINKS];           // bit j set <=> dof j is link i or one of its ancestors
+  int32_t chain_len[KM_MAX_ARMS];            // IK kinematic chain root -> site link
+  int32_t chain_link[KM_MAX_ARMS][KM_MAX_CHAIN];
+  int32_t chain_xidx[KM_MAX_ARMS][KM_MAX_CHAIN];  // index into the IK unknowns, -1 = fixed at current qpos
+};
+
+struct KDeviceModel {
+  KModelDesc d;
+  KModelAux x;
+};
+
+typedef double real;
+
+__device__ __forceinline__ real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(real* r, const real* a, const real* b) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+// mju_normalize3
+__device__ __forceinline__ real normalize3(real* v) {
+  real n = sqrt(dot3(v, v));
+  if (n < MJ_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; }
+  else { real inv = 1.0 / n; v[0] *= inv; v[1] *= inv; v[2] *= inv; }
+  return n;
+}
+__device__ __forceinline__ void normalize4(real* q) {
+  real n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MJ_MINVAL) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; }
+  else { real inv = 1.0 / n; q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv; }
+}
+__device__ __forceinline__ void qmul(real* r, const real* a, const real* b) {
+  real w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  real x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  real y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  real z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+__device__ __forceinline__ void quat2mat(real* m, const real* q) {
+  real w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void mat_vec3(real* r, const real* m, const real* v) {
+  real x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  real y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  real z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void matT_vec3(real* r, const real* m, const real* v) {
+  real x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  real y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  real z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void axis_angle2quat(real* q, const real* axis, real angle) {
+  if (angle == 0) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
+  real s, c;
+  sincos(angle * 0.5, &s, &c);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+// mju_mat2Quat
+__device__ __forceinline__ void mat2quat(real* q, const real* m) {
+  if (m[0] + m[4] + m[8] > 0) {
+    q[0] = 0.5 * sqrt(1 + m[0] + m[4] + m[8]);
+    real s = 0.25 / q[0];
+    q[1] = s * (m[7] - m[5]); q[2] = s * (m[2] - m[6]); q[3] = s * (m[3] - m[1]);
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    q[1] = 0.5 * sqrt(1 + m[0] - m[4] - m[8]);
+    real s = 0.25 / q[1];
+    q[0] = s * (m[7] - m[5]); q[2] = s * (m[1] + m[3]); q[3] = s * (m[2] + m[6]);
+  } else if (m[4] > m[8]) {
+    q[2] = 0.5 * sqrt(1 - m[0] + m[4] - m[8]);
+    real s = 0.25 / q[2];
+    q[0] = s * (m[2] - m[6]); q[1] = s * (m[1] + m[3]); q[3] = s * (m[5] + m[7]);
+  } else {
+    q[3] = 0.5 * sqrt(1 - m[0] - m[4] + m[8]);
+    real s = 0.25 / q[3];
+    q[0] = s * (m[3] - m[1]); q[1] = s * (m[2] + m[6]); q[2] = s * (m[5] + m[7]);
+  }
+  normalize4(q);
+}
+// mju_subQuat(res, qa, qb)
+__device__ __forceinline__ void sub_quat(real* res, const real* qa, const real* qb) {
+  real qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]}, qd[4];
+  qmul(qd, qn, qa);
+  real ax[3] = {qd[1], qd[2], qd[3]};
+  real sn = normalize3(ax);
+  real speed = 2 * atan2(sn, qd[0]);
+  if (speed > M_PI) speed -= 2 * M_PI;
+  res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter-based RNG for the cube spawn
+__device__ __host__ inline void philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __host__ inline double u53(uint32_t hi, uint32_t lo) {
+  return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) / 9007199254740992.0;
+}
+
+// Device state, struct-of-arrays over envs: element (k, env) of an [n_k, num_envs] array is at
+// k * num_envs + env, so a wave reading component k for consecutive envs is fully coalesced.
+struct KDeviceState {
+  double* qpos;       // [nq][N]
+  double* qvel;       // [nv][N]
+  double* ctrl;       // [nu][N]
+  double* warm;       // [nv][N]  qacc_warmstart
+  double* qpos_ik;    // [nl][N]  robot qpos after the IK's last evaluation (teleport, ik_mujoco.py:34,67)
+  int32_t* step_idx;  // [N]
+  int32_t* episode;   // [N]
+  uint32_t* contact_mask;  // [N]
+  int32_t* ik_nfev;   // [2][N]
+  int32_t* ik_status; // [2][N]
+  int num_envs;
+  int64_t env_id_offset;
+  uint64_t seed;
+};
+
+void kmanip_launch_ik(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act,
+                      hipStream_t stream);
+void kmanip_launch_ik_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
+                                 const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
+                                 int32_t* status, hipStream_t stream);
+void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs,
+                        double* reward, uint8_t* done, hipStream_t stream);
+void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const uint8_t* mask,
+                         int use_done_bits, double* obs, hipStream_t stream);

@@ -1,0 +1,208 @@
+"""`env_hip` -- the MI355X backend behind gym-kmanip's own backend seam.
+
+The reference picks a backend by calling a module-level `new(gym_env)` and then only ever calls
+k_reset / k_step / k_render / k_close on the returned object (reference gym_kmanip/env_base.py:192-200,
+:217,:221,:242,:266); `env_sim.new` (env_sim.py:206-211) and `env_real.new` are the two existing
+backends.  `env_hip.new(gym_env, num_envs, device)` is the third: same attribute reads from `gym_env`
+(mjcf_filename, seed, q_len, q_pos_home, q_id_*_mask, ctrl_id_*_grip, obs_list, act_list), same return
+tuple `(terminated, reward, discount, observation, sim_time)` (env_sim.py:194,200), every element with a
+leading [num_envs] dimension and the observation an OrderedDict in obs_list order.
+
+Buffers are PyTorch-ROCm tensors (device memory + streams only; all arithmetic is in the HIP library).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Optional
+
+import numpy as np
+
+from . import lib as _libmod
+from .model import (CONTROL_TIMESTEP, ENV_SPECS, KM_ACT_KEYS, CompiledModel, EnvSpec, compile_model)
+
+MJCF_TO_ASSET = {"_env_solo_arm.xml": "solo_arm", "_env_dual_arm.xml": "dual_arm", "_env_torso.xml": "torso"}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class KManipEnvHip:
+    """Batched simulated backend.  One instance <-> one device <-> one stream at a time."""
+
+    def __init__(self, cm: CompiledModel, num_envs: int = 1, device: int = 0, seed: int = 0,
+                 env_id_offset: int = 0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _libmod.KManipError("env_hip needs a HIP device (torch.cuda.is_available() is False); "
+                                      "there is no CPU fallback")
+        self.L = _libmod.load()
+        self.cm = cm
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", device)
+        self.device_index = device
+        h = C.c_void_p()
+        rc = self.L.kmanip_create(C.byref(cm.desc), self.num_envs, device, C.c_uint64(seed),
+                                  C.c_int64(env_id_offset), C.byref(h))
+        if rc != 0:
+            raise _libmod.KManipError("kmanip_create failed (%d): %s" % (rc, self.L.kmanip_last_error(None).decode()))
+        self.h = h
+        n = self.num_envs
+        self.obs = torch.zeros((n, cm.obs_dim), dtype=torch.float64, device=self.device)
+        self.reward = torch.zeros((n,), dtype=torch.float64, device=self.device)
+        self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        self.act = torch.zeros((n, cm.act_dim), dtype=torch.float32, device=self.device)
+        self.sim_step = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _libmod.KManipError("%s failed (%d): %s" % (what, rc, self.L.kmanip_last_error(self.h).decode()))
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def obs_dict(self, obs=None) -> "OrderedDict":
+        """Zero-copy per-key views of the flat observation, in obs_list order (env_sim.py:111-139)."""
+        obs = self.obs if obs is None else obs
+        out = OrderedDict()
+        for key in self.cm.spec.obs_list:
+            if key in self.cm.obs_slices:
+                out[key] = obs[:, self.cm.obs_slices[key]]
+        return out
+
+    def pack_action(self, action) -> "object":
+        """dict of arrays keyed like the reference action space (env_base.py:151-188) -> flat [N, act_dim]."""
+        torch = _torch()
+        if isinstance(action, dict):
+            flat = np.zeros((self.num_envs, self.cm.act_dim), dtype=np.float32)
+            for key, sl in self.cm.act_slices.items():
+                if key in action:
+                    flat[:, sl] = np.asarray(action[key], dtype=np.float32).reshape(self.num_envs, -1)
+            return torch.from_numpy(flat).to(self.device)
+        if isinstance(action, torch.Tensor):
+            return action.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, self.cm.act_dim).contiguous()
+        return torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(self.num_envs, self.cm.act_dim),
+                               device=self.device)
+
+    # ------------------------------------------------------------------ the seam (k_* methods)
+    def k_reset(self, mask=None):
+        """KManipEnvSim.k_reset (env_sim.py:190-194): (terminated, reward, discount, observation, sim_time)."""
+        torch = _torch()
+        mp = None
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            mp = C.c_void_p(mask.data_ptr())
+        self._check(self.L.kmanip_reset(self.h, mp, C.c_void_p(self.obs.data_ptr()), self._stream()), "kmanip_reset")
+        terminated = torch.zeros((self.num_envs,), dtype=torch.bool, device=self.device)
+        return terminated, None, None, self.obs_dict(), 0.0
+
+    def step_flat(self, act):
+        """Raw batched step on device tensors: returns (obs, reward, done) views of the handle's buffers."""
+        self._check(self.L.kmanip_step(self.h, C.c_void_p(act.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                       C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                                       self._stream()), "kmanip_step")
+        return self.obs, self.reward, self.done
+
+    def k_step(self, action):
+        """KManipEnvSim.k_step (env_sim.py:196-200).  `terminated` is always False in the reference
+        (get_termination -> None); the TimeLimit truncation and the divergence flag are in `self.done`."""
+        torch = _torch()
+        act = self.pack_action(action)
+        self.step_flat(act)
+        terminated = torch.zeros((self.num_envs,), dtype=torch.bool, device=self.device)
+        discount = torch.ones((self.num_envs,), dtype=torch.float64, device=self.device)
+        step_idx = self.get_state()[4]
+        sim_time = step_idx.astype(np.float64) * CONTROL_TIMESTEP
+        return terminated, self.reward, discount, self.obs_dict(), sim_time
+
+    def k_render(self, cam):
+        raise NotImplementedError("camera rendering is a 'next' row (SURVEY.md 8f rank 1), not built yet")
+
+    def k_close(self):
+        if getattr(self, "h", None):
+            self.L.kmanip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.k_close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state / diagnostics (parity tests)
+    def get_state(self):
+        cm, n = self.cm, self.num_envs
+        qpos = np.zeros((n, cm.nq)); qvel = np.zeros((n, cm.nv)); ctrl = np.zeros((n, cm.nu)); warm = np.zeros((n, cm.nv))
+        step = np.zeros(n, dtype=np.int32)
+        p = lambda a, t=C.c_double: a.ctypes.data_as(C.POINTER(t))
+        self._check(self.L.kmanip_get_state(self.h, p(qpos), p(qvel), p(ctrl), p(warm), p(step, C.c_int32)), "kmanip_get_state")
+        return qpos, qvel, ctrl, warm, step
+
+    def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None, step=None):
+        def p(a, dt, t):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=dt)
+            return a, a.ctypes.data_as(C.POINTER(t))
+        keep = []
+        args = []
+        for a, dt, t in [(qpos, np.float64, C.c_double), (qvel, np.float64, C.c_double), (ctrl, np.float64, C.c_double),
+                         (warm, np.float64, C.c_double), (step, np.int32, C.c_int32)]:
+            arr, ptr = p(a, dt, t)
+            keep.append(arr); args.append(ptr)
+        self._check(self.L.kmanip_set_state(self.h, *args), "kmanip_set_state")
+
+    def get_diag(self):
+        n = self.num_envs
+        mask = np.zeros(n, dtype=np.uint32); nfev = np.zeros((n, 2), dtype=np.int32); st = np.zeros((n, 2), dtype=np.int32)
+        self._check(self.L.kmanip_get_diag(self.h, mask.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                           nfev.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           st.ctypes.data_as(C.POINTER(C.c_int32))), "kmanip_get_diag")
+        return mask, nfev, st
+
+    def ik(self, arm, qpos, goal_pos, goal_quat):
+        """Batched ik_mujoco.ik on device: returns (q_out, qpos_after, nfev, status)."""
+        qpos = np.ascontiguousarray(qpos, dtype=np.float64).copy()
+        n = qpos.shape[0]
+        gp = np.ascontiguousarray(goal_pos, dtype=np.float64); gq = np.ascontiguousarray(goal_quat, dtype=np.float64)
+        nik = self.cm.desc.arm_nq[arm]
+        q = np.zeros((n, nik)); nfev = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+        p = lambda a, t=C.c_double: a.ctypes.data_as(C.POINTER(t))
+        self._check(self.L.kmanip_ik(self.h, arm, n, p(qpos), p(gp), p(gq), p(q), p(nfev, C.c_int32), p(st, C.c_int32)), "kmanip_ik")
+        return q, qpos, nfev, st
+
+    def enable_timing(self, on=True):
+        self._check(self.L.kmanip_enable_timing(self.h, int(on)), "kmanip_enable_timing")
+
+    def timing_summary(self):
+        """(ik_ms_sum, dyn_ms_sum, nsteps) of the steps recorded since enable_timing / the last summary."""
+        a = C.c_double(); b = C.c_double(); n = C.c_int32()
+        self._check(self.L.kmanip_timing_summary(self.h, C.byref(a), C.byref(b), C.byref(n)), "kmanip_timing_summary")
+        return float(a.value), float(b.value), int(n.value)
+
+
+def spec_from_gym_env(gym_env) -> EnvSpec:
+    """Read the same attributes env_sim.new reads from the KManipEnv instance."""
+    return EnvSpec(env_id=getattr(gym_env, "env_id", "custom"), asset=MJCF_TO_ASSET[gym_env.mjcf_filename],
+                   obs_list=list(gym_env.obs_list), act_list=list(gym_env.act_list),
+                   q_pos_home=np.asarray(gym_env.q_pos_home, dtype=np.float32),
+                   q_id_r_mask=None if gym_env.q_id_r_mask is None else list(gym_env.q_id_r_mask),
+                   q_id_l_mask=None if getattr(gym_env, "q_id_l_mask", None) is None else list(gym_env.q_id_l_mask),
+                   ctrl_id_r_grip=None if gym_env.ctrl_id_r_grip is None else list(gym_env.ctrl_id_r_grip),
+                   ctrl_id_l_grip=None if getattr(gym_env, "ctrl_id_l_grip", None) is None else list(gym_env.ctrl_id_l_grip))
+
+
+def new(gym_env, num_envs: int = 1, device: int = 0, env_id_offset: int = 0, **compile_kw) -> KManipEnvHip:
+    """Drop-in third backend: `self.env = env_hip.new(self)` in KManipEnv.__init__ (env_base.py:192-200)."""
+    cm = compile_model(spec_from_gym_env(gym_env), **compile_kw)
+    return KManipEnvHip(cm, num_envs=num_envs, device=device, seed=int(getattr(gym_env, "seed", 0) or 0),
+                        env_id_offset=env_id_offset)
+
+
+def make(env_id: str, num_envs: int = 1, device: int = 0, seed: int = 0, env_id_offset: int = 0, **compile_kw) -> KManipEnvHip:
+    """Shortcut used by bench/tests: build straight from a registered env id (__init__.py:244-483)."""
+    return KManipEnvHip(compile_model(ENV_SPECS[env_id], **compile_kw), num_envs=num_envs, device=device, seed=seed,
+                        env_id_offset=env_id_offset)

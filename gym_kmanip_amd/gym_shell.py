@@ -1,0 +1,167 @@
+"""Caller side of the seam: a KManipEnv-compatible shell over the HIP backend.
+
+Mirrors reference gym_kmanip/env_base.py:16-267 (constructor kwargs, Dict observation/action spaces with
+the same keys, order, shapes, dtypes and bounds, the `info` dict, reset/step signatures) and the
+TimeLimit(max_episode_steps=64) wrapper that `gym.make` adds (__init__.py:28,247).  `self.env` is chosen
+exactly like env_base.py:192-200 does -- by calling a module-level `new(self)` -- here `env_hip.new`.
+gymnasium is not installed in the build image, so spaces degrade to duck-typed shims (`contains`, `sample`,
+`shape`, `dtype`, `low`, `high`); when gymnasium is importable its real spaces are used.
+With num_envs == 1 and squeeze=True the return values have the reference's single-env shapes.
+"""
+from __future__ import annotations
+
+import time
+from collections import OrderedDict
+from typing import Any, Dict
+
+import numpy as np
+
+from . import env_hip
+from .model import (ENV_SPECS, MAX_EPISODE_STEPS, REWARD_SUCCESS_THRESHOLD, KM_DONE_DIVERGED, EnvSpec)
+
+OBS_DTYPE = np.float64   # __init__.py:50
+ACT_DTYPE = np.float32   # __init__.py:51
+
+try:  # pragma: no cover - gymnasium is absent in the build image
+    from gymnasium import spaces as _spaces
+    _HAVE_GYM = True
+except Exception:  # noqa: BLE001
+    _HAVE_GYM = False
+
+
+class Box:
+    def __init__(self, low, high, shape, dtype):
+        self.low = np.full(shape, low, dtype=dtype); self.high = np.full(shape, high, dtype=dtype)
+        self.shape = tuple(shape); self.dtype = np.dtype(dtype)
+        self._rng = np.random.default_rng()
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and x.dtype == self.dtype and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def sample(self):
+        return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+
+
+class DictSpace:
+    def __init__(self, d):
+        self.spaces = OrderedDict(d)
+
+    def contains(self, x):
+        return list(x.keys()) == list(self.spaces.keys()) and all(s.contains(x[k]) for k, s in self.spaces.items())
+
+    def sample(self):
+        return OrderedDict((k, s.sample()) for k, s in self.spaces.items())
+
+    def seed(self, seed=None):
+        for i, s in enumerate(self.spaces.values()):
+            s.seed(None if seed is None else seed + i)
+
+    def __getitem__(self, k):
+        return self.spaces[k]
+
+
+def _box(low, high, shape, dtype):
+    return _spaces.Box(low=low, high=high, shape=shape, dtype=dtype) if _HAVE_GYM else Box(low, high, shape, dtype)
+
+
+def _dict(d):
+    return _spaces.Dict(d) if _HAVE_GYM else DictSpace(d)
+
+
+class KManipEnv:
+    metadata = {"render_modes": ["rgb_array"], "render_fps": 30}
+
+    def __init__(self, env_id: str = "KManipSoloArm", num_envs: int = 1, device: int = 0, seed: int = 0,
+                 squeeze: bool = False, env_id_offset: int = 0, **overrides):
+        spec: EnvSpec = ENV_SPECS[env_id]
+        self.env_id = env_id
+        self.seed = seed
+        self.num_envs = num_envs
+        self.squeeze = squeeze and num_envs == 1
+        self.step_idx = 0
+        self.episode_idx = 0
+        # the attributes env_sim.new / env_hip.new read (env_base.py:61-78,110-115)
+        self.mjcf_filename = {"solo_arm": "_env_solo_arm.xml", "dual_arm": "_env_dual_arm.xml", "torso": "_env_torso.xml"}[spec.asset]
+        self.q_pos_home = spec.q_pos_home
+        self.q_len = len(spec.q_pos_home)
+        self.q_id_r_mask = spec.q_id_r_mask
+        self.q_id_l_mask = spec.q_id_l_mask
+        self.ctrl_id_r_grip = spec.ctrl_id_r_grip
+        self.ctrl_id_l_grip = spec.ctrl_id_l_grip
+        self.obs_list = [o for o in spec.obs_list]
+        self.act_list = list(spec.act_list)
+        self.cameras = [o.split("/")[-1] for o in self.obs_list if "camera" in o]
+        # observation space, env_base.py:115-147
+        od = OrderedDict()
+        if "q_pos" in self.obs_list:
+            od["q_pos"] = _box(-1, 1, (self.q_len,), OBS_DTYPE)
+        if "q_vel" in self.obs_list:
+            od["q_vel"] = _box(-1, 1, (self.q_len,), OBS_DTYPE)
+        if "cube_pos" in self.obs_list:
+            od["cube_pos"] = _box(-1, 1, (3,), OBS_DTYPE)
+        if "cube_orn" in self.obs_list:
+            od["cube_orn"] = _box(-1, 1, (4,), OBS_DTYPE)
+        self.observation_space = _dict(od)
+        # action space, env_base.py:149-190 (insertion order == flat column order)
+        ad = OrderedDict()
+        for key in ["eel_pos", "eel_orn", "eer_pos", "eer_orn"]:
+            if key in self.act_list:
+                ad[key] = _box(-1, 1, (3,), ACT_DTYPE)
+        for key in ["grip_l", "grip_r"]:
+            if key in self.act_list:
+                ad[key] = _box(-1, 1, (1,), ACT_DTYPE)
+        if "q_pos_r" in self.act_list:
+            ad["q_pos_r"] = _box(-1, 1, (len(self.q_id_r_mask),), ACT_DTYPE)
+        if "q_pos_l" in self.act_list:
+            ad["q_pos_l"] = _box(-1, 1, (len(self.q_id_l_mask),), ACT_DTYPE)
+        self.action_space = _dict(ad)
+        self.action_len = len(ad)
+        self.sim = True
+        # backend seam, env_base.py:192-200
+        self.env = env_hip.new(self, num_envs=num_envs, device=device, env_id_offset=env_id_offset,
+                               auto_reset=False, **overrides)
+        self.info: Dict[str, Any] = {
+            "step": self.step_idx, "episode": self.episode_idx, "is_success": False, "q_len": self.q_len,
+            "a_len": self.action_len, "obs_list": self.obs_list, "act_list": self.act_list,
+            "cameras": self.cameras, "sim": self.sim,
+        }
+
+    def _host_obs(self, obs):
+        out = OrderedDict()
+        for k, v in obs.items():
+            a = v.detach().cpu().numpy().astype(OBS_DTYPE, copy=False)
+            out[k] = a[0] if self.squeeze else a
+        return out
+
+    def reset(self, seed=None, options=None):
+        terminated, reward, _, observation, sim_time = self.env.k_reset()
+        self.step_idx = 0
+        self.episode_idx += 1
+        self.info.update(step=self.step_idx, episode=self.episode_idx, sim_time=sim_time, cpu_time=time.time(),
+                         reward=reward, is_success=False, terminated=False)
+        return self._host_obs(observation), self.info
+
+    def step(self, action):
+        if self.squeeze and isinstance(action, dict):
+            action = {k: np.asarray(v)[None] for k, v in action.items()}
+        terminated, reward, _, observation, sim_time = self.env.k_step(action)
+        self.step_idx += 1
+        r = reward.detach().cpu().numpy()
+        term = terminated.cpu().numpy()
+        trunc = np.full(self.num_envs, self.step_idx >= MAX_EPISODE_STEPS)          # TimeLimit wrapper
+        self.info.update(step=self.step_idx, episode=self.episode_idx, sim_time=sim_time, cpu_time=time.time(),
+                         reward=r, is_success=r > REWARD_SUCCESS_THRESHOLD, terminated=term,
+                         diverged=(self.env.done.cpu().numpy() & KM_DONE_DIVERGED) != 0)
+        if self.squeeze:
+            return self._host_obs(observation), float(r[0]), bool(term[0]), bool(trunc[0]), self.info
+        return self._host_obs(observation), r, term, trunc, self.info
+
+    def render(self):
+        return self.env.k_render("top")
+
+    def close(self):
+        self.env.k_close()

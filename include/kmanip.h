@@ -174,10 +174,15 @@ int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const do
  * ik_status int32[num_envs, 2]. Synchronous. */
 int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status);
 
-/* Kernel-only timing of the most recent kmanip_step launch sequence, in milliseconds, measured
- * with HIP events recorded on the launch stream (bench.py roofline leg). Synchronises. */
-int kmanip_last_step_ms(KHandle h, float* ms);
+/* Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).  While
+ * enabled, every kmanip_step records three events (before the decode/IK launches, between IK and the
+ * physics kernel, after the physics kernel) into a ring of `KM_TIMING_SLOTS` steps.
+ * kmanip_timing_summary synchronises the device and returns the summed durations in milliseconds of
+ * the IK leg (k_prepare + k_before_step) and of the physics kernel (k_step) over the recorded steps,
+ * then clears the ring. */
+#define KM_TIMING_SLOTS 1024
 int kmanip_enable_timing(KHandle h, int enable);
+int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, int32_t* nsteps);
 
 /* Standalone batched IK (ik_mujoco.ik, reference ik_mujoco.py:100-155) for parity tests:
  * qpos HOST double[n, nq] (in: current; out: qpos after the IK's last evaluation),

@@ -1,0 +1,223 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+ (a) the float64 C oracle on the same seeded inputs, (b) the committed fixtures in tests/golden/
+ (SciPy-generated IK vectors, oracle trajectories), (c) size-independent properties at BASELINE sizes.
+
+Tolerances (float64 on both sides; differences come only from operation order -- tree reductions,
+Cholesky-vs-SVD in the IK, explicit M^-1 vs factor solves):
+   IK vs SciPy          1e-6 rad   (termination knife-edges may shift nfev by one evaluation)
+   IK vs oracle         1e-7 rad
+   qpos / obs           1e-7       over a full 64-step episode + the auto-reset boundary
+   qvel                 1e-5
+   reward               1e-6
+   ctrl, done, contact masks, step counters: bit-exact
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ENVS3, GOLDEN
+from gym_kmanip_amd.model import KM_DONE_DIVERGED, KM_DONE_TRUNCATED, compile_model
+
+pytestmark = pytest.mark.gpu
+
+TOL_Q, TOL_V, TOL_R = 1e-7, 1e-5, 1e-6
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _mk(env_id, n, seed=0, off=0, **kw):
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    cm = compile_model(env_id, **kw)
+    return cm, env_hip.KManipEnvHip(cm, num_envs=n, seed=seed, env_id_offset=off), Oracle(cm, n, seed=seed, env_id_offset=off)
+
+
+def _cmp_state(g, o, k=""):
+    sg, so = g.get_state(), o.get_state()
+    assert np.abs(sg[0] - so[0]).max() < TOL_Q, ("qpos", k, np.abs(sg[0] - so[0]).max())
+    assert np.abs(sg[1] - so[1]).max() < TOL_V, ("qvel", k, np.abs(sg[1] - so[1]).max())
+    assert np.array_equal(sg[2], so[2]), ("ctrl", k)
+    assert np.array_equal(sg[4], so[4]), ("step_idx", k)
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_ik_golden_scipy_gpu(env):
+    _torch()
+    g = np.load(os.path.join(GOLDEN, "ik_scipy_%s.npz" % env))
+    cm, dev, orc = _mk(env, 1)
+    nf_mismatch = 0
+    for arm in range(2):
+        sel = np.where(g["arm"] == arm)[0]
+        if len(sel) == 0:
+            continue
+        n = cm.desc.arm_nq[arm]
+        q, qp_after, nfev, st = dev.ik(arm, g["qpos"][sel], g["goal_pos"][sel], g["goal_quat"][sel])
+        assert np.abs(q - g["q_out"][sel][:, :n]).max() < 1e-6
+        assert np.abs(qp_after - g["qpos_after"][sel]).max() < 1e-6
+        nf_mismatch += int((nfev != g["nfev"][sel]).sum())
+        failed = g["status"][sel] == -2                      # "IK failed: x0 is infeasible" branch
+        assert np.array_equal(st[failed], g["status"][sel][failed]) and (nfev[failed] == 0).all()
+        assert np.array_equal(qp_after[failed], g["qpos"][sel][failed])
+        for i, s in enumerate(sel):                          # and against the oracle
+            qo, qpo, nfo, sto = orc.ik(arm, g["qpos"][s], g["goal_pos"][s], g["goal_quat"][s])
+            assert np.abs(q[i] - qo).max() < 1e-7 and np.abs(qp_after[i] - qpo).max() < 1e-7
+    assert nf_mismatch <= 3, nf_mismatch
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_reset_parity(env):
+    torch = _torch()
+    cm, dev, orc = _mk(env, 32, seed=11, off=1000)
+    dev.k_reset(); obs_o = orc.reset()
+    sg, so = dev.get_state(), orc.get_state()
+    assert np.array_equal(sg[0], so[0]) and np.array_equal(sg[1], so[1]) and np.array_equal(sg[2], so[2])
+    assert np.abs(sg[3] - so[3]).max() < 1e-8          # qacc_warmstart of the unactuated mj_forward
+    assert np.array_equal(dev.obs.cpu().numpy(), obs_o)
+    # masked reset touches only the selected envs and advances their episode (new cube spawn)
+    mask = np.zeros(32, dtype=np.uint8); mask[[3, 17]] = 1
+    before = dev.get_state()[0].copy()
+    dev.k_reset(mask)
+    after = dev.get_state()[0]
+    changed = np.where(np.abs(after - before).max(axis=1) > 0)[0]
+    assert list(changed) == [3, 17]
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env,n,steps", [("KManipSoloArm", 32, 70), ("KManipDualArm", 16, 66), ("KManipTorso", 16, 66)])
+def test_step_parity_vs_oracle(env, n, steps):
+    """Full episodes incl. cube landing (contacts), joint-limit hits, IK-infeasible starts and the
+    auto-reset at step 64, on identical seeded actions."""
+    torch = _torch()
+    cm, dev, orc = _mk(env, n, seed=5, off=7, auto_reset=True)
+    dev.k_reset(); orc.reset()
+    rng = np.random.default_rng(42)
+    saw_contact = saw_reset = False
+    for k in range(steps):
+        act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda())
+        oo, ro, do = orc.step(act)
+        _cmp_state(dev, orc, k)
+        assert np.abs(dev.obs.cpu().numpy() - oo).max() < TOL_Q, k
+        assert np.abs(dev.reward.cpu().numpy() - ro).max() < TOL_R, k
+        assert np.array_equal(dev.done.cpu().numpy(), do), k
+        mg, nfg, stg = dev.get_diag(); mo, nfo, sto = orc.get_diag()
+        assert np.array_equal(mg, mo), (k, mg, mo)
+        assert np.array_equal(stg == -2, sto == -2) and np.abs(nfg - nfo).max() <= 1, k
+        saw_contact |= bool(mg.any()); saw_reset |= bool(do.any())
+    assert saw_contact and saw_reset
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_golden_trajectory_gpu(env):
+    torch = _torch()
+    g = np.load(os.path.join(GOLDEN, "traj_%s.npz" % env))
+    from gym_kmanip_amd import env_hip
+    cm = compile_model(env, auto_reset=True)
+    dev = env_hip.KManipEnvHip(cm, num_envs=g["act"].shape[1], seed=int(g["seed"]), env_id_offset=int(g["env_id_offset"]))
+    dev.k_reset()
+    assert np.abs(dev.obs.cpu().numpy() - g["obs0"]).max() < 1e-12
+    for k in range(g["act"].shape[0]):
+        dev.step_flat(torch.from_numpy(g["act"][k]).cuda())
+        qpos, qvel, ctrl, warm, step = dev.get_state()
+        assert np.abs(qpos - g["qpos"][k]).max() < TOL_Q and np.abs(qvel - g["qvel"][k]).max() < TOL_V, k
+        assert np.array_equal(ctrl, g["ctrl"][k]), k
+        assert np.abs(dev.obs.cpu().numpy() - g["obs"][k]).max() < TOL_Q
+        assert np.abs(dev.reward.cpu().numpy() - g["rew"][k]).max() < TOL_R
+        assert np.array_equal(dev.done.cpu().numpy(), g["done"][k])
+        assert np.array_equal(dev.get_diag()[0], g["mask"][k])
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env", ["KManipSoloArmQPos", "KManipDualArmQPos"])
+def test_qpos_action_modes(env):
+    torch = _torch()
+    cm, dev, orc = _mk(env, 8, seed=2)
+    dev.k_reset(); orc.reset()
+    rng = np.random.default_rng(9)
+    for k in range(6):
+        act = rng.uniform(-1, 1, (8, cm.act_dim)).astype(np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda()); orc.step(act)
+        _cmp_state(dev, orc, k)
+    assert (dev.get_diag()[2] == -3).all()       # no IK ran
+    dev.k_close()
+
+
+def test_seam_dict_api():
+    """k_reset / k_step through the reference's backend seam with dict actions (env_base.py:219-259)."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.gym_shell import KManipEnv
+    env = KManipEnv("KManipSoloArm", num_envs=4, seed=1)
+    obs, info = env.reset()
+    assert list(obs.keys()) == ["q_pos", "q_vel", "cube_pos", "cube_orn"]
+    act = {"eer_pos": np.zeros((4, 3), np.float32), "eer_orn": np.zeros((4, 3), np.float32), "grip_r": np.zeros((4, 1), np.float32)}
+    for k in range(64):
+        obs, reward, terminated, truncated, info = env.step(act)
+    assert not np.asarray(terminated).any() and np.asarray(truncated).all() and info["step"] == 64
+    assert obs["q_pos"].shape == (4, 10) and obs["cube_orn"].shape == (4, 4) and obs["q_pos"].dtype == np.float64
+    env.close()
+
+
+def test_diverged_flag_and_recovery():
+    torch = _torch()
+    cm, dev, orc = _mk("KManipSoloArm", 4, seed=1, auto_reset=False)
+    dev.k_reset()
+    qpos, qvel, ctrl, warm, step = dev.get_state()
+    qvel[2, 3] = np.nan
+    dev.set_state(qvel=qvel)
+    dev.step_flat(torch.zeros((4, 7), dtype=torch.float32, device="cuda"))
+    done = dev.done.cpu().numpy()
+    assert done[2] & KM_DONE_DIVERGED and not (done[[0, 1, 3]] & KM_DONE_DIVERGED).any()
+    q2 = dev.get_state()
+    assert np.isfinite(q2[0]).all() and np.isfinite(q2[1]).all() and q2[4][2] == 0    # env 2 was reset
+    dev.k_close()
+
+
+def test_full_size_properties_4096():
+    """BASELINE config 2 size (KManipSoloArm @ 4096): determinism, shard independence, invariants."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    n = 4096
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=3)
+    b = env_hip.make("KManipSoloArm", num_envs=n, seed=3)
+    c = env_hip.make("KManipSoloArm", num_envs=512, seed=3, env_id_offset=1024)   # a shard of the same job
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    a.k_reset(); b.k_reset(); c.k_reset()
+    for k in range(12):
+        act = torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1
+        a.step_flat(act); b.step_flat(act.clone()); c.step_flat(act[1024:1536].contiguous())
+    sa, sb, sc = a.get_state(), b.get_state(), c.get_state()
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)                                # bitwise deterministic
+    for x, z in zip(sa, sc):
+        assert np.array_equal(x[1024:1536], z)                     # results do not depend on the shard layout
+    nl = 10
+    assert np.abs(np.linalg.norm(sa[0][:, nl + 3:], axis=1) - 1).max() < 1e-12   # unit cube quaternion
+    obs = a.obs.cpu().numpy()
+    assert np.isfinite(obs).all() and (np.abs(obs[:, :2 * nl + 3]) <= 1).all()
+    assert (sa[4] == 12).all() and not a.done.cpu().numpy().any()
+    assert (sa[0][:, nl + 2] > 0.5 + 0.02 - 1e-3).all()            # no cube sinks through the table
+    for e in (a, b, c):
+        e.k_close()
+
+
+def test_dual_and_torso_full_size_smoke():
+    """BASELINE configs 3/4 per-GPU sizes run and stay finite (8192 envs each)."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    for env_id in ["KManipDualArm", "KManipTorso"]:
+        e = env_hip.make(env_id, num_envs=8192, seed=1)
+        e.k_reset()
+        act = torch.rand((8192, 14), device="cuda") * 2 - 1
+        for k in range(3):
+            e.step_flat(act)
+        assert torch.isfinite(e.obs).all() and torch.isfinite(e.reward).all()
+        assert not (e.done & KM_DONE_DIVERGED).any()
+        e.k_close()

@@ -1,0 +1,35 @@
+"""Ad-hoc GPU-vs-oracle comparison (debug aid; the real parity tests live in tests/test_gpu_*.py)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from gym_kmanip_amd.model import compile_model
+from gym_kmanip_amd import env_hip
+from oracle.oracle import Oracle
+
+def run(env_id, n=8, steps=6, seed=3):
+    import torch
+    cm = compile_model(env_id, auto_reset=True)
+    g = env_hip.KManipEnvHip(cm, num_envs=n, seed=seed, env_id_offset=10)
+    o = Oracle(cm, n, seed=seed, env_id_offset=10)
+    g.k_reset(); obs_o = o.reset()
+    torch.cuda.synchronize()
+    sg = g.get_state(); so = o.get_state()
+    print(env_id, "reset diffs:", [float(np.abs(a - b).max()) for a, b in zip(sg[:4], so[:4])], "obs", float(np.abs(g.obs.cpu().numpy() - obs_o).max()), flush=True)
+    rng = np.random.default_rng(seed)
+    for k in range(steps):
+        act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
+        t = time.time()
+        g.step_flat(torch.from_numpy(act).cuda()); torch.cuda.synchronize()
+        tg = time.time() - t
+        oo, ro, do = o.step(act)
+        sg = g.get_state(); so = o.get_state()
+        mg, nfg, stg = g.get_diag(); mo, nfo, sto = o.get_diag()
+        d = [float(np.abs(a - b).max()) for a, b in zip(sg[:4], so[:4])]
+        print(" step", k, "qpos %.2e qvel %.2e ctrl %.2e warm %.2e" % tuple(d), "obs %.2e rew %.2e" % (np.abs(g.obs.cpu().numpy() - oo).max(), np.abs(g.reward.cpu().numpy() - ro).max()),
+              "done", np.array_equal(g.done.cpu().numpy(), do), "mask", np.array_equal(mg, mo), "nfev", np.array_equal(nfg, nfo), nfg[0], nfo[0], "gpu ms %.2f" % (tg * 1e3), flush=True)
+
+if __name__ == "__main__":
+    envs = sys.argv[1:] or ["KManipSoloArm"]
+    for e in envs:
+        run(e)
