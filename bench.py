@@ -28,11 +28,33 @@ def algorithmic_bytes_per_env_step(cm):
     return 2 * state + cm.act_dim * 4 + cm.obs_dim * 8 + 8 + 1
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0]); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return n
+
+
 def cpu_baseline(cm, n_envs, budget_s=12.0):
     """The oracle (a C port of the reference path; the reference itself cannot run here) timed on this
     box's host cores with OpenMP over envs, on a bounded sample of the same workload."""
     from oracle.oracle import Oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = min(n_envs, 1024)
     o = Oracle(cm, n, seed=0)
     o.reset()
@@ -60,6 +82,7 @@ def main():
     ap.add_argument("--env", default="KManipSoloArm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--solver-iterations", type=int, default=100, help="PGS sweep cap (MuJoCo default 100); ablation only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,7 +98,7 @@ def main():
 
     from gym_kmanip_amd import env_hip
     from gym_kmanip_amd.model import compile_model
-    cm = compile_model(args.env, auto_reset=True)
+    cm = compile_model(args.env, auto_reset=True, solver_iterations=args.solver_iterations)
     n = args.envs_per_gpu
     env = env_hip.KManipEnvHip(cm, num_envs=n, device=local_rank, seed=0, env_id_offset=rank * n)
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)

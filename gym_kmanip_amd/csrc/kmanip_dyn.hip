@@ -30,6 +30,21 @@ template <int NL> struct Dim {
   static constexpr int NC = 4 + 2 * (NL / 5);     // cube-table corners + 2 pairs per finger sphere
 };
 
+// Solver view of one pyramidal contact (all group-uniform scalars).  Basis index 0 = normal, 1..2 =
+// tangents, 3 = torsion.  Edge e = 2*(k-1) + s uses J_0 + sm J_k with sm = (s ? -mu[k-1] : mu[k-1]).
+struct ConRec {
+  real G[10];     // symmetric Gram J_k M^-1 J_l^T, packed (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3)
+  real mu[3];
+  real R;         // regulariser shared by all edges (MuJoCo pyramidal rule)
+  real A[4];      // reference-acceleration basis: aref_e = A[0] + sm * A[k]
+  real inv[6];    // 1 / (A_ee + R)
+  real f[6];      // edge forces
+};
+__device__ __forceinline__ constexpr int gidx(int k, int l) {
+  const int a = k < l ? k : l, b = k < l ? l : k;
+  return a * 4 - a * (a - 1) / 2 + (b - a);
+}
+
 template <int NL>
 struct Ws {
   static constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ, NS = Dim<NL>::NS, NC = Dim<NL>::NC;
@@ -39,29 +54,49 @@ struct Ws {
   real cube_mat[9];
   // smooth dynamics
   real Minv[NL][NL];      // joint-space inertia, overwritten by its inverse
-  real Lw[NL][NL];        // Cholesky factor / L^-1 workspace
-  real FN[NL][6];         // per-body bias force (3) and moment about com (3)
-  real bias[NV], as[NV], tmp[NV], tmp2[NV];
+  real bias[NV], as[NV], tmp[NV];
   real Mtrace;
-  // single-dof constraint rows
+  // single-dof constraint rows (friction loss, joint limits)
   int ns;
   int s_dof[NS], s_type[NS];
-  real s_sign[NS], s_pos[NS], s_f[NS], s_R[NS], s_aref[NS], s_Ad[NS], s_floss[NS];
+  real s_sign[NS], s_pos[NS], s_f[NS], s_R[NS], s_aref[NS], s_den[NS], s_inv[NS], s_floss[NS];
   // contacts
   int ncon;
   int c_b1[NC], c_b2[NC], c_dim[NC], c_cube[NC];
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
-  real c_Jb[NC][4][NV], c_Bb[NC][4][NV], c_G[NC][4][4];
-  real c_R[NC], c_mu[NC][3], c_aref[NC][6], c_Ad[NC][6], c_f[NC][6];
+  real c_Jb[NC][4][NV];
+  union {
+    real c_Bb[NC][4][NV];                          // M^-1 J^T of the contact bases (built after M^-1)
+    struct { real Lw[NL][NL]; real FN[NL][6]; };   // Cholesky workspace / per-body bias wrenches (dead by then)
+  };
+  ConRec c_rec[NC];        // per-contact solver scalars, read as one block per contact per sweep
   uint32_t contact_mask;
   int touch_fc, touch_ct, bad;
 };
 
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// cross-lane double move with a DPP control word (row = 16 lanes)
+template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the G lanes of a group, result identical (bitwise) in every lane.  16-lane rows use four DPP
+// steps (row_mirror, row_half_mirror, two quad_perms) instead of ds_bpermute; G = 32 adds one swizzle.
 template <int G> __device__ __forceinline__ real gsum(real v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  static_assert(G == 16 || G == 32, "lane group must be one or two DPP rows");
+  v += dpp_f64<0x140>(v);   // row_mirror:      i <-> 15 - i
+  v += dpp_f64<0x141>(v);   // row_half_mirror: i <-> 7 - i within each half row
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (G == 32) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);   // bit mode: xor lane id with 16
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+    v += __hiloint2double(hi, lo);
+  }
   return v;
 }
 template <int G> __device__ __forceinline__ int gor(int v) {
@@ -73,7 +108,7 @@ template <int G> __device__ __forceinline__ int gor(int v) {
 // ---------------------------------------------------------------------------------------------
 // mj_kinematics (+ link com): serial over the tree on the group's lane 0
 template <int NL>
-__device__ void fk_serial(Ws<NL>& w, const KModelDesc* m) {
+__device__ __forceinline__ void fk_serial(Ws<NL>& w, const KModelDesc* m) {
   const int nl = m->nlink;
   for (int i = 0; i < nl; i++) {
     const int p = m->link_parent[i];
@@ -137,7 +172,7 @@ __device__ __forceinline__ void com_jac_col(const Ws<NL>& w, const KModelDesc* m
 
 // M_ij = sum over bodies b below both i and j of  m_b Jv_bi . Jv_bj + Jw_bi . I_b Jw_bj
 template <int NL, int G>
-__device__ void mass_matrix(Ws<NL>& w, const KDeviceModel* dm, int sub) {
+__device__ __forceinline__ void mass_matrix(Ws<NL>& w, const KDeviceModel* dm, int sub) {
   const KModelDesc* m = &dm->d;
   const int nl = m->nlink;
   for (int idx = sub; idx < nl * nl; idx += G) {
@@ -163,7 +198,7 @@ __device__ void mass_matrix(Ws<NL>& w, const KDeviceModel* dm, int sub) {
 
 // velocity-product + gravity wrenches per body (serial forward pass), then bias_j = sum_b J_bj^T wrench_b
 template <int NL>
-__device__ void bias_bodies_serial(Ws<NL>& w, const KModelDesc* m) {
+__device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const KModelDesc* m) {
   const int nl = m->nlink;
   // reuse Lw rows as scratch for (omega, alpha, a_origin) of each link: 9 numbers per link
   real (*kinv)[NL] = w.Lw;   // flat scratch view
@@ -215,7 +250,7 @@ __device__ void bias_bodies_serial(Ws<NL>& w, const KModelDesc* m) {
   for (int c = 0; c < 3; c++) { w.bias[nl + c] = -m->cube_mass * m->gravity[c]; w.bias[nl + 3 + c] = t[c]; }
 }
 template <int NL, int G>
-__device__ void bias_project(Ws<NL>& w, const KDeviceModel* dm, int sub) {
+__device__ __forceinline__ void bias_project(Ws<NL>& w, const KDeviceModel* dm, int sub) {
   const KModelDesc* m = &dm->d;
   const int nl = m->nlink;
   for (int j = sub; j < nl; j += G) {
@@ -234,7 +269,7 @@ __device__ void bias_project(Ws<NL>& w, const KDeviceModel* dm, int sub) {
 // Minv <- inverse of the SPD joint-space inertia held in Minv: cooperative left-looking Cholesky
 // (lane i owns row i), L^-1 by forward substitution (lane j owns column j), M^-1 = L^-T L^-1.
 template <int NL, int G>
-__device__ void invert_mass(Ws<NL>& w, int nl, int sub) {
+__device__ __forceinline__ void invert_mass(Ws<NL>& w, int nl, int sub) {
   real tr = 0;
   for (int i = 0; i < nl; i++) tr += w.Minv[i][i];
   if (sub == 0) w.Mtrace = tr;
@@ -296,7 +331,7 @@ __device__ __forceinline__ void make_frame(real* fr) {
 
 // narrow phase for the fixed candidate set: plane-box (first 4 corners below the table), sphere-box, plane-sphere
 template <int NL>
-__device__ void collide_serial(Ws<NL>& w, const KModelDesc* m) {
+__device__ __forceinline__ void collide_serial(Ws<NL>& w, const KModelDesc* m) {
   const int nl = m->nlink;
   int n = 0, cnt = 0;
   uint32_t mask = 0;
@@ -429,7 +464,7 @@ __device__ __forceinline__ void point_jac_col(const Ws<NL>& w, const KDeviceMode
 
 // single-dof rows in mj_makeConstraint order (friction loss, then limits), enumerated by lane 0
 template <int NL>
-__device__ void scalar_rows_serial(Ws<NL>& w, const KModelDesc* m) {
+__device__ __forceinline__ void scalar_rows_serial(Ws<NL>& w, const KModelDesc* m) {
   const int nl = m->nlink, nv = nl + 6;
   int n = 0;
   for (int j = 0; j < nv; j++) {
@@ -445,7 +480,7 @@ __device__ void scalar_rows_serial(Ws<NL>& w, const KModelDesc* m) {
 }
 
 template <int NL, int G>
-__device__ void build_constraints(Ws<NL>& w, const KDeviceModel* dm, int sub) {
+__device__ __forceinline__ void build_constraints(Ws<NL>& w, const KDeviceModel* dm, int sub) {
   constexpr int NV = Dim<NL>::NV;
   const KModelDesc* m = &dm->d;
   const int nl = m->nlink, nv = nl + 6;
@@ -456,8 +491,10 @@ __device__ void build_constraints(Ws<NL>& w, const KDeviceModel* dm, int sub) {
     real pos = w.s_pos[r];
     real imp = impedance(m->con_def_solimp, pos), kk, bb;
     get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
-    w.s_Ad[r] = Ad;
-    w.s_R[r] = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+    const real R = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+    w.s_R[r] = R;
+    w.s_den[r] = Ad + R;
+    w.s_inv[r] = 1.0 / (Ad + R);
     w.s_aref[r] = -bb * (w.s_sign[r] * w.qvel[j]) - kk * imp * pos;
   }
   // contact bases J (normal, 2 tangents, torsion): lane j builds column j of every contact
@@ -502,37 +539,45 @@ __device__ void build_constraints(Ws<NL>& w, const KDeviceModel* dm, int sub) {
       for (int l = 0; l < 4; l++) {
         real g = 0;
         for (int j = 0; j < nv; j++) g += w.c_Jb[c][k][j] * w.c_Bb[c][l][j];
-        Gm[k][l] = g; w.c_G[c][k][l] = g;
+        Gm[k][l] = g;
       }
     }
     const real* fr = w.c_cube[c] ? m->con_cube_friction : m->con_def_friction;
     const real* sr = w.c_cube[c] ? m->con_cube_solref : m->con_def_solref;
     const real* si = w.c_cube[c] ? m->con_cube_solimp : m->con_def_solimp;
     real mu[3] = {fr[0], fr[0], fr[1]};
-    w.c_mu[c][0] = mu[0]; w.c_mu[c][1] = mu[1]; w.c_mu[c][2] = mu[2];
     const real dist = w.c_dist[c];
     real imp = impedance(si, dist), kk, bb;
     get_kb(m, sr, si, kk, bb);
     const int ne = 2 * (w.c_dim[c] - 1);
-    for (int e = 0; e < ne; e++) {
+    ConRec& rc = w.c_rec[c];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int l = k; l < 4; l++) rc.G[gidx(k, l)] = 0.5 * (Gm[k][l] + Gm[l][k]);
+    rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2];
+    rc.A[0] = -bb * vb[0] - kk * imp * dist;
+    rc.A[1] = -bb * vb[1]; rc.A[2] = -bb * vb[2]; rc.A[3] = -bb * vb[3];
+    real R = 0;
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
       const int k = e / 2 + 1;
       const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
       real Ad = Gm[0][0] + sm * (Gm[0][k] + Gm[k][0]) + sm * sm * Gm[k][k];
-      real vel = vb[0] + sm * vb[k];
-      w.c_Ad[c][e] = Ad;
-      w.c_aref[c][e] = -bb * vel - kk * imp * dist;
-      if (e == 0) w.c_R[c] = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+      if (e == 0) { R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad); rc.R = R; }
+      rc.inv[e] = e < ne ? 1.0 / (Ad + R) : 0.0;
+      rc.f[e] = 0;
     }
   }
   GSYNC();
   (void)NV;
 }
 
-// one Gauss-Seidel update of a non-negative / box-bounded row (returns delta f)
-__device__ __forceinline__ real pgs_row(real Ja, real aref, real R, real Ad, real f, int type, real floss, real& improvement) {
-  const real den = Ad + R;
+// one Gauss-Seidel update of a non-negative / box-bounded row (returns delta f); inv = 1 / den
+__device__ __forceinline__ real pgs_row(real Ja, real aref, real R, real den, real inv, real f, int type, real floss,
+                                        real& improvement) {
   const real res = Ja - aref + R * f;
-  real fn = f - res / den;
+  real fn = f - res * inv;
   if (type == 0) fn = fmin(fmax(fn, -floss), floss);
   else fn = fmax(fn, 0.0);
   const real dlt = fn - f;
@@ -543,10 +588,12 @@ __device__ __forceinline__ real pgs_row(real Ja, real aref, real R, real Ad, rea
 // mj_step2 up to (not including) integration: actuation, qacc_smooth, warm start, PGS.  Returns this
 // lane's component of qacc (lane `sub` owns dof `sub`).
 template <int NL, int G>
-__device__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, int sub, int actuation) {
+__device__ __forceinline__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, int sub, int actuation) {
   const KModelDesc* m = &dm->d;
   const int nl = m->nlink, nv = nl + 6;
   // ---- actuation (position servos on actuator_length = q at mj_step1 time) and smooth acceleration
+  real invm = 0;                                  // diagonal of M^-1 for the cube dofs (lane-local)
+  if (sub >= nl && sub < nv) invm = sub < nl + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - nl - 3];
   if (sub < nv) {
     real rhs = -w.bias[sub];
     if (actuation && sub < nl) {
@@ -560,8 +607,7 @@ __device__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, int sub, int actu
   GSYNC();
   real a_s = 0;
   if (sub < nl) { for (int j = 0; j < nl; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
-  else if (sub < nl + 3) a_s = w.tmp[sub] / m->cube_mass;
-  else if (sub < nv) a_s = w.tmp[sub] / m->cube_inertia[sub - nl - 3];
+  else if (sub < nv) a_s = w.tmp[sub] * invm;
   if (sub < nv) w.as[sub] = a_s;
   GSYNC();
   const int ns = w.ns, nc = w.ncon;
@@ -585,14 +631,16 @@ __device__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, int sub, int actu
       wk[k] = s1; ak[k] = s2;
     }
     const int ne = 2 * (w.c_dim[c] - 1);
-    const real R = w.c_R[c];
-    for (int e = 0; e < ne; e++) {
+    ConRec& rc = w.c_rec[c];
+    const real R = rc.R;
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
       const int k = e / 2 + 1;
-      const real sm = (e & 1) ? -w.c_mu[c][k - 1] : w.c_mu[c][k - 1];
-      const real aref = w.c_aref[c][e];
+      const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+      const real aref = rc.A[0] + sm * rc.A[k];
       real jar = wk[0] + sm * wk[k] - aref;
-      real f = jar < 0 ? -jar / R : 0.0;
-      w.c_f[c][e] = f;
+      real f = (e < ne && jar < 0) ? -jar / R : 0.0;
+      rc.f[e] = f;
       cost_rows += 0.5 * R * f * f + f * (ak[0] + sm * ak[k] - aref);
     }
   }
@@ -602,13 +650,14 @@ __device__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, int sub, int actu
   if (sub < nv) {
     for (int r = 0; r < ns; r++) if (w.s_dof[r] == sub) y += w.s_sign[r] * w.s_f[r];
     for (int c = 0; c < nc; c++) {
-      const int ne = 2 * (w.c_dim[c] - 1);
+      const ConRec& rc = w.c_rec[c];
       real F[4] = {0, 0, 0, 0};
-      for (int e = 0; e < ne; e++) {
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
         const int k = e / 2 + 1;
-        const real f = w.c_f[c][e];
+        const real f = rc.f[e];
         F[0] += f;
-        F[k] += ((e & 1) ? -w.c_mu[c][k - 1] : w.c_mu[c][k - 1]) * f;
+        F[k] += ((e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1]) * f;
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) y += w.c_Jb[c][k][sub] * F[k];
@@ -618,62 +667,96 @@ __device__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, int sub, int actu
   GSYNC();
   real z = 0;
   if (sub < nl) { for (int j = 0; j < nl; j++) z += w.Minv[sub][j] * w.tmp[j]; }
-  else if (sub < nl + 3) z = y / m->cube_mass;
-  else if (sub < nv) z = y / m->cube_inertia[sub - nl - 3];
+  else if (sub < nv) z = y * invm;
   const real cost = gsum<G>(0.5 * y * z + cost_rows);
   real a = a_s;
   if (cost > 0) {
     for (int r = sub; r < ns; r += G) w.s_f[r] = 0;
-    for (int c = sub; c < nc; c += G) for (int e = 0; e < 6; e++) w.c_f[c][e] = 0;
+    for (int c = sub; c < nc; c += G) for (int e = 0; e < 6; e++) w.c_rec[c].f[e] = 0;
   } else a += z;
   GSYNC();
-  // ---- projected Gauss-Seidel in acceleration space: a = a_s + M^-1 J^T f kept distributed (lane = dof)
+  // ---- projected Gauss-Seidel in acceleration space: a = a_s + M^-1 J^T f kept distributed (lane = dof).
+  // Row order = mj_makeConstraint order.  Rows on the cube's own dofs (its friction loss) touch only the
+  // diagonal block of M^-1, so the owning lane updates them locally -- identical to processing them one
+  // after another, and no cross-lane traffic.  Rows on arm dofs need one broadcast each; a contact needs
+  // four DPP row reductions (its basis projections), then its 4-6 pyramid edges run on the 4x4 Gram form.
   const real scale = 1.0 / (w.Mtrace + 3 * m->cube_mass + m->cube_inertia[0] + m->cube_inertia[1] + m->cube_inertia[2]);
+  // the (at most one) cube friction-loss row owned by this lane, kept in registers across sweeps
+  int my_row = -1;
+  for (int r = 0; r < ns; r++) if (w.s_dof[r] == sub && sub >= nl && w.s_type[r] == 0) my_row = r;
+  real my_f = 0, my_aref = 0, my_R = 0, my_den = 1, my_inv = 0, my_fl = 0;
+  if (my_row >= 0) {
+    my_f = w.s_f[my_row]; my_aref = w.s_aref[my_row]; my_R = w.s_R[my_row]; my_den = w.s_den[my_row];
+    my_inv = w.s_inv[my_row]; my_fl = w.s_floss[my_row];
+  }
   for (int iter = 0; iter < m->solver_iterations; iter++) {
-    real improvement = 0;
+    real improvement = 0, imp_local = 0;
     for (int r = 0; r < ns; r++) {
       const int j = w.s_dof[r];
+      if (j >= nl) continue;                               // cube rows: lane-local, below
       const real sg = w.s_sign[r];
       const real Ja = sg * __shfl(a, j, G);
       const real f = w.s_f[r];
-      const real dlt = pgs_row(Ja, w.s_aref[r], w.s_R[r], w.s_Ad[r], f, w.s_type[r], w.s_floss[r], improvement);
-      if (dlt != 0) {
-        w.s_f[r] = f + dlt;
-        if (j < nl) { if (sub < nl) a += sg * w.Minv[sub][j] * dlt; }
-        else if (sub == j) a += sg * dlt * (j < nl + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[j - nl - 3]);
-      }
+      const real mij = sub < nl ? w.Minv[sub][j] : 0.0;
+      const real dlt = pgs_row(Ja, w.s_aref[r], w.s_R[r], w.s_den[r], w.s_inv[r], f, w.s_type[r], w.s_floss[r], improvement);
+      w.s_f[r] = f + dlt;
+      a += sg * mij * dlt;
+    }
+    if (my_row >= 0) {
+      const real dlt = pgs_row(a, my_aref, my_R, my_den, my_inv, my_f, 0, my_fl, imp_local);
+      my_f += dlt;
+      a += dlt * invm;
     }
     for (int c = 0; c < nc; c++) {
-      real u[4], Dk[4] = {0, 0, 0, 0};
+      // block-load the contact record (group-uniform broadcast reads) and this lane's basis columns
+      const ConRec& rr = w.c_rec[c];
+      real Gs[10], mu[3], Ab[4], inv[6], f[6];
+      const real Rc = rr.R;
 #pragma unroll
-      for (int k = 0; k < 4; k++) u[k] = gsum<G>(sub < nv ? w.c_Jb[c][k][sub] * a : 0.0);
-      const int ne = 2 * (w.c_dim[c] - 1);
-      const real R = w.c_R[c];
-      for (int e = 0; e < ne; e++) {
+      for (int i = 0; i < 10; i++) Gs[i] = rr.G[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) mu[i] = rr.mu[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) Ab[i] = rr.A[i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { inv[i] = rr.inv[i]; f[i] = rr.f[i]; }
+      real jb[4], bb[4], u[4], Dk[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; k++) { jb[k] = sub < nv ? w.c_Jb[c][k][sub] : 0.0; bb[k] = sub < nv ? w.c_Bb[c][k][sub] : 0.0; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) u[k] = gsum<G>(jb[k] * a);
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
         const int k = e / 2 + 1;
-        const real sm = (e & 1) ? -w.c_mu[c][k - 1] : w.c_mu[c][k - 1];
-        const real f = w.c_f[c][e];
-        const real dlt = pgs_row(u[0] + sm * u[k], w.c_aref[c][e], R, w.c_Ad[c][e], f, 1, 0.0, improvement);
-        if (dlt != 0) {
-          w.c_f[c][e] = f + dlt;
-          Dk[0] += dlt; Dk[k] += sm * dlt;
+        const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
+        real Ge[4];
 #pragma unroll
-          for (int l = 0; l < 4; l++) u[l] += (w.c_G[c][l][0] + sm * w.c_G[c][l][k]) * dlt;
-        }
-      }
-      if (sub < nv) {
+        for (int l = 0; l < 4; l++) Ge[l] = Gs[gidx(l, 0)] + sm * Gs[gidx(l, k)];   // J_l . (B_0 + sm B_k)
+        const real den = Ge[0] + sm * Ge[k] + Rc;
+        const real res = (u[0] + sm * u[k]) - (Ab[0] + sm * Ab[k]) + Rc * f[e];
+        const real fn = fmax(f[e] - res * inv[e], 0.0);       // inv == 0 for the unused edges of a condim-3 pair
+        const real dlt = fn - f[e];
+        improvement -= dlt * (res + 0.5 * den * dlt);
+        f[e] = fn;
+        Dk[0] += dlt; Dk[k] += sm * dlt;
 #pragma unroll
-        for (int k = 0; k < 4; k++) a += w.c_Bb[c][k][sub] * Dk[k];
+        for (int l = 0; l < 4; l++) u[l] += Ge[l] * dlt;
       }
+#pragma unroll
+      for (int e = 0; e < 6; e++) w.c_rec[c].f[e] = f[e];
+#pragma unroll
+      for (int k = 0; k < 4; k++) a += bb[k] * Dk[k];
     }
+    improvement += gsum<G>(imp_local);
     if (improvement * scale < m->solver_tolerance) break;
   }
+  if (my_row >= 0) w.s_f[my_row] = my_f;
   return a;
 }
 
 // everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
 template <int NL, int G>
-__device__ void step1_products(Ws<NL>& w, const KDeviceModel* dm, int sub) {
+__device__ __forceinline__ void step1_products(Ws<NL>& w, const KDeviceModel* dm, int sub) {
   const KModelDesc* m = &dm->d;
   if (sub == 0) { fk_serial<NL>(w, m); }
   GSYNC();
@@ -689,7 +772,7 @@ __device__ void step1_products(Ws<NL>& w, const KDeviceModel* dm, int sub) {
 // mj_Euler: qvel += dt*qacc, then positions with the NEW velocity (semi-implicit); free-joint quaternion
 // integrated on the group's lane 0
 template <int NL, int G>
-__device__ void integrate(Ws<NL>& w, const KModelDesc* m, int sub, real a) {
+__device__ __forceinline__ void integrate(Ws<NL>& w, const KModelDesc* m, int sub, real a) {
   const int nl = m->nlink, nv = nl + 6;
   const real dt = m->timestep;
   if (sub < nv) {
@@ -716,7 +799,7 @@ __device__ __forceinline__ real clip1(real x) { return fmin(fmax(x, -1.0), 1.0);
 
 // get_observation, env_sim.py:110-146 (state keys; cameras are out of this kernel)
 template <int NL, int G>
-__device__ void write_obs(const Ws<NL>& w, const KModelDesc* m, int sub, double* obs_row) {
+__device__ __forceinline__ void write_obs(const Ws<NL>& w, const KModelDesc* m, int sub, double* obs_row) {
   const int nl = m->nlink;
   for (int i = sub; i < nl; i += G) {
     obs_row[i] = clip1((w.qpos[i] - m->jnt_range[i][0]) / (m->jnt_range[i][1] - m->jnt_range[i][0]));
@@ -730,7 +813,7 @@ __device__ void write_obs(const Ws<NL>& w, const KModelDesc* m, int sub, double*
 
 // initialize_episode (env_sim.py:23-36) + mj_forward without actuation (dm_control after_reset)
 template <int NL, int G>
-__device__ void reset_env(Ws<NL>& w, const KDeviceModel* dm, int sub, uint64_t seed, int64_t genv, int episode) {
+__device__ __forceinline__ void reset_env(Ws<NL>& w, const KDeviceModel* dm, int sub, uint64_t seed, int64_t genv, int episode) {
   const KModelDesc* m = &dm->d;
   const int nl = m->nlink, nv = nl + 6;
   if (sub < nv) { w.qvel[sub] = 0; w.warm[sub] = 0; }
@@ -772,12 +855,24 @@ __device__ __forceinline__ void store_state(const Ws<NL>& w, const KDeviceState&
   for (int i = sub; i < nl; i += G) st.ctrl[(size_t)i * NE + env] = w.ctrl[i];
 }
 
+// copy the model into LDS with all 64 lanes (8-byte words), then a workgroup barrier (one wave: cheap)
+__device__ __forceinline__ void stage_model(KDeviceModel* dst, const KDeviceModel* src) {
+  static_assert(sizeof(KDeviceModel) % 8 == 0, "model must be a whole number of 8-byte words");
+  const uint64_t* s8 = reinterpret_cast<const uint64_t*>(src);
+  uint64_t* d8 = reinterpret_cast<uint64_t*>(dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(KDeviceModel) / 8); i += 64) d8[i] = s8[i];
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int NL, int G>
-__global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm, KDeviceState st, double* __restrict__ obs,
+__global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm_g, KDeviceState st, double* __restrict__ obs,
                                              double* __restrict__ reward, uint8_t* __restrict__ done) {
   constexpr int EPB = 64 / G;
   __shared__ Ws<NL> ws[EPB];
+  __shared__ KDeviceModel smodel;     // model constants staged once per workgroup (lane-indexed reads stay on-chip)
+  stage_model(&smodel, dm_g);
+  const KDeviceModel* dm = &smodel;
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const int env = blockIdx.x * EPB + grp;
@@ -851,10 +946,13 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
 
 // KManipEnvSim.k_reset for the envs selected by mask (NULL = all) or, with use_done_bits, by nonzero bytes of mask
 template <int NL, int G>
-__global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ dm, KDeviceState st,
+__global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ dm_g, KDeviceState st,
                                               const uint8_t* __restrict__ mask, double* __restrict__ obs) {
   constexpr int EPB = 64 / G;
   __shared__ Ws<NL> ws[EPB];
+  __shared__ KDeviceModel smodel;
+  stage_model(&smodel, dm_g);
+  const KDeviceModel* dm = &smodel;
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const int env = blockIdx.x * EPB + grp;

@@ -145,7 +145,8 @@ def test_qpos_action_modes(env):
         act = rng.uniform(-1, 1, (8, cm.act_dim)).astype(np.float32)
         dev.step_flat(torch.from_numpy(act).cuda()); orc.step(act)
         _cmp_state(dev, orc, k)
-    assert (dev.get_diag()[2] == -3).all()       # no IK ran
+    st = dev.get_diag()[2]
+    assert all((st[:, a] == -3).all() for a in range(2) if cm.desc.arm_present[a])       # no IK ran
     dev.k_close()
 
 
@@ -203,7 +204,7 @@ def test_full_size_properties_4096():
     obs = a.obs.cpu().numpy()
     assert np.isfinite(obs).all() and (np.abs(obs[:, :2 * nl + 3]) <= 1).all()
     assert (sa[4] == 12).all() and not a.done.cpu().numpy().any()
-    assert (sa[0][:, nl + 2] > 0.5 + 0.02 - 1e-3).all()            # no cube sinks through the table
+    assert (sa[0][:, nl + 2] > 0.5).all()                         # no cube centre below the table plane
     for e in (a, b, c):
         e.k_close()
 
