@@ -8,71 +8,89 @@
 // (KManipTask.initialize_episode env_sim.py:23-36 + dm_control's mj_forward without actuation).
 //
 // Execution model ("many envs per wavefront"): a workgroup is ONE wave of 64 lanes holding 64/G envs;
-// each env is owned by a group of G lanes (G = 16 for nv = 16, G = 32 for nv = 26), lane i of the group
-// owning dof i (its acceleration / velocity component lives in that lane's registers).  Every per-env
-// intermediate (body frames, joint-space inertia and its inverse, contact Jacobian bases, constraint
-// rows) is staged in LDS; HBM is touched once on entry and once on exit with struct-of-arrays
-// coalesced columns.  Small per-env reductions (constraint-row dot products, norms) use DPP/bpermute
-// wave shuffles of width G.  Groups never need s_barrier: all lanes of a group sit in the same wave.
+// each env is owned by a group of G lanes (G = 16 for nv = 16, G = 32 for nv = 26), lane d of the group
+// owning dof d: its component of qacc and its COLUMN of every contact-basis Jacobian (J and M^-1 J^T)
+// live in that lane's registers for the whole constraint solve.  Per-env intermediates that need random
+// access (body frames, joint-space inertia and inverse, group-uniform constraint scalars) sit in LDS --
+// about 8 KB per env, sized so that 16 envs fit one CU (4 workgroups x 4 envs) and all 4096 envs of the
+// headline config are resident in a single round.  HBM is touched once on entry and once on exit with
+// struct-of-arrays coalesced columns.  Per-env reductions (basis projections J.a, norms, costs) are DPP
+// row reductions (row_mirror / row_half_mirror / quad_perm), not ds_bpermute.  A lane group never needs
+// s_barrier: all its lanes sit in one wave.
 //
 // Formulations deliberately differ from the oracle's (so parity is a cross-check, not a re-run):
 //   mass matrix      : sum over bodies of COM-Jacobian outer products (oracle: composite-body CRBA)
 //   bias forces      : per-body bias wrenches projected with J^T   (oracle: RNE backward recursion)
 //   M^-1             : explicit inverse via cooperative Cholesky    (oracle: factor + solves)
-//   constraint rows  : compact (single-dof rows + 4-vector contact bases, edges expanded on the fly)
-//   PGS              : per-contact block form with a 4x4 Gram matrix (algebraically the same row order)
+//   constraint rows  : single-dof rows + 4-vector contact bases, pyramid edges expanded on the fly
+//   PGS              : per-contact block form on the 4x4 Gram matrix (algebraically the same row order)
 #include "kmanip_device.hpp"
 
 template <int NL> struct Dim {
   static constexpr int NV = NL + 6;
   static constexpr int NQ = NL + 7;
-  static constexpr int NS = NV + NL;              // single-dof rows: friction loss (<= nv) + limits (<= nl)
-  static constexpr int NC = 4 + 2 * (NL / 5);     // cube-table corners + 2 pairs per finger sphere
+  static constexpr int NS = 2 * NL;               // arm single-dof rows: friction loss (<= nl) + limits (<= nl)
+  static constexpr int NSPH = NL / 5;             // finger spheres (2 solo, 4 dual/torso)
+  static constexpr int NC = 4 + 2 * NSPH;         // contact SLOTS: 4 cube-table corners, NSPH finger-cube, NSPH finger-table
+  static constexpr int NCF = 2 * NSPH;            // slots that involve arm dofs
+};
+// compile-time kind of contact slot c: 0 = table(plane) - cube corner, 1 = finger sphere - cube, 2 = table - finger sphere
+template <int NL> __device__ __forceinline__ constexpr int slot_kind(int c) { return c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2); }
+template <int NL> __device__ __forceinline__ constexpr int slot_sphere(int c) { return c < 4 ? -1 : (c < 4 + Dim<NL>::NSPH ? c - 4 : c - 4 - Dim<NL>::NSPH); }
+
+// Per-link model constants staged in LDS once per workgroup (lane-indexed reads stay on-chip); scalars
+// and small fixed arrays are read straight from the global KModelDesc with wave-uniform (scalar) loads.
+template <int NL>
+struct LModel {
+  int parent[NL], jtype[NL], forcelimited[NL];
+  uint32_t anc[NL];
+  real pos[NL][3], quat[NL][4], jaxis[NL][3], range[NL][2], floss[NL], kp[NL], ctrlrange[NL][2], forcerange[NL][2];
+  real mass[NL], com[NL][3], inertia[NL][3], q_home[NL];
 };
 
-// Solver view of one pyramidal contact (all group-uniform scalars).  Basis index 0 = normal, 1..2 =
-// tangents, 3 = torsion.  Edge e = 2*(k-1) + s uses J_0 + sm J_k with sm = (s ? -mu[k-1] : mu[k-1]).
+// Solver view of one pyramidal contact (group-uniform scalars).  Basis index 0 = normal, 1..2 = tangents,
+// 3 = torsion.  Edge e = 2*(k-1) + s uses J_0 + sm J_k with sm = (s ? -mu[k-1] : mu[k-1]).
 struct ConRec {
-  real G[10];     // symmetric Gram J_k M^-1 J_l^T, packed (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3)
   real mu[3];
-  real R;         // regulariser shared by all edges (MuJoCo pyramidal rule)
-  real A[4];      // reference-acceleration basis: aref_e = A[0] + sm * A[k]
-  real inv[6];    // 1 / (A_ee + R)
-  real f[6];      // edge forces
+  real R;          // regulariser shared by all edges (MuJoCo pyramidal rule)
+  real inv[6];     // 1 / (A_ee + R); 0 for the unused edges of a condim-3 pair
+  real den[6];     // A_ee + R
+  real aref[6];    // reference acceleration of the edge
+  real f[6];       // edge forces
 };
-__device__ __forceinline__ constexpr int gidx(int k, int l) {
-  const int a = k < l ? k : l, b = k < l ? l : k;
-  return a * 4 - a * (a - 1) / 2 + (b - a);
-}
 
 template <int NL>
 struct Ws {
   static constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ, NS = Dim<NL>::NS, NC = Dim<NL>::NC;
   real qpos[NQ], qvel[NV], ctrl[NL], warm[NV], qpos_ik[NL];
-  // kinematics
-  real xpos[NL][3], xquat[NL][4], xmat[NL][9], axis[NL][3], cpos[NL][3];
-  real cube_mat[9];
-  // smooth dynamics
-  real Minv[NL][NL];      // joint-space inertia, overwritten by its inverse
+  union {
+    // kinematics: live from fk() to the end of the contact-Jacobian build ...
+    struct { real xpos[NL][3], xquat[NL][4], xmat[NL][9], axis[NL][3], cpos[NL][3], cube_mat[9]; } k;
+    // ... then the same bytes hold the per-edge Gram rows Ge[c][e][l] = J_l . M^-1 (J_0 + sm J_k)^T for PGS
+    struct { real Ge[NC][6][4]; } p;
+  };
+  real Minv[NL][NL];       // joint-space inertia, overwritten by its inverse
+  union {
+    struct { real Lw[NL][NL]; real FN[NL][6]; } f;   // Cholesky workspace, per-body bias wrenches
+    real stage[4][NV];                               // staging of basis rows for B = M^-1 J^T
+    ConRec rec[NC];                                  // solver records (built last)
+  };
   real bias[NV], as[NV], tmp[NV];
   real Mtrace;
-  // single-dof constraint rows (friction loss, joint limits)
-  int ns;
+  int ns, bad, touch_fc, touch_ct;
+  uint32_t contact_mask;   // KM_CON_* bits (which candidate pairs touch)
+  uint32_t cact;           // active contact slots
+  // single-dof constraint rows on ARM dofs (friction loss, then limits); the cube's friction-loss rows are
+  // lane-local registers
   int s_dof[NS], s_type[NS];
   real s_sign[NS], s_pos[NS], s_f[NS], s_R[NS], s_aref[NS], s_den[NS], s_inv[NS], s_floss[NS];
-  // contacts
-  int ncon;
-  int c_b1[NC], c_b2[NC], c_dim[NC], c_cube[NC];
+  // contact geometry per slot
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
-  real c_Jb[NC][4][NV];
-  union {
-    real c_Bb[NC][4][NV];                          // M^-1 J^T of the contact bases (built after M^-1)
-    struct { real Lw[NL][NL]; real FN[NL][6]; };   // Cholesky workspace / per-body bias wrenches (dead by then)
-  };
-  ConRec c_rec[NC];        // per-contact solver scalars, read as one block per contact per sweep
-  uint32_t contact_mask;
-  int touch_fc, touch_ct, bad;
 };
+
+// this lane's column of every contact basis: J (jb) and M^-1 J^T (bb); compile-time indexed only
+// (bb only for the slots that involve arm dofs: for table-cube slots M^-1 is diagonal, bb = jb * invm)
+template <int NC, int NCF> struct CReg { real jb[NC][4]; real bb[NCF][4]; };
 
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -108,25 +126,24 @@ template <int G> __device__ __forceinline__ int gor(int v) {
 // ---------------------------------------------------------------------------------------------
 // mj_kinematics (+ link com): serial over the tree on the group's lane 0
 template <int NL>
-__device__ __forceinline__ void fk_serial(Ws<NL>& w, const KModelDesc* m) {
-  const int nl = m->nlink;
-  for (int i = 0; i < nl; i++) {
-    const int p = m->link_parent[i];
+__device__ __forceinline__ void fk_serial(Ws<NL>& w, const LModel<NL>& lm) {
+  for (int i = 0; i < NL; i++) {
+    const int p = lm.parent[i];
     real pos[3], quat[4];
-    real lp[3] = {m->link_pos[i][0], m->link_pos[i][1], m->link_pos[i][2]};
-    real lq[4] = {m->link_quat[i][0], m->link_quat[i][1], m->link_quat[i][2], m->link_quat[i][3]};
-    real ja[3] = {m->jnt_axis[i][0], m->jnt_axis[i][1], m->jnt_axis[i][2]};
+    real lp[3] = {lm.pos[i][0], lm.pos[i][1], lm.pos[i][2]};
+    real lq[4] = {lm.quat[i][0], lm.quat[i][1], lm.quat[i][2], lm.quat[i][3]};
+    real ja[3] = {lm.jaxis[i][0], lm.jaxis[i][1], lm.jaxis[i][2]};
     if (p < 0) {
       pos[0] = lp[0]; pos[1] = lp[1]; pos[2] = lp[2];
       quat[0] = lq[0]; quat[1] = lq[1]; quat[2] = lq[2]; quat[3] = lq[3];
     } else {
-      mat_vec3(pos, w.xmat[p], lp);
-      pos[0] += w.xpos[p][0]; pos[1] += w.xpos[p][1]; pos[2] += w.xpos[p][2];
-      qmul(quat, w.xquat[p], lq);
+      mat_vec3(pos, w.k.xmat[p], lp);
+      pos[0] += w.k.xpos[p][0]; pos[1] += w.k.xpos[p][1]; pos[2] += w.k.xpos[p][2];
+      qmul(quat, w.k.xquat[p], lq);
     }
     const real q = w.qpos[i];
     real mat[9], aw[3];
-    if (m->jnt_type[i] == KM_JNT_SLIDE) {
+    if (lm.jtype[i] == KM_JNT_SLIDE) {
       normalize4(quat);
       quat2mat(mat, quat);
       mat_vec3(aw, mat, ja);
@@ -140,31 +157,31 @@ __device__ __forceinline__ void fk_serial(Ws<NL>& w, const KModelDesc* m) {
       quat2mat(mat, quat);
       mat_vec3(aw, mat, ja);
     }
-    real cl[3] = {m->com[i][0], m->com[i][1], m->com[i][2]}, cw[3];
+    real cl[3] = {lm.com[i][0], lm.com[i][1], lm.com[i][2]}, cw[3];
     mat_vec3(cw, mat, cl);
 #pragma unroll
-    for (int c = 0; c < 3; c++) { w.xpos[i][c] = pos[c]; w.axis[i][c] = aw[c]; w.cpos[i][c] = pos[c] + cw[c]; }
+    for (int c = 0; c < 3; c++) { w.k.xpos[i][c] = pos[c]; w.k.axis[i][c] = aw[c]; w.k.cpos[i][c] = pos[c] + cw[c]; }
 #pragma unroll
-    for (int c = 0; c < 4; c++) w.xquat[i][c] = quat[c];
+    for (int c = 0; c < 4; c++) w.k.xquat[i][c] = quat[c];
 #pragma unroll
-    for (int c = 0; c < 9; c++) w.xmat[i][c] = mat[c];
+    for (int c = 0; c < 9; c++) w.k.xmat[i][c] = mat[c];
   }
-  real cq[4] = {w.qpos[nl + 3], w.qpos[nl + 4], w.qpos[nl + 5], w.qpos[nl + 6]}, cm[9];
+  real cq[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]}, cm[9];
   normalize4(cq);
   quat2mat(cm, cq);
 #pragma unroll
-  for (int c = 0; c < 9; c++) w.cube_mat[c] = cm[c];
+  for (int c = 0; c < 9; c++) w.k.cube_mat[c] = cm[c];
 }
 
 // column j of the com Jacobian of body b (world frame): linear part jv, angular part jw
 template <int NL>
-__device__ __forceinline__ void com_jac_col(const Ws<NL>& w, const KModelDesc* m, int b, int j, real* jv, real* jw) {
-  if (m->jnt_type[j] == KM_JNT_SLIDE) {
-    jv[0] = w.axis[j][0]; jv[1] = w.axis[j][1]; jv[2] = w.axis[j][2];
+__device__ __forceinline__ void com_jac_col(const Ws<NL>& w, const LModel<NL>& lm, int b, int j, real* jv, real* jw) {
+  if (lm.jtype[j] == KM_JNT_SLIDE) {
+    jv[0] = w.k.axis[j][0]; jv[1] = w.k.axis[j][1]; jv[2] = w.k.axis[j][2];
     jw[0] = 0; jw[1] = 0; jw[2] = 0;
   } else {
-    real r[3] = {w.cpos[b][0] - w.xpos[j][0], w.cpos[b][1] - w.xpos[j][1], w.cpos[b][2] - w.xpos[j][2]};
-    real ax[3] = {w.axis[j][0], w.axis[j][1], w.axis[j][2]};
+    real r[3] = {w.k.cpos[b][0] - w.k.xpos[j][0], w.k.cpos[b][1] - w.k.xpos[j][1], w.k.cpos[b][2] - w.k.xpos[j][2]};
+    real ax[3] = {w.k.axis[j][0], w.k.axis[j][1], w.k.axis[j][2]};
     cross3(jv, ax, r);
     jw[0] = ax[0]; jw[1] = ax[1]; jw[2] = ax[2];
   }
@@ -172,24 +189,22 @@ __device__ __forceinline__ void com_jac_col(const Ws<NL>& w, const KModelDesc* m
 
 // M_ij = sum over bodies b below both i and j of  m_b Jv_bi . Jv_bj + Jw_bi . I_b Jw_bj
 template <int NL, int G>
-__device__ __forceinline__ void mass_matrix(Ws<NL>& w, const KDeviceModel* dm, int sub) {
-  const KModelDesc* m = &dm->d;
-  const int nl = m->nlink;
-  for (int idx = sub; idx < nl * nl; idx += G) {
-    const int i = idx / nl, j = idx % nl;
+__device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+  for (int idx = sub; idx < NL * NL; idx += G) {
+    const int i = idx / NL, j = idx % NL;
     if (i > j) continue;
     real s = 0;
-    if ((dm->x.anc_mask[j] >> i) & 1u) {
-      for (int b = j; b < nl; b++) {
-        if (!((dm->x.anc_mask[b] >> j) & 1u)) continue;
+    if ((lm.anc[j] >> i) & 1u) {
+      for (int b = j; b < NL; b++) {
+        if (!((lm.anc[b] >> j) & 1u)) continue;
         real jvi[3], jwi[3], jvj[3], jwj[3];
-        com_jac_col<NL>(w, m, b, i, jvi, jwi);
-        com_jac_col<NL>(w, m, b, j, jvj, jwj);
-        s += m->mass[b] * dot3(jvi, jvj);
+        com_jac_col<NL>(w, lm, b, i, jvi, jwi);
+        com_jac_col<NL>(w, lm, b, j, jvj, jwj);
+        s += lm.mass[b] * dot3(jvi, jvj);
         real li[3], lj[3];
-        matT_vec3(li, w.xmat[b], jwi);
-        matT_vec3(lj, w.xmat[b], jwj);
-        s += m->inertia[b][0] * li[0] * lj[0] + m->inertia[b][1] * li[1] * lj[1] + m->inertia[b][2] * li[2] * lj[2];
+        matT_vec3(li, w.k.xmat[b], jwi);
+        matT_vec3(lj, w.k.xmat[b], jwj);
+        s += lm.inertia[b][0] * li[0] * lj[0] + lm.inertia[b][1] * li[1] * lj[1] + lm.inertia[b][2] * li[2] * lj[2];
       }
     }
     w.Minv[i][j] = s; w.Minv[j][i] = s;
@@ -198,27 +213,25 @@ __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const KDeviceModel* dm, i
 
 // velocity-product + gravity wrenches per body (serial forward pass), then bias_j = sum_b J_bj^T wrench_b
 template <int NL>
-__device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const KModelDesc* m) {
-  const int nl = m->nlink;
-  // reuse Lw rows as scratch for (omega, alpha, a_origin) of each link: 9 numbers per link
-  real (*kinv)[NL] = w.Lw;   // flat scratch view
-  real* scratch = &kinv[0][0];
-  for (int i = 0; i < nl; i++) {
-    const int p = m->link_parent[i];
+__device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m) {
+  real* scratch = &w.f.Lw[0][0];   // (omega, alpha, a_origin) per link: 9 numbers each
+  for (int i = 0; i < NL; i++) {
+    const int p = lm.parent[i];
     real wp[3] = {0, 0, 0}, alp[3] = {0, 0, 0}, ap[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]}, op[3] = {0, 0, 0};
     if (p >= 0) {
 #pragma unroll
-      for (int c = 0; c < 3; c++) { wp[c] = scratch[9 * p + c]; alp[c] = scratch[9 * p + 3 + c]; ap[c] = scratch[9 * p + 6 + c]; op[c] = w.xpos[p][c]; }
+      for (int c = 0; c < 3; c++) { wp[c] = scratch[9 * p + c]; alp[c] = scratch[9 * p + 3 + c]; ap[c] = scratch[9 * p + 6 + c]; op[c] = w.k.xpos[p][c]; }
     }
-    real r[3] = {w.xpos[i][0] - op[0], w.xpos[i][1] - op[1], w.xpos[i][2] - op[2]};
+    real r[3] = {w.k.xpos[i][0] - op[0], w.k.xpos[i][1] - op[1], w.k.xpos[i][2] - op[2]};
     real t1[3], t2[3], ai[3], wi[3], ali[3];
     cross3(t1, alp, r);
     cross3(t2, wp, r); cross3(t2, wp, t2);
-    real ax[3] = {w.axis[i][0] * w.qvel[i], w.axis[i][1] * w.qvel[i], w.axis[i][2] * w.qvel[i]}, cz[3];
+    const real qv = w.qvel[i];
+    real ax[3] = {w.k.axis[i][0] * qv, w.k.axis[i][1] * qv, w.k.axis[i][2] * qv}, cz[3];
     cross3(cz, wp, ax);
 #pragma unroll
     for (int c = 0; c < 3; c++) { ai[c] = ap[c] + t1[c] + t2[c]; wi[c] = wp[c]; ali[c] = alp[c]; }
-    if (m->jnt_type[i] == KM_JNT_SLIDE) {
+    if (lm.jtype[i] == KM_JNT_SLIDE) {
 #pragma unroll
       for (int c = 0; c < 3; c++) ai[c] += 2 * cz[c];
     } else {
@@ -227,40 +240,38 @@ __device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const KModelDesc* 
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) { scratch[9 * i + c] = wi[c]; scratch[9 * i + 3 + c] = ali[c]; scratch[9 * i + 6 + c] = ai[c]; }
-    real cr[3] = {w.cpos[i][0] - w.xpos[i][0], w.cpos[i][1] - w.xpos[i][1], w.cpos[i][2] - w.xpos[i][2]};
+    real cr[3] = {w.k.cpos[i][0] - w.k.xpos[i][0], w.k.cpos[i][1] - w.k.xpos[i][1], w.k.cpos[i][2] - w.k.xpos[i][2]};
     cross3(t1, ali, cr);
     cross3(t2, wi, cr); cross3(t2, wi, t2);
     real wl[3], all[3], Iw[3], nl3[3], nw[3];
-    matT_vec3(wl, w.xmat[i], wi);
-    matT_vec3(all, w.xmat[i], ali);
+    matT_vec3(wl, w.k.xmat[i], wi);
+    matT_vec3(all, w.k.xmat[i], ali);
 #pragma unroll
-    for (int c = 0; c < 3; c++) Iw[c] = m->inertia[i][c] * wl[c];
+    for (int c = 0; c < 3; c++) Iw[c] = lm.inertia[i][c] * wl[c];
     cross3(nl3, wl, Iw);
 #pragma unroll
-    for (int c = 0; c < 3; c++) nl3[c] += m->inertia[i][c] * all[c];
-    mat_vec3(nw, w.xmat[i], nl3);
+    for (int c = 0; c < 3; c++) nl3[c] += lm.inertia[i][c] * all[c];
+    mat_vec3(nw, w.k.xmat[i], nl3);
 #pragma unroll
-    for (int c = 0; c < 3; c++) { w.FN[i][c] = m->mass[i] * (ai[c] + t1[c] + t2[c]); w.FN[i][3 + c] = nw[c]; }
+    for (int c = 0; c < 3; c++) { w.f.FN[i][c] = lm.mass[i] * (ai[c] + t1[c] + t2[c]); w.f.FN[i][3 + c] = nw[c]; }
   }
   // cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
-  real wv[3] = {w.qvel[nl + 3], w.qvel[nl + 4], w.qvel[nl + 5]};
+  real wv[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
   real Iw[3] = {m->cube_inertia[0] * wv[0], m->cube_inertia[1] * wv[1], m->cube_inertia[2] * wv[2]}, t[3];
   cross3(t, wv, Iw);
 #pragma unroll
-  for (int c = 0; c < 3; c++) { w.bias[nl + c] = -m->cube_mass * m->gravity[c]; w.bias[nl + 3 + c] = t[c]; }
+  for (int c = 0; c < 3; c++) { w.bias[NL + c] = -m->cube_mass * m->gravity[c]; w.bias[NL + 3 + c] = t[c]; }
 }
 template <int NL, int G>
-__device__ __forceinline__ void bias_project(Ws<NL>& w, const KDeviceModel* dm, int sub) {
-  const KModelDesc* m = &dm->d;
-  const int nl = m->nlink;
-  for (int j = sub; j < nl; j += G) {
+__device__ __forceinline__ void bias_project(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+  for (int j = sub; j < NL; j += G) {
     real s = 0;
-    for (int b = j; b < nl; b++) {
-      if (!((dm->x.anc_mask[b] >> j) & 1u)) continue;
+    for (int b = j; b < NL; b++) {
+      if (!((lm.anc[b] >> j) & 1u)) continue;
       real jv[3], jw[3];
-      com_jac_col<NL>(w, m, b, j, jv, jw);
-      s += jv[0] * w.FN[b][0] + jv[1] * w.FN[b][1] + jv[2] * w.FN[b][2];
-      s += jw[0] * w.FN[b][3] + jw[1] * w.FN[b][4] + jw[2] * w.FN[b][5];
+      com_jac_col<NL>(w, lm, b, j, jv, jw);
+      s += jv[0] * w.f.FN[b][0] + jv[1] * w.f.FN[b][1] + jv[2] * w.f.FN[b][2];
+      s += jw[0] * w.f.FN[b][3] + jw[1] * w.f.FN[b][4] + jw[2] * w.f.FN[b][5];
     }
     w.bias[j] = s;
   }
@@ -269,48 +280,47 @@ __device__ __forceinline__ void bias_project(Ws<NL>& w, const KDeviceModel* dm, 
 // Minv <- inverse of the SPD joint-space inertia held in Minv: cooperative left-looking Cholesky
 // (lane i owns row i), L^-1 by forward substitution (lane j owns column j), M^-1 = L^-T L^-1.
 template <int NL, int G>
-__device__ __forceinline__ void invert_mass(Ws<NL>& w, int nl, int sub) {
+__device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub) {
   real tr = 0;
-  for (int i = 0; i < nl; i++) tr += w.Minv[i][i];
+  for (int i = 0; i < NL; i++) tr += w.Minv[i][i];
   if (sub == 0) w.Mtrace = tr;
-  for (int k = 0; k < nl; k++) {
-    if (sub >= k && sub < nl) {
+  for (int k = 0; k < NL; k++) {
+    if (sub >= k && sub < NL) {
       real s = w.Minv[sub][k];
-      for (int t = 0; t < k; t++) s -= w.Lw[sub][t] * w.Lw[k][t];
-      w.Lw[sub][k] = s;
+      for (int t = 0; t < k; t++) s -= w.f.Lw[sub][t] * w.f.Lw[k][t];
+      w.f.Lw[sub][k] = s;
     }
     GSYNC();
-    real dk = w.Lw[k][k];
+    real dk = w.f.Lw[k][k];
     if (!(dk > 0)) { w.bad = 1; dk = 1; }
     real d = sqrt(dk);
     GSYNC();
-    if (sub == k) w.Lw[k][k] = d;
-    else if (sub > k && sub < nl) w.Lw[sub][k] = w.Lw[sub][k] / d;
+    if (sub == k) w.f.Lw[k][k] = d;
+    else if (sub > k && sub < NL) w.f.Lw[sub][k] = w.f.Lw[sub][k] / d;
     GSYNC();
   }
   // lane j: column j of L^-1 into Minv (lower part), x_j = 1/L_jj, x_i = -(sum_{t=j}^{i-1} L_it x_t) / L_ii
-  if (sub < nl) {
+  if (sub < NL) {
     const int j = sub;
-    for (int i = 0; i < nl; i++) {
+    for (int i = 0; i < NL; i++) {
       real x = 0;
-      if (i == j) x = 1.0 / w.Lw[j][j];
+      if (i == j) x = 1.0 / w.f.Lw[j][j];
       else if (i > j) {
         real s = 0;
-        for (int t = j; t < i; t++) s += w.Lw[i][t] * w.Minv[t][j];
-        x = -s / w.Lw[i][i];
+        for (int t = j; t < i; t++) s += w.f.Lw[i][t] * w.Minv[t][j];
+        x = -s / w.f.Lw[i][i];
       }
       w.Minv[i][j] = x;
     }
   }
   GSYNC();
-  // copy L^-1 to Lw, then Minv[i][j] = sum_{t >= max(i,j)} Linv[t][i] Linv[t][j]
-  if (sub < nl) for (int i = 0; i < nl; i++) w.Lw[i][sub] = w.Minv[i][sub];
+  if (sub < NL) for (int i = 0; i < NL; i++) w.f.Lw[i][sub] = w.Minv[i][sub];
   GSYNC();
-  if (sub < nl) {
+  if (sub < NL) {
     const int j = sub;
-    for (int i = 0; i < nl; i++) {
+    for (int i = 0; i < NL; i++) {
       real s = 0;
-      for (int t = (i > j ? i : j); t < nl; t++) s += w.Lw[t][i] * w.Lw[t][j];
+      for (int t = (i > j ? i : j); t < NL; t++) s += w.f.Lw[t][i] * w.f.Lw[t][j];
       w.Minv[i][j] = s;
     }
   }
@@ -329,42 +339,45 @@ __device__ __forceinline__ void make_frame(real* fr) {
   cross3(fr + 6, fr, fr + 3);
 }
 
-// narrow phase for the fixed candidate set: plane-box (first 4 corners below the table), sphere-box, plane-sphere
+// narrow phase for the fixed candidate set, written into fixed slots: plane-box (first 4 corners below the
+// table -> slots 0..3 in corner order), sphere-box (slot 4 + s), plane-sphere (slot 4 + NSPH + s)
 template <int NL>
 __device__ __forceinline__ void collide_serial(Ws<NL>& w, const KModelDesc* m) {
-  const int nl = m->nlink;
-  int n = 0, cnt = 0;
-  uint32_t mask = 0;
+  constexpr int NSPH = Dim<NL>::NSPH;
+  int cnt = 0;
+  uint32_t mask = 0, act = 0;
   int tfc = 0, tct = 0;
-  real cp[3] = {w.qpos[nl], w.qpos[nl + 1], w.qpos[nl + 2]};
+  real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
   for (int i = 0; i < 8 && cnt < 4; i++) {
     real loc[3] = {(i & 1 ? 1 : -1) * m->cube_half[0], (i & 2 ? 1 : -1) * m->cube_half[1], (i & 4 ? 1 : -1) * m->cube_half[2]}, c[3];
-    mat_vec3(c, w.cube_mat, loc);
+    mat_vec3(c, w.k.cube_mat, loc);
     c[0] += cp[0]; c[1] += cp[1]; c[2] += cp[2];
     real dist = c[2] - m->table_z;
     if (dist < 0) {
+      const int n = cnt;
       real fr[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0};
       make_frame(fr);
 #pragma unroll
       for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
       w.c_dist[n] = dist;
       w.c_pos[n][0] = c[0]; w.c_pos[n][1] = c[1]; w.c_pos[n][2] = c[2] - 0.5 * dist;
-      w.c_b1[n] = -1; w.c_b2[n] = nl; w.c_dim[n] = 4; w.c_cube[n] = 1;
-      mask |= KM_CON_CUBE_TABLE(i); tct = 1; cnt++; n++;
+      mask |= KM_CON_CUBE_TABLE(i); act |= 1u << n; tct = 1; cnt++;
     }
   }
-  for (int s = 0; s < m->nsphere; s++) {
+  const int nsph = m->nsphere < NSPH ? m->nsphere : NSPH;
+  for (int s = 0; s < nsph; s++) {
     const int l = m->sphere_link[s];
     real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, ctr[3], rel[3], loc[3], cl[3];
-    mat_vec3(ctr, w.xmat[l], sl);
+    mat_vec3(ctr, w.k.xmat[l], sl);
 #pragma unroll
-    for (int a = 0; a < 3; a++) { ctr[a] += w.xpos[l][a]; rel[a] = ctr[a] - cp[a]; }
-    matT_vec3(loc, w.cube_mat, rel);
+    for (int a = 0; a < 3; a++) { ctr[a] += w.k.xpos[l][a]; rel[a] = ctr[a] - cp[a]; }
+    const real rad = m->sphere_radius[s];
+    // sphere (geom1) - cube box (geom2)
+    matT_vec3(loc, w.k.cube_mat, rel);
     bool inside = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) { cl[a] = fmin(fmax(loc[a], -m->cube_half[a]), m->cube_half[a]); if (cl[a] != loc[a]) inside = false; }
     real nloc[3], dist;
-    const real rad = m->sphere_radius[s];
     if (!inside) {
       nloc[0] = cl[0] - loc[0]; nloc[1] = cl[1] - loc[1]; nloc[2] = cl[2] - loc[2];
       real dn = normalize3(nloc);
@@ -374,43 +387,36 @@ __device__ __forceinline__ void collide_serial(Ws<NL>& w, const KModelDesc* m) {
 #pragma unroll
       for (int a = 0; a < 3; a++) { real dd = m->cube_half[a] - fabs(loc[a]); if (dd < bd) { bd = dd; best = a; } }
       nloc[0] = 0; nloc[1] = 0; nloc[2] = 0;
-      real sg = loc[best] >= 0 ? -1.0 : 1.0;
+      real sg = (best == 0 ? loc[0] : (best == 1 ? loc[1] : loc[2])) >= 0 ? -1.0 : 1.0;
       if (best == 0) nloc[0] = sg; else if (best == 1) nloc[1] = sg; else nloc[2] = sg;
       dist = -bd - rad;
     }
     if (dist < 0) {
+      const int n = 4 + s;
       real fr[9];
-      mat_vec3(fr, w.cube_mat, nloc);
+      mat_vec3(fr, w.k.cube_mat, nloc);
       make_frame(fr);
 #pragma unroll
       for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
       w.c_dist[n] = dist;
 #pragma unroll
       for (int a = 0; a < 3; a++) w.c_pos[n][a] = ctr[a] + fr[a] * (rad + 0.5 * dist);
-      w.c_b1[n] = l; w.c_b2[n] = nl; w.c_dim[n] = 4; w.c_cube[n] = 1;
-      mask |= KM_CON_FINGER_CUBE(s); tfc = 1; n++;
+      mask |= KM_CON_FINGER_CUBE(s); act |= 1u << n; tfc = 1;
     }
-  }
-  for (int s = 0; s < m->nsphere; s++) {
-    const int l = m->sphere_link[s];
-    real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, ctr[3];
-    mat_vec3(ctr, w.xmat[l], sl);
-#pragma unroll
-    for (int a = 0; a < 3; a++) ctr[a] += w.xpos[l][a];
-    const real rad = m->sphere_radius[s];
-    real dist = ctr[2] - m->table_z - rad;
-    if (dist < 0) {
+    // table plane (geom1) - sphere (geom2)
+    real dist2 = ctr[2] - m->table_z - rad;
+    if (dist2 < 0) {
+      const int n = 4 + NSPH + s;
       real fr[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0};
       make_frame(fr);
 #pragma unroll
       for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
-      w.c_dist[n] = dist;
-      w.c_pos[n][0] = ctr[0]; w.c_pos[n][1] = ctr[1]; w.c_pos[n][2] = ctr[2] - (rad + 0.5 * dist);
-      w.c_b1[n] = -1; w.c_b2[n] = l; w.c_dim[n] = 3; w.c_cube[n] = 0;
-      mask |= KM_CON_FINGER_TABLE(s); n++;
+      w.c_dist[n] = dist2;
+      w.c_pos[n][0] = ctr[0]; w.c_pos[n][1] = ctr[1]; w.c_pos[n][2] = ctr[2] - (rad + 0.5 * dist2);
+      mask |= KM_CON_FINGER_TABLE(s); act |= 1u << n;
     }
   }
-  w.ncon = n; w.contact_mask = mask; w.touch_fc = tfc; w.touch_ct = tct;
+  w.cact = act; w.contact_mask = mask; w.touch_fc = tfc; w.touch_ct = tct;
 }
 
 // MuJoCo impedance / reference acceleration parameters
@@ -435,59 +441,57 @@ __device__ __forceinline__ void get_kb(const KModelDesc* m, const real* sr, cons
 
 // linear/angular velocity Jacobian column of dof j for a world point `pt` fixed to body `body`
 template <int NL>
-__device__ __forceinline__ void point_jac_col(const Ws<NL>& w, const KDeviceModel* dm, int body, int j, const real* pt,
+__device__ __forceinline__ void point_jac_col(const Ws<NL>& w, const LModel<NL>& lm, int body, int j, const real* pt,
                                               real* jp, real* jr) {
-  const KModelDesc* m = &dm->d;
-  const int nl = m->nlink;
   jp[0] = 0; jp[1] = 0; jp[2] = 0; jr[0] = 0; jr[1] = 0; jr[2] = 0;
   if (body < 0) return;
-  if (body < nl) {
-    if (j >= nl || !((dm->x.anc_mask[body] >> j) & 1u)) return;
-    if (m->jnt_type[j] == KM_JNT_SLIDE) { jp[0] = w.axis[j][0]; jp[1] = w.axis[j][1]; jp[2] = w.axis[j][2]; }
+  if (body < NL) {
+    if (j >= NL || !((lm.anc[body] >> j) & 1u)) return;
+    if (lm.jtype[j] == KM_JNT_SLIDE) { jp[0] = w.k.axis[j][0]; jp[1] = w.k.axis[j][1]; jp[2] = w.k.axis[j][2]; }
     else {
-      real ax[3] = {w.axis[j][0], w.axis[j][1], w.axis[j][2]};
-      real r[3] = {pt[0] - w.xpos[j][0], pt[1] - w.xpos[j][1], pt[2] - w.xpos[j][2]};
+      real ax[3] = {w.k.axis[j][0], w.k.axis[j][1], w.k.axis[j][2]};
+      real r[3] = {pt[0] - w.k.xpos[j][0], pt[1] - w.k.xpos[j][1], pt[2] - w.k.xpos[j][2]};
       cross3(jp, ax, r);
       jr[0] = ax[0]; jr[1] = ax[1]; jr[2] = ax[2];
     }
     return;
   }
-  if (j < nl) return;
-  const int e = j - nl;
-  if (e < 3) { jp[e] = 1; return; }
+  if (j < NL) return;
+  const int e = j - NL;
+  if (e < 3) { jp[0] = e == 0; jp[1] = e == 1; jp[2] = e == 2; return; }
   const int k = e - 3;
-  real col[3] = {w.cube_mat[k], w.cube_mat[3 + k], w.cube_mat[6 + k]};
-  real r[3] = {pt[0] - w.qpos[nl], pt[1] - w.qpos[nl + 1], pt[2] - w.qpos[nl + 2]};
+  real col[3] = {w.k.cube_mat[k], w.k.cube_mat[3 + k], w.k.cube_mat[6 + k]};
+  real r[3] = {pt[0] - w.qpos[NL], pt[1] - w.qpos[NL + 1], pt[2] - w.qpos[NL + 2]};
   cross3(jp, col, r);
   jr[0] = col[0]; jr[1] = col[1]; jr[2] = col[2];
 }
 
-// single-dof rows in mj_makeConstraint order (friction loss, then limits), enumerated by lane 0
+// arm single-dof rows in mj_makeConstraint order (friction loss, then limits), enumerated by one lane
 template <int NL>
-__device__ __forceinline__ void scalar_rows_serial(Ws<NL>& w, const KModelDesc* m) {
-  const int nl = m->nlink, nv = nl + 6;
+__device__ __forceinline__ void scalar_rows_serial(Ws<NL>& w, const LModel<NL>& lm) {
   int n = 0;
-  for (int j = 0; j < nv; j++) {
-    real fl = j < nl ? m->frictionloss[j] : m->cube_frictionloss;
+  for (int j = 0; j < NL; j++) {
+    real fl = lm.floss[j];
     if (fl > 0) { w.s_dof[n] = j; w.s_type[n] = 0; w.s_sign[n] = 1; w.s_pos[n] = 0; w.s_floss[n] = fl; n++; }
   }
-  for (int j = 0; j < nl; j++) {
-    real dl = w.qpos[j] - m->jnt_range[j][0], du = m->jnt_range[j][1] - w.qpos[j];
+  for (int j = 0; j < NL; j++) {
+    real dl = w.qpos[j] - lm.range[j][0], du = lm.range[j][1] - w.qpos[j];
     if (dl < 0) { w.s_dof[n] = j; w.s_type[n] = 1; w.s_sign[n] = 1; w.s_pos[n] = dl; w.s_floss[n] = 0; n++; }
     if (du < 0) { w.s_dof[n] = j; w.s_type[n] = 1; w.s_sign[n] = -1; w.s_pos[n] = du; w.s_floss[n] = 0; n++; }
   }
   w.ns = n;
 }
 
+// Constraint assembly.  Arm single-dof rows: parameters in LDS (parallel over rows).  Contacts: this lane's
+// Jacobian column of each basis row in registers (cr.jb), B = M^-1 J^T columns (cr.bb), then per-contact
+// Gram / edge tables (group-uniform) in LDS.
 template <int NL, int G>
-__device__ __forceinline__ void build_constraints(Ws<NL>& w, const KDeviceModel* dm, int sub) {
-  constexpr int NV = Dim<NL>::NV;
-  const KModelDesc* m = &dm->d;
-  const int nl = m->nlink, nv = nl + 6;
-  // single-dof rows: parameters in parallel over rows
+__device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
+                                                  CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   for (int r = sub; r < w.ns; r += G) {
     const int j = w.s_dof[r];
-    real Ad = j < nl ? w.Minv[j][j] : (j < nl + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[j - nl - 3]);
+    real Ad = w.Minv[j][j];
     real pos = w.s_pos[r];
     real imp = impedance(m->con_def_solimp, pos), kk, bb;
     get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
@@ -497,80 +501,103 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const KDeviceModel*
     w.s_inv[r] = 1.0 / (Ad + R);
     w.s_aref[r] = -bb * (w.s_sign[r] * w.qvel[j]) - kk * imp * pos;
   }
-  // contact bases J (normal, 2 tangents, torsion): lane j builds column j of every contact
-  const int nc = w.ncon;
-  for (int j = sub; j < nv; j += G) {
-    for (int c = 0; c < nc; c++) {
+  const uint32_t act = w.cact;
+  // ---- J columns (needs kinematics, which the Gram tables will overwrite: finish all slots first)
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    constexpr int dummy = 0; (void)dummy;
+    cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
+    if (((act >> c) & 1u) && sub < NV) {
+      const int kind = slot_kind<NL>(c);
+      const int link = kind == 0 ? -1 : m->sphere_link[slot_sphere<NL>(c) < 0 ? 0 : slot_sphere<NL>(c)];
+      const int b1 = kind == 1 ? link : -1, b2 = kind == 2 ? link : NL;   // geom1 / geom2 bodies
       real pt[3] = {w.c_pos[c][0], w.c_pos[c][1], w.c_pos[c][2]};
       real p1[3], r1[3], p2[3], r2[3];
-      point_jac_col<NL>(w, dm, w.c_b1[c], j, pt, p1, r1);
-      point_jac_col<NL>(w, dm, w.c_b2[c], j, pt, p2, r2);
+      point_jac_col<NL>(w, lm, b1, sub, pt, p1, r1);
+      point_jac_col<NL>(w, lm, b2, sub, pt, p2, r2);
       real dl[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, dr[3] = {r2[0] - r1[0], r2[1] - r1[1], r2[2] - r1[2]};
-      w.c_Jb[c][0][j] = dot3(w.c_frame[c], dl);
-      w.c_Jb[c][1][j] = dot3(w.c_frame[c] + 3, dl);
-      w.c_Jb[c][2][j] = dot3(w.c_frame[c] + 6, dl);
-      w.c_Jb[c][3][j] = dot3(w.c_frame[c], dr);
+      cr.jb[c][0] = dot3(w.c_frame[c], dl);
+      cr.jb[c][1] = dot3(w.c_frame[c] + 3, dl);
+      cr.jb[c][2] = dot3(w.c_frame[c] + 6, dl);
+      cr.jb[c][3] = dot3(w.c_frame[c], dr);
     }
   }
   GSYNC();
-  // B = M^-1 J^T per basis row: lane i builds component i
-  for (int i = sub; i < nv; i += G) {
-    for (int c = 0; c < nc; c++) {
+  // ---- B = M^-1 J^T for the slots with arm dofs: arm lanes need the whole row -> stage through LDS;
+  // cube lanes (and every lane of a table-cube slot) just scale by the diagonal
+#pragma unroll
+  for (int c = 4; c < NC; c++) {
+    cr.bb[c - 4][0] = 0; cr.bb[c - 4][1] = 0; cr.bb[c - 4][2] = 0; cr.bb[c - 4][3] = 0;
+    if ((act >> c) & 1u) {
+      if (sub < NV) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) w.stage[k][sub] = cr.jb[c][k];
+      }
+      GSYNC();
+      if (sub < NL) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          real s = 0;
+          for (int j = 0; j < NL; j++) s += w.Minv[sub][j] * w.stage[k][j];
+          cr.bb[c - 4][k] = s;
+        }
+      } else if (sub < NV) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) cr.bb[c - 4][k] = cr.jb[c][k] * invm;
+      }
+      GSYNC();
+    }
+  }
+  // ---- Gram matrix + edge tables per slot (all lanes get identical sums; lane 0 stores)
+  const real qv = sub < NV ? w.qvel[sub] : 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    if ((act >> c) & 1u) {
+      const int kind = slot_kind<NL>(c);
+      real Gm[4][4], vb[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        real s;
-        if (i < nl) { s = 0; for (int j = 0; j < nl; j++) s += w.Minv[i][j] * w.c_Jb[c][k][j]; }
-        else if (i < nl + 3) s = w.c_Jb[c][k][i] / m->cube_mass;
-        else s = w.c_Jb[c][k][i] / m->cube_inertia[i - nl - 3];
-        w.c_Bb[c][k][i] = s;
+        vb[k] = gsum<G>(cr.jb[c][k] * qv);
+#pragma unroll
+        for (int l = k; l < 4; l++) {
+          const real bl = c < 4 ? cr.jb[c][l] * invm : cr.bb[c < 4 ? 0 : c - 4][l];
+          Gm[k][l] = gsum<G>(cr.jb[c][k] * bl); Gm[l][k] = Gm[k][l];
+        }
       }
+      const bool cube = kind != 2;
+      const real* fr = cube ? m->con_cube_friction : m->con_def_friction;
+      const real* sr = cube ? m->con_cube_solref : m->con_def_solref;
+      const real* si = cube ? m->con_cube_solimp : m->con_def_solimp;
+      real mu[3] = {fr[0], fr[0], fr[1]};
+      const real dist = w.c_dist[c];
+      real imp = impedance(si, dist), kk, bb;
+      get_kb(m, sr, si, kk, bb);
+      const int ne = kind == 2 ? 4 : 6;
+      real R = 0;
+      ConRec& rc = w.rec[c];
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        const int k = e / 2 + 1;
+        const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
+        real Ge[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) Ge[l] = Gm[l][0] + sm * Gm[l][k];        // J_l . M^-1 (J_0 + sm J_k)^T
+        const real Ad = Ge[0] + sm * Ge[k];
+        if (e == 0) R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+        const real vel = vb[0] + sm * vb[k];
+        if (sub == 0) {
+          rc.den[e] = Ad + R;
+          rc.inv[e] = e < ne ? 1.0 / (Ad + R) : 0.0;
+          rc.aref[e] = -bb * vel - kk * imp * dist;
+          rc.f[e] = 0;
+#pragma unroll
+          for (int l = 0; l < 4; l++) w.p.Ge[c][e][l] = Ge[l];
+        }
+      }
+      if (sub == 0) { rc.R = R; rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2]; }
     }
   }
   GSYNC();
-  // per-contact Gram matrix, edge parameters (pyramidal cone, MuJoCo mj_makeImpedance)
-  for (int c = sub; c < nc; c += G) {
-    real Gm[4][4], vb[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      real s = 0;
-      for (int j = 0; j < nv; j++) s += w.c_Jb[c][k][j] * w.qvel[j];
-      vb[k] = s;
-#pragma unroll
-      for (int l = 0; l < 4; l++) {
-        real g = 0;
-        for (int j = 0; j < nv; j++) g += w.c_Jb[c][k][j] * w.c_Bb[c][l][j];
-        Gm[k][l] = g;
-      }
-    }
-    const real* fr = w.c_cube[c] ? m->con_cube_friction : m->con_def_friction;
-    const real* sr = w.c_cube[c] ? m->con_cube_solref : m->con_def_solref;
-    const real* si = w.c_cube[c] ? m->con_cube_solimp : m->con_def_solimp;
-    real mu[3] = {fr[0], fr[0], fr[1]};
-    const real dist = w.c_dist[c];
-    real imp = impedance(si, dist), kk, bb;
-    get_kb(m, sr, si, kk, bb);
-    const int ne = 2 * (w.c_dim[c] - 1);
-    ConRec& rc = w.c_rec[c];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int l = k; l < 4; l++) rc.G[gidx(k, l)] = 0.5 * (Gm[k][l] + Gm[l][k]);
-    rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2];
-    rc.A[0] = -bb * vb[0] - kk * imp * dist;
-    rc.A[1] = -bb * vb[1]; rc.A[2] = -bb * vb[2]; rc.A[3] = -bb * vb[3];
-    real R = 0;
-#pragma unroll
-    for (int e = 0; e < 6; e++) {
-      const int k = e / 2 + 1;
-      const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
-      real Ad = Gm[0][0] + sm * (Gm[0][k] + Gm[k][0]) + sm * sm * Gm[k][k];
-      if (e == 0) { R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad); rc.R = R; }
-      rc.inv[e] = e < ne ? 1.0 / (Ad + R) : 0.0;
-      rc.f[e] = 0;
-    }
-  }
-  GSYNC();
-  (void)NV;
 }
 
 // one Gauss-Seidel update of a non-negative / box-bounded row (returns delta f); inv = 1 / den
@@ -588,31 +615,43 @@ __device__ __forceinline__ real pgs_row(real Ja, real aref, real R, real den, re
 // mj_step2 up to (not including) integration: actuation, qacc_smooth, warm start, PGS.  Returns this
 // lane's component of qacc (lane `sub` owns dof `sub`).
 template <int NL, int G>
-__device__ __forceinline__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, int sub, int actuation) {
-  const KModelDesc* m = &dm->d;
-  const int nl = m->nlink, nv = nl + 6;
+__device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
+                                            CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   // ---- actuation (position servos on actuator_length = q at mj_step1 time) and smooth acceleration
-  real invm = 0;                                  // diagonal of M^-1 for the cube dofs (lane-local)
-  if (sub >= nl && sub < nv) invm = sub < nl + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - nl - 3];
-  if (sub < nv) {
+  if (sub < NV) {
     real rhs = -w.bias[sub];
-    if (actuation && sub < nl) {
-      real c = fmin(fmax(w.ctrl[sub], m->ctrlrange[sub][0]), m->ctrlrange[sub][1]);
-      real force = m->kp[sub] * c - m->kp[sub] * w.qpos[sub];
-      if (m->forcelimited[sub]) force = fmin(fmax(force, m->forcerange[sub][0]), m->forcerange[sub][1]);
+    if (actuation && sub < NL) {
+      real c = fmin(fmax(w.ctrl[sub], lm.ctrlrange[sub][0]), lm.ctrlrange[sub][1]);
+      real force = lm.kp[sub] * c - lm.kp[sub] * w.qpos[sub];
+      if (lm.forcelimited[sub]) force = fmin(fmax(force, lm.forcerange[sub][0]), lm.forcerange[sub][1]);
       rhs += force;
     }
     w.tmp[sub] = rhs;
   }
   GSYNC();
   real a_s = 0;
-  if (sub < nl) { for (int j = 0; j < nl; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
-  else if (sub < nv) a_s = w.tmp[sub] * invm;
-  if (sub < nv) w.as[sub] = a_s;
+  if (sub < NL) { for (int j = 0; j < NL; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
+  else if (sub < NV) a_s = w.tmp[sub] * invm;
+  if (sub < NV) w.as[sub] = a_s;
   GSYNC();
-  const int ns = w.ns, nc = w.ncon;
+  const int ns = w.ns;
+  const uint32_t act = w.cact;
+  const real warm = sub < NV ? w.warm[sub] : 0.0;
+  // ---- the cube's friction-loss row owned by this lane (registers only)
+  const bool my_row = sub >= NL && sub < NV && m->cube_frictionloss > 0;
+  real my_f = 0, my_aref = 0, my_R = 1, my_den = 1, my_inv = 0;
+  const real my_fl = m->cube_frictionloss;
+  if (my_row) {
+    real imp = impedance(m->con_def_solimp, 0.0), kk, bb;
+    get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
+    my_R = fmax(MJ_MINVAL, (1 - imp) / imp * invm);
+    my_den = invm + my_R;
+    my_inv = 1.0 / my_den;
+    my_aref = -bb * w.qvel[sub];
+  }
   // ---- warm start: forces implied by qacc_warmstart, kept only if the dual cost is negative
-  real cost_rows = 0;
+  real cost_rows = 0, y = 0;
   for (int r = sub; r < ns; r += G) {
     const int j = w.s_dof[r];
     const real sg = w.s_sign[r], R = w.s_R[r], aref = w.s_aref[r];
@@ -622,175 +661,153 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const KDeviceModel* dm, i
     w.s_f[r] = f;
     cost_rows += 0.5 * R * f * f + f * (sg * w.as[j] - aref);
   }
-  for (int c = sub; c < nc; c += G) {
-    real wk[4], ak[4];
+  if (my_row) {
+    real jar = warm - my_aref;
+    my_f = (jar <= -my_R * my_fl) ? my_fl : ((jar >= my_R * my_fl) ? -my_fl : -jar / my_R);
+    cost_rows += 0.5 * my_R * my_f * my_f + my_f * (a_s - my_aref);
+    y += my_f;
+  }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      real s1 = 0, s2 = 0;
-      for (int j = 0; j < nv; j++) { s1 += w.c_Jb[c][k][j] * w.warm[j]; s2 += w.c_Jb[c][k][j] * w.as[j]; }
-      wk[k] = s1; ak[k] = s2;
-    }
-    const int ne = 2 * (w.c_dim[c] - 1);
-    ConRec& rc = w.c_rec[c];
-    const real R = rc.R;
+  for (int c = 0; c < NC; c++) {
+    if ((act >> c) & 1u) {
+      real wk[4], ak[4], F[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int e = 0; e < 6; e++) {
-      const int k = e / 2 + 1;
-      const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
-      const real aref = rc.A[0] + sm * rc.A[k];
-      real jar = wk[0] + sm * wk[k] - aref;
-      real f = (e < ne && jar < 0) ? -jar / R : 0.0;
-      rc.f[e] = f;
-      cost_rows += 0.5 * R * f * f + f * (ak[0] + sm * ak[k] - aref);
+      for (int k = 0; k < 4; k++) { wk[k] = gsum<G>(cr.jb[c][k] * warm); ak[k] = gsum<G>(cr.jb[c][k] * a_s); }
+      ConRec& rc = w.rec[c];
+      const real R = rc.R;
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        const int k = e / 2 + 1;
+        const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+        const real aref = rc.aref[e];
+        real jar = wk[0] + sm * wk[k] - aref;
+        real f = (rc.inv[e] != 0 && jar < 0) ? -jar / R : 0.0;
+        if (sub == 0) { rc.f[e] = f; cost_rows += 0.5 * R * f * f + f * (ak[0] + sm * ak[k] - aref); }
+        F[0] += f; F[k] += sm * f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) y += cr.jb[c][k] * F[k];
     }
   }
   GSYNC();
   // y = J^T f (lane j), z = M^-1 y
-  real y = 0;
-  if (sub < nv) {
-    for (int r = 0; r < ns; r++) if (w.s_dof[r] == sub) y += w.s_sign[r] * w.s_f[r];
-    for (int c = 0; c < nc; c++) {
-      const ConRec& rc = w.c_rec[c];
-      real F[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int e = 0; e < 6; e++) {
-        const int k = e / 2 + 1;
-        const real f = rc.f[e];
-        F[0] += f;
-        F[k] += ((e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1]) * f;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) y += w.c_Jb[c][k][sub] * F[k];
-    }
-    w.tmp[sub] = y;
-  }
+  if (sub < NL) { for (int r = 0; r < ns; r++) if (w.s_dof[r] == sub) y += w.s_sign[r] * w.s_f[r]; }
+  if (sub < NV) w.tmp[sub] = y;
   GSYNC();
   real z = 0;
-  if (sub < nl) { for (int j = 0; j < nl; j++) z += w.Minv[sub][j] * w.tmp[j]; }
-  else if (sub < nv) z = y * invm;
+  if (sub < NL) { for (int j = 0; j < NL; j++) z += w.Minv[sub][j] * w.tmp[j]; }
+  else if (sub < NV) z = y * invm;
   const real cost = gsum<G>(0.5 * y * z + cost_rows);
   real a = a_s;
   if (cost > 0) {
     for (int r = sub; r < ns; r += G) w.s_f[r] = 0;
-    for (int c = sub; c < nc; c += G) for (int e = 0; e < 6; e++) w.c_rec[c].f[e] = 0;
+    for (int c = sub; c < NC; c += G) for (int e = 0; e < 6; e++) w.rec[c].f[e] = 0;
+    my_f = 0;
   } else a += z;
   GSYNC();
   // ---- projected Gauss-Seidel in acceleration space: a = a_s + M^-1 J^T f kept distributed (lane = dof).
-  // Row order = mj_makeConstraint order.  Rows on the cube's own dofs (its friction loss) touch only the
-  // diagonal block of M^-1, so the owning lane updates them locally -- identical to processing them one
-  // after another, and no cross-lane traffic.  Rows on arm dofs need one broadcast each; a contact needs
-  // four DPP row reductions (its basis projections), then its 4-6 pyramid edges run on the 4x4 Gram form.
+  // Row order = mj_makeConstraint order.  The cube's friction-loss rows touch only the diagonal block of
+  // M^-1, so the owning lanes update them locally and simultaneously -- identical to one after another,
+  // and no cross-lane traffic.  A row on an arm dof needs one broadcast; a contact needs four DPP row
+  // reductions (its basis projections u = J a), then its pyramid edges run on precomputed Gram rows.
   const real scale = 1.0 / (w.Mtrace + 3 * m->cube_mass + m->cube_inertia[0] + m->cube_inertia[1] + m->cube_inertia[2]);
-  // the (at most one) cube friction-loss row owned by this lane, kept in registers across sweeps
-  int my_row = -1;
-  for (int r = 0; r < ns; r++) if (w.s_dof[r] == sub && sub >= nl && w.s_type[r] == 0) my_row = r;
-  real my_f = 0, my_aref = 0, my_R = 0, my_den = 1, my_inv = 0, my_fl = 0;
-  if (my_row >= 0) {
-    my_f = w.s_f[my_row]; my_aref = w.s_aref[my_row]; my_R = w.s_R[my_row]; my_den = w.s_den[my_row];
-    my_inv = w.s_inv[my_row]; my_fl = w.s_floss[my_row];
-  }
-  for (int iter = 0; iter < m->solver_iterations; iter++) {
+  const int maxit = m->solver_iterations;
+  const real tol = m->solver_tolerance;
+  for (int iter = 0; iter < maxit; iter++) {
     real improvement = 0, imp_local = 0;
     for (int r = 0; r < ns; r++) {
       const int j = w.s_dof[r];
-      if (j >= nl) continue;                               // cube rows: lane-local, below
       const real sg = w.s_sign[r];
-      const real Ja = sg * __shfl(a, j, G);
       const real f = w.s_f[r];
-      const real mij = sub < nl ? w.Minv[sub][j] : 0.0;
+      const real mij = sub < NL ? w.Minv[sub][j] : 0.0;
+      const real Ja = sg * __shfl(a, j, G);
       const real dlt = pgs_row(Ja, w.s_aref[r], w.s_R[r], w.s_den[r], w.s_inv[r], f, w.s_type[r], w.s_floss[r], improvement);
       w.s_f[r] = f + dlt;
       a += sg * mij * dlt;
     }
-    if (my_row >= 0) {
+    if (my_row) {
       const real dlt = pgs_row(a, my_aref, my_R, my_den, my_inv, my_f, 0, my_fl, imp_local);
       my_f += dlt;
       a += dlt * invm;
     }
-    for (int c = 0; c < nc; c++) {
-      // block-load the contact record (group-uniform broadcast reads) and this lane's basis columns
-      const ConRec& rr = w.c_rec[c];
-      real Gs[10], mu[3], Ab[4], inv[6], f[6];
-      const real Rc = rr.R;
 #pragma unroll
-      for (int i = 0; i < 10; i++) Gs[i] = rr.G[i];
+    for (int c = 0; c < NC; c++) {
+      if ((act >> c) & 1u) {
+        // group-uniform tables come from LDS as broadcast reads (no stores in between: freely scheduled)
+        const ConRec& rr = w.rec[c];
+        const real Rc = rr.R;
+        real u[4], Dk[4] = {0, 0, 0, 0}, f[6];
 #pragma unroll
-      for (int i = 0; i < 3; i++) mu[i] = rr.mu[i];
+        for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
 #pragma unroll
-      for (int i = 0; i < 4; i++) Ab[i] = rr.A[i];
+        for (int e = 0; e < 6; e++) {
+          const int k = e / 2 + 1;
+          if (slot_kind<NL>(c) == 2 && e >= 4) { f[e] = 0; continue; }        // condim-3 pair: 4 edges
+          const real sm = (e & 1) ? -rr.mu[k - 1] : rr.mu[k - 1];
+          const real f0 = rr.f[e];
+          const real res = (u[0] + sm * u[k]) + (Rc * f0 - rr.aref[e]);
+          const real fn = fmax(f0 - res * rr.inv[e], 0.0);
+          const real dlt = fn - f0;
+          improvement -= dlt * (res + 0.5 * rr.den[e] * dlt);
+          f[e] = fn;
+          Dk[0] += dlt; Dk[k] += sm * dlt;
 #pragma unroll
-      for (int i = 0; i < 6; i++) { inv[i] = rr.inv[i]; f[i] = rr.f[i]; }
-      real jb[4], bb[4], u[4], Dk[4] = {0, 0, 0, 0};
+          for (int l = 0; l < 4; l++) u[l] += w.p.Ge[c][e][l] * dlt;
+        }
+        if (sub == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) { jb[k] = sub < nv ? w.c_Jb[c][k][sub] : 0.0; bb[k] = sub < nv ? w.c_Bb[c][k][sub] : 0.0; }
+          for (int e = 0; e < 6; e++) w.rec[c].f[e] = f[e];
+        }
 #pragma unroll
-      for (int k = 0; k < 4; k++) u[k] = gsum<G>(jb[k] * a);
-#pragma unroll
-      for (int e = 0; e < 6; e++) {
-        const int k = e / 2 + 1;
-        const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
-        real Ge[4];
-#pragma unroll
-        for (int l = 0; l < 4; l++) Ge[l] = Gs[gidx(l, 0)] + sm * Gs[gidx(l, k)];   // J_l . (B_0 + sm B_k)
-        const real den = Ge[0] + sm * Ge[k] + Rc;
-        const real res = (u[0] + sm * u[k]) - (Ab[0] + sm * Ab[k]) + Rc * f[e];
-        const real fn = fmax(f[e] - res * inv[e], 0.0);       // inv == 0 for the unused edges of a condim-3 pair
-        const real dlt = fn - f[e];
-        improvement -= dlt * (res + 0.5 * den * dlt);
-        f[e] = fn;
-        Dk[0] += dlt; Dk[k] += sm * dlt;
-#pragma unroll
-        for (int l = 0; l < 4; l++) u[l] += Ge[l] * dlt;
+        for (int k = 0; k < 4; k++) a += (c < 4 ? cr.jb[c][k] * invm : cr.bb[c < 4 ? 0 : c - 4][k]) * Dk[k];
       }
-#pragma unroll
-      for (int e = 0; e < 6; e++) w.c_rec[c].f[e] = f[e];
-#pragma unroll
-      for (int k = 0; k < 4; k++) a += bb[k] * Dk[k];
     }
     improvement += gsum<G>(imp_local);
-    if (improvement * scale < m->solver_tolerance) break;
+    if (improvement * scale < tol) break;
   }
-  if (my_row >= 0) w.s_f[my_row] = my_f;
   return a;
 }
 
 // everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
 template <int NL, int G>
-__device__ __forceinline__ void step1_products(Ws<NL>& w, const KDeviceModel* dm, int sub) {
-  const KModelDesc* m = &dm->d;
-  if (sub == 0) { fk_serial<NL>(w, m); }
+__device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
+                                               CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+  if (sub == 0) {
+    fk_serial<NL>(w, lm);
+    bias_bodies_serial<NL>(w, lm, m);
+    collide_serial<NL>(w, m);
+    scalar_rows_serial<NL>(w, lm);
+  }
   GSYNC();
-  if (sub == 0) { bias_bodies_serial<NL>(w, m); }
-  if (sub == 1 % G) { collide_serial<NL>(w, m); scalar_rows_serial<NL>(w, m); }
-  mass_matrix<NL, G>(w, dm, sub);
+  mass_matrix<NL, G>(w, lm, sub);
+  bias_project<NL, G>(w, lm, sub);
   GSYNC();
-  bias_project<NL, G>(w, dm, sub);
-  invert_mass<NL, G>(w, m->nlink, sub);
-  build_constraints<NL, G>(w, dm, sub);
+  invert_mass<NL, G>(w, sub);
+  build_constraints<NL, G>(w, lm, m, sub, cr, invm);
 }
 
 // mj_Euler: qvel += dt*qacc, then positions with the NEW velocity (semi-implicit); free-joint quaternion
 // integrated on the group's lane 0
 template <int NL, int G>
 __device__ __forceinline__ void integrate(Ws<NL>& w, const KModelDesc* m, int sub, real a) {
-  const int nl = m->nlink, nv = nl + 6;
+  constexpr int NV = Dim<NL>::NV;
   const real dt = m->timestep;
-  if (sub < nv) {
+  if (sub < NV) {
     real v = w.qvel[sub] + dt * a;
     w.qvel[sub] = v;
     w.warm[sub] = a;
-    if (sub < nl + 3) w.qpos[sub] += dt * v;
+    if (sub < NL + 3) w.qpos[sub] += dt * v;
   }
   GSYNC();
   if (sub == 0) {
-    real ax[3] = {w.qvel[nl + 3], w.qvel[nl + 4], w.qvel[nl + 5]};
+    real ax[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
     real ang = dt * normalize3(ax), qr[4], qn[4];
-    real q[4] = {w.qpos[nl + 3], w.qpos[nl + 4], w.qpos[nl + 5], w.qpos[nl + 6]};
+    real q[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]};
     axis_angle2quat(qr, ax, ang);
     normalize4(q);
     qmul(qn, q, qr);
     normalize4(qn);
-    w.qpos[nl + 3] = qn[0]; w.qpos[nl + 4] = qn[1]; w.qpos[nl + 5] = qn[2]; w.qpos[nl + 6] = qn[3];
+    w.qpos[NL + 3] = qn[0]; w.qpos[NL + 4] = qn[1]; w.qpos[NL + 5] = qn[2]; w.qpos[NL + 6] = qn[3];
   }
   GSYNC();
 }
@@ -799,25 +816,24 @@ __device__ __forceinline__ real clip1(real x) { return fmin(fmax(x, -1.0), 1.0);
 
 // get_observation, env_sim.py:110-146 (state keys; cameras are out of this kernel)
 template <int NL, int G>
-__device__ __forceinline__ void write_obs(const Ws<NL>& w, const KModelDesc* m, int sub, double* obs_row) {
-  const int nl = m->nlink;
-  for (int i = sub; i < nl; i += G) {
-    obs_row[i] = clip1((w.qpos[i] - m->jnt_range[i][0]) / (m->jnt_range[i][1] - m->jnt_range[i][0]));
-    obs_row[nl + i] = clip1(w.qvel[i] / m->max_q_vel);
+__device__ __forceinline__ void write_obs(const Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, double* obs_row) {
+  for (int i = sub; i < NL; i += G) {
+    obs_row[i] = clip1((w.qpos[i] - lm.range[i][0]) / (lm.range[i][1] - lm.range[i][0]));
+    obs_row[NL + i] = clip1(w.qvel[i] / m->max_q_vel);
   }
   for (int c = sub; c < 7; c += G) {
-    if (c < 3) obs_row[2 * nl + c] = clip1((w.qpos[nl + c] - m->cube_spawn_lo[c]) / (m->cube_spawn_hi[c] - m->cube_spawn_lo[c]));
-    else obs_row[2 * nl + c] = w.qpos[nl + c];
+    if (c < 3) obs_row[2 * NL + c] = clip1((w.qpos[NL + c] - m->cube_spawn_lo[c]) / (m->cube_spawn_hi[c] - m->cube_spawn_lo[c]));
+    else obs_row[2 * NL + c] = w.qpos[NL + c];
   }
 }
 
 // initialize_episode (env_sim.py:23-36) + mj_forward without actuation (dm_control after_reset)
 template <int NL, int G>
-__device__ __forceinline__ void reset_env(Ws<NL>& w, const KDeviceModel* dm, int sub, uint64_t seed, int64_t genv, int episode) {
-  const KModelDesc* m = &dm->d;
-  const int nl = m->nlink, nv = nl + 6;
-  if (sub < nv) { w.qvel[sub] = 0; w.warm[sub] = 0; }
-  if (sub < nl) { w.qpos[sub] = m->q_home[sub]; w.ctrl[sub] = m->q_home[sub]; }
+__device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, uint64_t seed,
+                                          int64_t genv, int episode, CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+  constexpr int NV = Dim<NL>::NV;
+  if (sub < NV) { w.qvel[sub] = 0; w.warm[sub] = 0; }
+  if (sub < NL) { w.qpos[sub] = lm.q_home[sub]; w.ctrl[sub] = lm.q_home[sub]; }
   if (sub == 0) {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), (uint32_t)episode, 0}, o[4];
@@ -826,77 +842,87 @@ __device__ __forceinline__ void reset_env(Ws<NL>& w, const KDeviceModel* dm, int
     ctr[3] = 1;
     philox4x32_10(ctr, key, o);
     real u2 = u53(o[0], o[1]);
-    w.qpos[nl] = m->cube_spawn_lo[0] + (m->cube_spawn_hi[0] - m->cube_spawn_lo[0]) * u0;
-    w.qpos[nl + 1] = m->cube_spawn_lo[1] + (m->cube_spawn_hi[1] - m->cube_spawn_lo[1]) * u1;
-    w.qpos[nl + 2] = m->cube_spawn_lo[2] + (m->cube_spawn_hi[2] - m->cube_spawn_lo[2]) * u2;
-    for (int c = 0; c < 4; c++) w.qpos[nl + 3 + c] = m->cube_quat0[c];
+    w.qpos[NL] = m->cube_spawn_lo[0] + (m->cube_spawn_hi[0] - m->cube_spawn_lo[0]) * u0;
+    w.qpos[NL + 1] = m->cube_spawn_lo[1] + (m->cube_spawn_hi[1] - m->cube_spawn_lo[1]) * u1;
+    w.qpos[NL + 2] = m->cube_spawn_lo[2] + (m->cube_spawn_hi[2] - m->cube_spawn_lo[2]) * u2;
+    for (int c = 0; c < 4; c++) w.qpos[NL + 3 + c] = m->cube_quat0[c];
     w.bad = 0;
   }
   GSYNC();
-  step1_products<NL, G>(w, dm, sub);
-  real a = solve_accel<NL, G>(w, dm, sub, 0);
-  if (sub < nv) w.warm[sub] = a;
+  step1_products<NL, G>(w, lm, m, sub, cr, invm);
+  real a = solve_accel<NL, G>(w, lm, m, sub, 0, cr, invm);
+  if (sub < NV) w.warm[sub] = a;
   GSYNC();
 }
 
 template <int NL, int G>
-__device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, int env, int sub, int nl) {
-  const int NE = st.num_envs, nv = nl + 6, nq = nl + 7;
-  for (int i = sub; i < nq; i += G) w.qpos[i] = st.qpos[(size_t)i * NE + env];
-  for (int i = sub; i < nv; i += G) { w.qvel[i] = st.qvel[(size_t)i * NE + env]; w.warm[i] = st.warm[(size_t)i * NE + env]; }
-  for (int i = sub; i < nl; i += G) { w.ctrl[i] = st.ctrl[(size_t)i * NE + env]; w.qpos_ik[i] = st.qpos_ik[(size_t)i * NE + env]; }
+__device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, int env, int sub) {
+  constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
+  const int NE = st.num_envs;
+  for (int i = sub; i < NQ; i += G) w.qpos[i] = st.qpos[(size_t)i * NE + env];
+  for (int i = sub; i < NV; i += G) { w.qvel[i] = st.qvel[(size_t)i * NE + env]; w.warm[i] = st.warm[(size_t)i * NE + env]; }
+  for (int i = sub; i < NL; i += G) { w.ctrl[i] = st.ctrl[(size_t)i * NE + env]; w.qpos_ik[i] = st.qpos_ik[(size_t)i * NE + env]; }
   if (sub == 0) w.bad = 0;
 }
 template <int NL, int G>
-__device__ __forceinline__ void store_state(const Ws<NL>& w, const KDeviceState& st, int env, int sub, int nl) {
-  const int NE = st.num_envs, nv = nl + 6, nq = nl + 7;
-  for (int i = sub; i < nq; i += G) st.qpos[(size_t)i * NE + env] = w.qpos[i];
-  for (int i = sub; i < nv; i += G) { st.qvel[(size_t)i * NE + env] = w.qvel[i]; st.warm[(size_t)i * NE + env] = w.warm[i]; }
-  for (int i = sub; i < nl; i += G) st.ctrl[(size_t)i * NE + env] = w.ctrl[i];
+__device__ __forceinline__ void store_state(const Ws<NL>& w, const KDeviceState& st, int env, int sub) {
+  constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
+  const int NE = st.num_envs;
+  for (int i = sub; i < NQ; i += G) st.qpos[(size_t)i * NE + env] = w.qpos[i];
+  for (int i = sub; i < NV; i += G) { st.qvel[(size_t)i * NE + env] = w.qvel[i]; st.warm[(size_t)i * NE + env] = w.warm[i]; }
+  for (int i = sub; i < NL; i += G) st.ctrl[(size_t)i * NE + env] = w.ctrl[i];
 }
 
-// copy the model into LDS with all 64 lanes (8-byte words), then a workgroup barrier (one wave: cheap)
-__device__ __forceinline__ void stage_model(KDeviceModel* dst, const KDeviceModel* src) {
-  static_assert(sizeof(KDeviceModel) % 8 == 0, "model must be a whole number of 8-byte words");
-  const uint64_t* s8 = reinterpret_cast<const uint64_t*>(src);
-  uint64_t* d8 = reinterpret_cast<uint64_t*>(dst);
-  for (int i = threadIdx.x; i < (int)(sizeof(KDeviceModel) / 8); i += 64) d8[i] = s8[i];
+// per-link constants -> LDS with all 64 lanes, then a workgroup barrier (one wave: cheap)
+template <int NL>
+__device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* dm) {
+  const KModelDesc* m = &dm->d;
+  for (int i = threadIdx.x; i < NL; i += 64) {
+    lm.parent[i] = m->link_parent[i]; lm.jtype[i] = m->jnt_type[i]; lm.forcelimited[i] = m->forcelimited[i];
+    lm.anc[i] = dm->x.anc_mask[i];
+    lm.floss[i] = m->frictionloss[i]; lm.kp[i] = m->kp[i]; lm.mass[i] = m->mass[i]; lm.q_home[i] = m->q_home[i];
+    for (int c = 0; c < 3; c++) { lm.pos[i][c] = m->link_pos[i][c]; lm.jaxis[i][c] = m->jnt_axis[i][c]; lm.com[i][c] = m->com[i][c]; lm.inertia[i][c] = m->inertia[i][c]; }
+    for (int c = 0; c < 4; c++) lm.quat[i][c] = m->link_quat[i][c];
+    for (int c = 0; c < 2; c++) { lm.range[i][c] = m->jnt_range[i][c]; lm.ctrlrange[i][c] = m->ctrlrange[i][c]; lm.forcerange[i][c] = m->forcerange[i][c]; }
+  }
   __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
 template <int NL, int G>
-__global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm_g, KDeviceState st, double* __restrict__ obs,
+__global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm, KDeviceState st, double* __restrict__ obs,
                                              double* __restrict__ reward, uint8_t* __restrict__ done) {
-  constexpr int EPB = 64 / G;
+  constexpr int EPB = 64 / G, NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
   __shared__ Ws<NL> ws[EPB];
-  __shared__ KDeviceModel smodel;     // model constants staged once per workgroup (lane-indexed reads stay on-chip)
-  stage_model(&smodel, dm_g);
-  const KDeviceModel* dm = &smodel;
+  __shared__ LModel<NL> lm;
+  stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const int env = blockIdx.x * EPB + grp;
   if (env >= st.num_envs) return;     // whole group exits together
   Ws<NL>& w = ws[grp];
-  const int nl = m->nlink, nv = nl + 6;
-  load_state<NL, G>(w, st, env, sub, nl);
+  CReg<Dim<NL>::NC, Dim<NL>::NCF> cr;
+  real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
+  if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
+  load_state<NL, G>(w, st, env, sub);
   GSYNC();
   int bad = 0;
-  for (int s = 0; s < m->n_sub_steps; s++) {
-    step1_products<NL, G>(w, dm, sub);                 // s == 0: products of the pre-IK state (stale mj_step2)
-    real a = solve_accel<NL, G>(w, dm, sub, 1);
-    int lb = (sub < nv) && (!isfinite(a) || fabs(a) > 1e10);   // mjWARN_BADQACC
+  const int nsub = m->n_sub_steps;
+  for (int s = 0; s < nsub; s++) {
+    step1_products<NL, G>(w, lm, m, sub, cr, invm);      // s == 0: products of the pre-IK state (stale mj_step2)
+    real a = solve_accel<NL, G>(w, lm, m, sub, 1, cr, invm);
+    int lb = (sub < NV) && (!isfinite(a) || fabs(a) > 1e10);   // mjWARN_BADQACC
     bad = gor<G>(lb) | w.bad;
     if (bad) break;
-    if (s == 0) {                                       // the IK teleported the arm (ik_mujoco.py:34,67)
-      if (sub < nl) w.qpos[sub] = w.qpos_ik[sub];
+    if (s == 0) {                                        // the IK teleported the arm (ik_mujoco.py:34,67)
+      if (sub < NL) w.qpos[sub] = w.qpos_ik[sub];
       GSYNC();
     }
     integrate<NL, G>(w, m, sub, a);
   }
   if (!bad) {
     int lb = 0;
-    for (int i = sub; i < nl + 7; i += G) lb |= !isfinite(w.qpos[i]);
+    for (int i = sub; i < NQ; i += G) lb |= !isfinite(w.qpos[i]);
     bad = gor<G>(lb);
   }
   uint8_t dn = 0;
@@ -904,26 +930,24 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   double* obs_row = obs + (size_t)env * m->obs_dim;
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
-    if (sub == 0) { fk_serial<NL>(w, m); }
+    if (sub == 0) { fk_serial<NL>(w, lm); collide_serial<NL>(w, m); }
+    real v2 = gsum<G>(sub < NV ? w.qvel[sub] * w.qvel[sub] : 0.0);
     GSYNC();
-    if (sub == 0) collide_serial<NL>(w, m);
     // get_reward, env_sim.py:148-179
-    real v2 = gsum<G>(sub < nv ? w.qvel[sub] * w.qvel[sub] : 0.0);
-    GSYNC();
     rew = -m->reward_vel_penalty * sqrt(v2);
     for (int arm = 1; arm >= 0; arm--) {
       if (!m->arm_present[arm] || !m->arm_has_grip[arm]) continue;
       const int l = m->arm_site_link[arm];
       real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]}, sp[3];
-      mat_vec3(sp, w.xmat[l], so);
-      real df[3] = {w.qpos[nl] - (sp[0] + w.xpos[l][0]), w.qpos[nl + 1] - (sp[1] + w.xpos[l][1]), w.qpos[nl + 2] - (sp[2] + w.xpos[l][2])};
+      mat_vec3(sp, w.k.xmat[l], so);
+      real df[3] = {w.qpos[NL] - (sp[0] + w.k.xpos[l][0]), w.qpos[NL + 1] - (sp[1] + w.k.xpos[l][1]), w.qpos[NL + 2] - (sp[2] + w.k.xpos[l][2])};
       rew += m->reward_grip_dist * (1.0 / (sqrt(dot3(df, df)) + m->epsilon));
     }
     if (m->touch_reward_enabled && w.touch_fc) {
       rew += m->reward_touch_cube;
       if (!w.touch_ct) rew += m->reward_lift_cube;
     }
-    write_obs<NL, G>(w, m, sub, obs_row);
+    write_obs<NL, G>(w, lm, m, sub, obs_row);
     if (sub == 0) st.contact_mask[env] = w.contact_mask;
   } else {
     dn |= KM_DONE_DIVERGED;
@@ -936,36 +960,37 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (dn && (m->auto_reset || bad)) {
     episode += 1; step_idx = 0;
     GSYNC();
-    reset_env<NL, G>(w, dm, sub, st.seed, st.env_id_offset + env, episode);
-    write_obs<NL, G>(w, m, sub, obs_row);
+    reset_env<NL, G>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
+    write_obs<NL, G>(w, lm, m, sub, obs_row);
   }
   if (sub == 0) { reward[env] = rew; done[env] = dn; st.step_idx[env] = step_idx; st.episode[env] = episode; }
   GSYNC();
-  store_state<NL, G>(w, st, env, sub, nl);
+  store_state<NL, G>(w, st, env, sub);
 }
 
-// KManipEnvSim.k_reset for the envs selected by mask (NULL = all) or, with use_done_bits, by nonzero bytes of mask
+// KManipEnvSim.k_reset for the envs selected by mask (NULL = all)
 template <int NL, int G>
-__global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ dm_g, KDeviceState st,
+__global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ dm, KDeviceState st,
                                               const uint8_t* __restrict__ mask, double* __restrict__ obs) {
-  constexpr int EPB = 64 / G;
+  constexpr int EPB = 64 / G, NV = Dim<NL>::NV;
   __shared__ Ws<NL> ws[EPB];
-  __shared__ KDeviceModel smodel;
-  stage_model(&smodel, dm_g);
-  const KDeviceModel* dm = &smodel;
+  __shared__ LModel<NL> lm;
+  stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const int env = blockIdx.x * EPB + grp;
   if (env >= st.num_envs) return;
   if (mask && !mask[env]) return;
   Ws<NL>& w = ws[grp];
-  const int nl = m->nlink;
+  CReg<Dim<NL>::NC, Dim<NL>::NCF> cr;
+  real invm = 0;
+  if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   int episode = st.episode[env] + 1;
-  reset_env<NL, G>(w, dm, sub, st.seed, st.env_id_offset + env, episode);
-  if (obs) write_obs<NL, G>(w, m, sub, obs + (size_t)env * m->obs_dim);
+  reset_env<NL, G>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
+  if (obs) write_obs<NL, G>(w, lm, m, sub, obs + (size_t)env * m->obs_dim);
   if (sub == 0) { st.step_idx[env] = 0; st.episode[env] = episode; st.contact_mask[env] = 0; }
   GSYNC();
-  store_state<NL, G>(w, st, env, sub, nl);
+  store_state<NL, G>(w, st, env, sub);
 }
 
 void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs, double* reward,
