@@ -106,20 +106,15 @@ def main():
     acts = [(torch.rand((n, cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous() for _ in range(nbank)]
     env.k_reset()
 
-    gather = (dist is not None) and not args.no_gather
-    if gather:   # packed [reward f64 | done as f64] record per env, all-gathered asynchronously each step
-        rec = [torch.zeros((n, 2), dtype=torch.float64, device="cuda") for _ in range(2)]
-        allrec = [torch.zeros((world * n, 2), dtype=torch.float64, device="cuda") for _ in range(2)]
-        pending = [None, None]
+    gather = None
+    if dist is not None and not args.no_gather:
+        from gym_kmanip_amd.dist import RewardDoneGather
+        gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist)
 
     def one_step(k):
         env.step_flat(acts[k % nbank])
-        if gather:
-            b = k & 1
-            if pending[b] is not None:
-                pending[b].wait()
-            rec[b][:, 0].copy_(env.reward); rec[b][:, 1].copy_(env.done)
-            pending[b] = dist.all_gather_into_tensor(allrec[b], rec[b], async_op=True)
+        if gather is not None:
+            gather.post(env.reward, env.done)
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,10 +129,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.warmup + k)
-    if gather:
-        for p in pending:
-            if p is not None:
-                p.wait()
+    if gather is not None:
+        gather.wait()
     barrier()
     dt = time.perf_counter() - t0
     ik_ms, dyn_ms, nt = env.timing_summary()
@@ -160,7 +153,7 @@ def main():
             "config": {"workload": "%s, %d envs per GPU (%d total), no cameras, random U(-1,1) actions, 64-step episodes with auto-reset"
                                    % (args.env, n, world * n),
                        "envs_per_gpu": n, "sharding": "contiguous env-index blocks, 1 process per GPU",
-                       "collective": "async all_gather of (reward, done) per step" if gather else "none"},
+                       "collective": "async all_gather of (reward, done) per step" if gather is not None else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "bytes_per_env_step": algorithmic_bytes_per_env_step(cm),

@@ -1,0 +1,58 @@
+"""Multi-GPU plumbing: env-index sharding + the per-step (reward, done) all-gather.
+
+Envs share nothing but the read-only model (the reference holds one Physics per env instance,
+env_sim.py:206-211), so the hot path shards by env index with NO data-path collective.  The only exchange
+the north star names is the tiny per-step reward/done all-gather for a single learner process: one packed
+[reward f64 | done f64] record per env, issued asynchronously (RCCL over xGMI on GPUs, gloo in the CPU
+tests) and double-buffered so that it overlaps the next control step.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+
+def shard_range(total_envs: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous env-index block [lo, hi) of `rank`; sizes differ by at most one."""
+    base, rem = divmod(total_envs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class RewardDoneGather:
+    """Asynchronous, double-buffered all-gather of (reward, done) across ranks (equal shard sizes)."""
+
+    def __init__(self, n_local: int, world: int, device, dist=None):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.world = world
+        self.n = n_local
+        self.rec = [torch.zeros((n_local, 2), dtype=torch.float64, device=device) for _ in range(2)]
+        self.all = [torch.zeros((world * n_local, 2), dtype=torch.float64, device=device) for _ in range(2)]
+        self.pending = [None, None]
+        self.k = 0
+
+    def post(self, reward, done):
+        """Pack this step's local results and start the collective; returns the buffer index."""
+        b = self.k & 1
+        self.k += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+        self.rec[b][:, 0].copy_(reward)
+        self.rec[b][:, 1].copy_(done)
+        if self.dist is not None and self.world > 1:
+            self.pending[b] = self.dist.all_gather_into_tensor(self.all[b], self.rec[b], async_op=True)
+        else:
+            self.all[b].copy_(self.rec[b])
+        return b
+
+    def wait(self, b: Optional[int] = None):
+        for i in ([b] if b is not None else [0, 1]):
+            if self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+
+    def result(self, b: int):
+        """(reward[world*n], done[world*n] uint8) of buffer b, global env order."""
+        self.wait(b)
+        return self.all[b][:, 0], self.all[b][:, 1].to(self.torch.uint8)
