@@ -50,6 +50,25 @@ def usable_cores():
     return n
 
 
+def measure_variant(env_id, solver, n, local_rank, rank, steps=16, warmup=12):
+    """Short single-rank measurement of the other constraint solver on the same workload (reported, not `value`)."""
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.model import compile_model
+    cm = compile_model(env_id, auto_reset=True, solver=solver)
+    env = env_hip.KManipEnvHip(cm, num_envs=n, device=local_rank, seed=0, env_id_offset=rank * n)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(99)
+    acts = [(torch.rand((n, cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous() for _ in range(8)]
+    env.k_reset()
+    for k in range(warmup):
+        env.step_flat(acts[k % 8])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(steps):
+        env.step_flat(acts[k % 8])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    env.k_close()
+    return {"solver": solver, "value": n * steps / dt, "unit": "env steps/s", "steps": steps, "ms_per_step": dt / steps * 1e3}
+
+
 def cpu_baseline(cm, n_envs, budget_s=12.0):
     """The oracle (a C port of the reference path; the reference itself cannot run here) timed on this
     box's host cores with OpenMP over envs, on a bounded sample of the same workload."""
@@ -82,7 +101,10 @@ def main():
     ap.add_argument("--env", default="KManipSoloArm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--solver-iterations", type=int, default=100, help="PGS sweep cap (MuJoCo default 100); ablation only")
+    ap.add_argument("--solver-iterations", type=int, default=100, help="solver iteration cap (MuJoCo default 100); ablation only")
+    ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
+                    help="newton = MuJoCo default, what the reference runs; pgs = the north star's named solver (100 sweeps)")
+    ap.add_argument("--no-pgs-variant", action="store_true", help="skip the extra short PGS measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,7 +120,7 @@ def main():
 
     from gym_kmanip_amd import env_hip
     from gym_kmanip_amd.model import compile_model
-    cm = compile_model(args.env, auto_reset=True, solver_iterations=args.solver_iterations)
+    cm = compile_model(args.env, auto_reset=True, solver_iterations=args.solver_iterations, solver=args.solver)
     n = args.envs_per_gpu
     env = env_hip.KManipEnvHip(cm, num_envs=n, device=local_rank, seed=0, env_id_offset=rank * n)
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
@@ -152,7 +174,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %d envs per GPU (%d total), no cameras, random U(-1,1) actions, 64-step episodes with auto-reset"
                                    % (args.env, n, world * n),
-                       "envs_per_gpu": n, "sharding": "contiguous env-index blocks, 1 process per GPU",
+                       "envs_per_gpu": n, "solver": args.solver, "solver_iterations": args.solver_iterations,
+                       "sharding": "contiguous env-index blocks, 1 process per GPU",
                        "collective": "async all_gather of (reward, done) per step" if gather is not None else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
@@ -160,8 +183,11 @@ def main():
                          "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "decode_ik": ik_ms / max(nt, 1)},
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }
+        if not args.no_pgs_variant and args.solver == "newton":
+            out["pgs_variant"] = measure_variant(args.env, "pgs", n, local_rank, rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cm, n)
+            out["cpu_baseline"]["solver"] = args.solver
         print(json.dumps(out), flush=True)
     env.k_close()
     if dist is not None:

@@ -68,21 +68,24 @@ struct Ws {
     struct { real xpos[NL][3], xquat[NL][4], xmat[NL][9], axis[NL][3], cpos[NL][3], cube_mat[9]; } k;
     // ... then the same bytes hold the per-edge Gram rows Ge[c][e][l] = J_l . M^-1 (J_0 + sm J_k)^T for PGS
     struct { real Ge[NC][6][4]; } p;
+    // ... or, for the Newton solver, the nv x nv Hessian M + J^T D J and its Cholesky factor (in place)
+    struct { real Hm[NV][NV]; } h;
   };
   real Minv[NL][NL];       // joint-space inertia, overwritten by its inverse
+  real Mm[NL][NL];         // copy of the joint-space inertia itself (Newton: Gauss term and Hessian)
   union {
     struct { real Lw[NL][NL]; real FN[NL][6]; } f;   // Cholesky workspace, per-body bias wrenches
     real stage[4][NV];                               // staging of basis rows for B = M^-1 J^T
     ConRec rec[NC];                                  // solver records (built last)
   };
-  real bias[NV], as[NV], tmp[NV];
+  real bias[NV], as[NV], tmp[NV], tmp2[NV], tmp3[NV];
   real Mtrace;
   int ns, bad, touch_fc, touch_ct;
   uint32_t contact_mask;   // KM_CON_* bits (which candidate pairs touch)
   uint32_t cact;           // active contact slots
   // single-dof constraint rows on ARM dofs (friction loss, then limits); the cube's friction-loss rows are
   // lane-local registers
-  int s_dof[NS], s_type[NS];
+  int s_dof[NS], s_type[NS], s_quad[NS];
   real s_sign[NS], s_pos[NS], s_f[NS], s_R[NS], s_aref[NS], s_den[NS], s_inv[NS], s_floss[NS];
   // contact geometry per slot
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
@@ -284,6 +287,7 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub) {
   real tr = 0;
   for (int i = 0; i < NL; i++) tr += w.Minv[i][i];
   if (sub == 0) w.Mtrace = tr;
+  if (sub < NL) for (int i = 0; i < NL; i++) w.Mm[i][sub] = w.Minv[i][sub];
   for (int k = 0; k < NL; k++) {
     if (sub >= k && sub < NL) {
       real s = w.Minv[sub][k];
@@ -768,8 +772,368 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
   return a;
 }
 
-// everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
+
+// =============================================================================================
+// Newton solver (MuJoCo's default solver, i.e. what the reference actually runs: no <option> element in
+// any of its XML files).  Primal problem over qacc:  1/2 (a-a_s)^T M (a-a_s) + sum_i s_i(J_i a - aref_i).
+// Lane d owns a_d, grad_d, the search component p_d and column d of the Hessian; the nv x nv Hessian lives
+// in LDS (aliasing the dead kinematics) and is factored by a cooperative Cholesky; projections of the
+// contact bases are DPP row reductions; the exact line search evaluates phi', phi'' with the rows strided
+// over the lanes.  The minimiser is unique, so parity with the oracle does not depend on iteration counts.
+
+// in-place lower Cholesky of the n x n SPD matrix A (LDS, leading dimension LD): lane i owns row i
+template <int G>
+__device__ __forceinline__ void chol_lds(real* A, int LD, int n, int sub, int* bad) {
+  for (int k = 0; k < n; k++) {
+    if (sub >= k && sub < n) {
+      real s = A[sub * LD + k];
+      for (int t = 0; t < k; t++) s -= A[sub * LD + t] * A[k * LD + t];
+      A[sub * LD + k] = s;
+    }
+    GSYNC();
+    real dk = A[k * LD + k];
+    if (!(dk > 0)) { *bad = 1; dk = 1; }
+    const real inv = 1.0 / sqrt(dk);
+    GSYNC();
+    if (sub == k) A[k * LD + k] = dk * inv;
+    else if (sub > k && sub < n) A[sub * LD + k] *= inv;
+    GSYNC();
+  }
+}
+// x <- (L L^T)^-1 b with b distributed (lane i holds b_i); vec = n doubles of LDS scratch
+template <int G>
+__device__ __forceinline__ real chol_solve_lds(const real* L, int LD, int n, int sub, real b, real* vec) {
+  for (int k = 0; k < n; k++) {
+    if (sub == k) vec[k] = b / L[k * LD + k];
+    GSYNC();
+    if (sub > k && sub < n) b -= L[sub * LD + k] * vec[k];
+  }
+  GSYNC();
+  real z = sub < n ? vec[sub] : 0.0;
+  GSYNC();
+  for (int k = n - 1; k >= 0; k--) {
+    if (sub == k) vec[k] = z / L[k * LD + k];
+    GSYNC();
+    if (sub < k) z -= L[k * LD + sub] * vec[k];
+  }
+  GSYNC();
+  real x = sub < n ? vec[sub] : 0.0;
+  GSYNC();
+  return x;
+}
+
+// s_i'(x) and s_i''(x) contributions of one row to the line-search derivatives
+__device__ __forceinline__ void row_ls(int type, real x, real y, real R, real fl, real& d1, real& d2) {
+  const real Dn = 1.0 / R;
+  if (type == 0) {
+    if (x <= -R * fl) d1 += -fl * y;
+    else if (x >= R * fl) d1 += fl * y;
+    else { d1 += Dn * x * y; d2 += Dn * y * y; }
+  } else if (x < 0) { d1 += Dn * x * y; d2 += Dn * y * y; }
+}
+// cost / force / quadratic-zone flag of one row
+__device__ __forceinline__ real row_eval(int type, real x, real R, real fl, real& f, int& quad) {
+  const real Dn = 1.0 / R;
+  if (type == 0) {
+    if (x <= -R * fl) { f = fl; quad = 0; return fl * (-0.5 * R * fl - x); }
+    if (x >= R * fl) { f = -fl; quad = 0; return fl * (-0.5 * R * fl + x); }
+    f = -Dn * x; quad = 1; return 0.5 * Dn * x * x;
+  }
+  if (x < 0) { f = -Dn * x; quad = 1; return 0.5 * Dn * x * x; }
+  f = 0; quad = 0; return 0;
+}
+
+// Constraint assembly for Newton: like build_constraints but no B = M^-1 J^T / Gram tables -- only the
+// first-edge diagonal (for MuJoCo's pyramidal regulariser) and the velocity projections (for aref).
 template <int NL, int G>
+__device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
+                                                         CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+  for (int r = sub; r < w.ns; r += G) {
+    const int j = w.s_dof[r];
+    real Ad = w.Minv[j][j];
+    real pos = w.s_pos[r];
+    real imp = impedance(m->con_def_solimp, pos), kk, bb;
+    get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
+    w.s_R[r] = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+    w.s_aref[r] = -bb * (w.s_sign[r] * w.qvel[j]) - kk * imp * pos;
+  }
+  const uint32_t act = w.cact;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
+    if (((act >> c) & 1u) && sub < NV) {
+      const int kind = slot_kind<NL>(c);
+      const int link = kind == 0 ? -1 : m->sphere_link[slot_sphere<NL>(c) < 0 ? 0 : slot_sphere<NL>(c)];
+      const int b1 = kind == 1 ? link : -1, b2 = kind == 2 ? link : NL;
+      real pt[3] = {w.c_pos[c][0], w.c_pos[c][1], w.c_pos[c][2]};
+      real p1[3], r1[3], p2[3], r2[3];
+      point_jac_col<NL>(w, lm, b1, sub, pt, p1, r1);
+      point_jac_col<NL>(w, lm, b2, sub, pt, p2, r2);
+      real dl[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, dr[3] = {r2[0] - r1[0], r2[1] - r1[1], r2[2] - r1[2]};
+      cr.jb[c][0] = dot3(w.c_frame[c], dl);
+      cr.jb[c][1] = dot3(w.c_frame[c] + 3, dl);
+      cr.jb[c][2] = dot3(w.c_frame[c] + 6, dl);
+      cr.jb[c][3] = dot3(w.c_frame[c], dr);
+    }
+  }
+  GSYNC();
+  const real qv = sub < NV ? w.qvel[sub] : 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    if ((act >> c) & 1u) {
+      const int kind = slot_kind<NL>(c);
+      const bool cube = kind != 2;
+      const real* fr = cube ? m->con_cube_friction : m->con_def_friction;
+      const real* sr = cube ? m->con_cube_solref : m->con_def_solref;
+      const real* si = cube ? m->con_cube_solimp : m->con_def_solimp;
+      real mu[3] = {fr[0], fr[0], fr[1]};
+      // first pyramid edge v = J_0 + mu J_1 and M^-1 v (arm lanes need the whole row: stage through LDS)
+      const real v = cr.jb[c][0] + mu[0] * cr.jb[c][1];
+      real Mv = sub >= NL ? v * invm : 0.0;
+      if (kind != 0) {                       // (w.stage aliases the records being written here: use w.tmp)
+        if (sub < NV) w.tmp[sub] = v;
+        GSYNC();
+        if (sub < NL) { real s = 0; for (int j = 0; j < NL; j++) s += w.Minv[sub][j] * w.tmp[j]; Mv = s; }
+        GSYNC();
+      }
+      const real Ad = gsum<G>(v * Mv);
+      real vb[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) vb[k] = gsum<G>(cr.jb[c][k] * qv);
+      const real dist = w.c_dist[c];
+      real imp = impedance(si, dist), kk, bb;
+      get_kb(m, sr, si, kk, bb);
+      if (sub == 0) {
+        ConRec& rc = w.rec[c];
+        rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+        rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2];
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+          const int k = e / 2 + 1;
+          const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
+          rc.aref[e] = -bb * (vb[0] + sm * vb[k]) - kk * imp * dist;
+        }
+      }
+    }
+  }
+  GSYNC();
+}
+
+// cost, forces, gradient at a (lane component); also stages a in w.tmp2 and leaves M(a - a_s) in Mr
+template <int NL, int G>
+__device__ __forceinline__ real newton_eval(Ws<NL>& w, const KModelDesc* m, int sub, const CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr,
+                                            real a, real a_s, real mdiag, bool my_row, real my_aref, real my_R, real my_fl,
+                                            real& Mr, real& grad, real& my_f, int& my_quad) {
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+  const uint32_t act = w.cact;
+  const real r = a - a_s;
+  if (sub < NV) { w.tmp[sub] = r; w.tmp2[sub] = a; }
+  GSYNC();
+  Mr = 0;
+  if (sub < NL) { for (int j = 0; j < NL; j++) Mr += w.Mm[sub][j] * w.tmp[j]; }
+  else if (sub < NV) Mr = mdiag * r;
+  real cost = 0.5 * r * Mr;                 // per-lane share; summed at the end
+  grad = Mr;
+  // arm single-dof rows, strided over lanes
+  const int ns = w.ns;
+  for (int q = sub; q < ns; q += G) {
+    const int j = w.s_dof[q];
+    real f; int quad;
+    cost += row_eval(w.s_type[q], w.s_sign[q] * w.tmp2[j] - w.s_aref[q], w.s_R[q], w.s_floss[q], f, quad);
+    w.s_f[q] = f; w.s_quad[q] = quad;
+  }
+  // the cube friction-loss row owned by this lane
+  my_f = 0; my_quad = 0;
+  if (my_row) { cost += row_eval(0, a - my_aref, my_R, my_fl, my_f, my_quad); grad -= my_f; }
+  // contacts: basis projections, edge forces (identical on every lane; lane 0 books the cost)
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    if ((act >> c) & 1u) {
+      const ConRec& rc = w.rec[c];
+      real u[4], F[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
+      const real R = rc.R;
+      uint32_t qm = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        if (slot_kind<NL>(c) == 2 && e >= 4) continue;
+        const int k = e / 2 + 1;
+        const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+        real f; int quad;
+        const real ce = row_eval(1, u[0] + sm * u[k] - rc.aref[e], R, 0.0, f, quad);
+        if (sub == 0) cost += ce;
+        F[0] += f; F[k] += sm * f;
+        qm |= (uint32_t)quad << e;
+      }
+      if (sub == 0) w.rec[c].f[0] = (real)qm;   // active-edge mask (a small integer stored in a double)
+#pragma unroll
+      for (int k = 0; k < 4; k++) grad -= cr.jb[c][k] * F[k];
+    }
+  }
+  GSYNC();
+  if (sub < NL) { for (int q = 0; q < ns; q++) if (w.s_dof[q] == sub) grad -= w.s_sign[q] * w.s_f[q]; }
+  return gsum<G>(cost);
+}
+
+template <int NL, int G>
+__device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
+                                             CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+  // ---- actuation and smooth acceleration (as in the PGS path)
+  if (sub < NV) {
+    real rhs = -w.bias[sub];
+    if (actuation && sub < NL) {
+      real c = fmin(fmax(w.ctrl[sub], lm.ctrlrange[sub][0]), lm.ctrlrange[sub][1]);
+      real force = lm.kp[sub] * c - lm.kp[sub] * w.qpos[sub];
+      if (lm.forcelimited[sub]) force = fmin(fmax(force, lm.forcerange[sub][0]), lm.forcerange[sub][1]);
+      rhs += force;
+    }
+    w.tmp[sub] = rhs;
+  }
+  GSYNC();
+  real a_s = 0;
+  if (sub < NL) { for (int j = 0; j < NL; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
+  else if (sub < NV) a_s = w.tmp[sub] * invm;
+  GSYNC();
+  const uint32_t act = w.cact;
+  const real warm = sub < NV ? w.warm[sub] : 0.0;
+  const real mdiag = (sub >= NL && sub < NV) ? 1.0 / invm : 0.0;
+  // the cube friction-loss row owned by this lane (registers only)
+  const bool my_row = sub >= NL && sub < NV && m->cube_frictionloss > 0;
+  real my_aref = 0, my_R = 1;
+  const real my_fl = m->cube_frictionloss;
+  if (my_row) {
+    real imp = impedance(m->con_def_solimp, 0.0), kk, bb;
+    get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
+    my_R = fmax(MJ_MINVAL, (1 - imp) / imp * invm);
+    my_aref = -bb * w.qvel[sub];
+  }
+  real Mr, grad, my_f; int my_quad;
+  // ---- warm start: the better of qacc_warmstart and qacc_smooth (primal costs)
+  const real cw = newton_eval<NL, G>(w, m, sub, cr, warm, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad);
+  const real cs = newton_eval<NL, G>(w, m, sub, cr, a_s, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad);
+  real a = a_s;
+  real cost = cs;
+  if (cw < cs) { a = warm; cost = newton_eval<NL, G>(w, m, sub, cr, a, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad); }
+  const real scale = 1.0 / (w.Mtrace + 3 * m->cube_mass + m->cube_inertia[0] + m->cube_inertia[1] + m->cube_inertia[2]);
+  const real tol = m->solver_tolerance;
+  const int maxit = m->solver_iterations;
+  if (sqrt(gsum<G>(grad * grad)) * scale < tol) return a;
+  const int ns = w.ns;
+  for (int iter = 0; iter < maxit; iter++) {
+    // ---- Hessian column `sub`: M, plus D on the diagonal for quadratic single-dof rows, plus J^T W J per contact
+    if (sub < NV) {
+      for (int i = 0; i < NV; i++) w.h.Hm[i][sub] = (i < NL && sub < NL) ? w.Mm[i][sub] : 0.0;
+      real dg = sub < NL ? 0.0 : mdiag;
+      if (sub < NL) { for (int q = 0; q < ns; q++) if (w.s_dof[q] == sub && w.s_quad[q]) dg += 1.0 / w.s_R[q]; }
+      else if (my_quad) dg += 1.0 / my_R;
+      w.h.Hm[sub][sub] += dg;
+    }
+    GSYNC();
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      if ((act >> c) & 1u) {
+        const ConRec& rc = w.rec[c];
+        const uint32_t qm = (uint32_t)rc.f[0];
+        const real Dn = 1.0 / rc.R;
+        real W[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+          const int k = e / 2 + 1;
+          const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+          const real d = ((qm >> e) & 1u) ? Dn : 0.0;
+          W[0][0] += d; W[0][k] += d * sm; W[k][k] += d * sm * sm;
+        }
+        real t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          t[k] = 0;
+#pragma unroll
+          for (int l = 0; l < 4; l++) t[k] += (k <= l ? W[k][l] : W[l][k]) * cr.jb[c][l];
+        }
+        // stage the basis rows in the four vector rows that are free here (w.stage aliases the live records)
+        if (sub < NV) { w.bias[sub] = cr.jb[c][0]; w.as[sub] = cr.jb[c][1]; w.tmp[sub] = cr.jb[c][2]; w.tmp3[sub] = cr.jb[c][3]; }
+        GSYNC();
+        const int i0 = slot_kind<NL>(c) == 0 ? NL : 0;          // table-cube slots touch only the cube block
+        if (sub >= i0 && sub < NV) {
+          for (int i = i0; i < NV; i++)
+            w.h.Hm[i][sub] += w.bias[i] * t[0] + w.as[i] * t[1] + w.tmp[i] * t[2] + w.tmp3[i] * t[3];
+        }
+        GSYNC();
+      }
+    }
+    // ---- p = -H^-1 grad
+    chol_lds<G>(&w.h.Hm[0][0], NV, NV, sub, &w.bad);
+    const real p = chol_solve_lds<G>(&w.h.Hm[0][0], NV, NV, sub, -grad, w.tmp3);
+    // ---- exact line search on phi(alpha) = cost(a + alpha p)
+    if (sub < NV) w.tmp[sub] = p;
+    GSYNC();
+    real Mp = 0;
+    if (sub < NL) { for (int j = 0; j < NL; j++) Mp += w.Mm[sub][j] * w.tmp[j]; }
+    else if (sub < NV) Mp = mdiag * p;
+    const real gp = gsum<G>(p * Mr), pMp = gsum<G>(p * Mp);
+    // per-contact projections of a and p, parked in the (otherwise unused) inv/den slots of the records
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      if ((act >> c) & 1u) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const real x = gsum<G>(cr.jb[c][k] * a), y = gsum<G>(cr.jb[c][k] * p);
+          if (sub == 0) { w.rec[c].inv[k] = x; w.rec[c].den[k] = y; }
+        }
+      }
+    }
+    GSYNC();
+    real alpha = 0, lo = 0, hi = INFINITY, d1 = 0, d2 = 0, d10 = 0;
+    for (int it = 0; it <= 50; it++) {
+      real e1 = 0, e2 = 0;
+      for (int q = sub; q < ns; q += G) {
+        const int j = w.s_dof[q];
+        const real sg = w.s_sign[q];
+        row_ls(w.s_type[q], sg * w.tmp2[j] - w.s_aref[q] + alpha * (sg * w.tmp[j]), sg * w.tmp[j], w.s_R[q], w.s_floss[q], e1, e2);
+      }
+      if (my_row) row_ls(0, (a - my_aref) + alpha * p, p, my_R, my_fl, e1, e2);
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        if ((act >> c) & 1u) {
+          const ConRec& rc = w.rec[c];
+#pragma unroll
+          for (int e = 0; e < 6; e++) {
+            if (slot_kind<NL>(c) == 2 && e >= 4) continue;
+            if (((6 * c + e) % G) != sub) continue;                   // edges strided over the lanes
+            const int k = e / 2 + 1;
+            const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+            const real y = rc.den[0] + sm * rc.den[k];
+            row_ls(1, (rc.inv[0] + sm * rc.inv[k] - rc.aref[e]) + alpha * y, y, rc.R, 0.0, e1, e2);
+          }
+        }
+      }
+      d1 = gp + alpha * pMp + gsum<G>(e1);
+      d2 = pMp + gsum<G>(e2);
+      if (it == 0) { d10 = d1; if (!(d10 < 0)) break; }
+      else {
+        if (fabs(d1) <= 1e-8 * fabs(d10)) break;      // MuJoCo's ls_tolerance is 1e-2; the outer Newton absorbs the rest
+        if (d1 < 0) lo = alpha; else hi = alpha;
+        if (hi - lo <= 1e-14 * hi) break;               // bracket collapsed to roundoff
+      }
+      if (it == 50) break;
+      real an = alpha - d1 / d2;
+      if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
+      alpha = an;
+    }
+    a += alpha * p;
+    const real cost_new = newton_eval<NL, G>(w, m, sub, cr, a, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad);
+    const real improvement = scale * (cost - cost_new), gradient = scale * sqrt(gsum<G>(grad * grad));
+    cost = cost_new;
+    if (improvement < tol || gradient < tol || w.bad) break;
+  }
+  return a;
+}
+
+// everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
+template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
                                                CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
   if (sub == 0) {
@@ -783,7 +1147,14 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   bias_project<NL, G>(w, lm, sub);
   GSYNC();
   invert_mass<NL, G>(w, sub);
-  build_constraints<NL, G>(w, lm, m, sub, cr, invm);
+  if (SOLVER == KM_SOLVER_NEWTON) build_constraints_newton<NL, G>(w, lm, m, sub, cr, invm);
+  else build_constraints<NL, G>(w, lm, m, sub, cr, invm);
+}
+template <int NL, int G, int SOLVER>
+__device__ __forceinline__ real solve(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
+                                      CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+  if (SOLVER == KM_SOLVER_NEWTON) return solve_newton<NL, G>(w, lm, m, sub, actuation, cr, invm);
+  return solve_accel<NL, G>(w, lm, m, sub, actuation, cr, invm);
 }
 
 // mj_Euler: qvel += dt*qacc, then positions with the NEW velocity (semi-implicit); free-joint quaternion
@@ -828,7 +1199,7 @@ __device__ __forceinline__ void write_obs(const Ws<NL>& w, const LModel<NL>& lm,
 }
 
 // initialize_episode (env_sim.py:23-36) + mj_forward without actuation (dm_control after_reset)
-template <int NL, int G>
+template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, uint64_t seed,
                                           int64_t genv, int episode, CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
   constexpr int NV = Dim<NL>::NV;
@@ -849,8 +1220,8 @@ __device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const
     w.bad = 0;
   }
   GSYNC();
-  step1_products<NL, G>(w, lm, m, sub, cr, invm);
-  real a = solve_accel<NL, G>(w, lm, m, sub, 0, cr, invm);
+  step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm);
+  real a = solve<NL, G, SOLVER>(w, lm, m, sub, 0, cr, invm);
   if (sub < NV) w.warm[sub] = a;
   GSYNC();
 }
@@ -889,7 +1260,7 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NL, int G>
+template <int NL, int G, int SOLVER>
 __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm, KDeviceState st, double* __restrict__ obs,
                                              double* __restrict__ reward, uint8_t* __restrict__ done) {
   constexpr int EPB = 64 / G, NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
@@ -909,8 +1280,8 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   int bad = 0;
   const int nsub = m->n_sub_steps;
   for (int s = 0; s < nsub; s++) {
-    step1_products<NL, G>(w, lm, m, sub, cr, invm);      // s == 0: products of the pre-IK state (stale mj_step2)
-    real a = solve_accel<NL, G>(w, lm, m, sub, 1, cr, invm);
+    step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm);      // s == 0: products of the pre-IK state (stale mj_step2)
+    real a = solve<NL, G, SOLVER>(w, lm, m, sub, 1, cr, invm);
     int lb = (sub < NV) && (!isfinite(a) || fabs(a) > 1e10);   // mjWARN_BADQACC
     bad = gor<G>(lb) | w.bad;
     if (bad) break;
@@ -960,7 +1331,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (dn && (m->auto_reset || bad)) {
     episode += 1; step_idx = 0;
     GSYNC();
-    reset_env<NL, G>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
+    reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
   }
   if (sub == 0) { reward[env] = rew; done[env] = dn; st.step_idx[env] = step_idx; st.episode[env] = episode; }
@@ -969,7 +1340,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
 }
 
 // KManipEnvSim.k_reset for the envs selected by mask (NULL = all)
-template <int NL, int G>
+template <int NL, int G, int SOLVER>
 __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ dm, KDeviceState st,
                                               const uint8_t* __restrict__ mask, double* __restrict__ obs) {
   constexpr int EPB = 64 / G, NV = Dim<NL>::NV;
@@ -986,31 +1357,33 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   real invm = 0;
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   int episode = st.episode[env] + 1;
-  reset_env<NL, G>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
+  reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
   if (obs) write_obs<NL, G>(w, lm, m, sub, obs + (size_t)env * m->obs_dim);
   if (sub == 0) { st.step_idx[env] = 0; st.episode[env] = episode; st.contact_mask[env] = 0; }
   GSYNC();
   store_state<NL, G>(w, st, env, sub);
 }
 
+template <int NL, int G, int SOLVER>
+static void launch_step_t(const KDeviceModel* dm, const KDeviceState& st, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
+  constexpr int EPB = 64 / G;
+  hipLaunchKernelGGL((k_step<NL, G, SOLVER>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, obs, reward, done);
+}
+template <int NL, int G, int SOLVER>
+static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
+  constexpr int EPB = 64 / G;
+  hipLaunchKernelGGL((k_reset<NL, G, SOLVER>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, mask, obs);
+}
 void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs, double* reward,
                         uint8_t* done, hipStream_t stream) {
-  if (hd.nlink <= 10) {
-    constexpr int G = 16, EPB = 64 / G;
-    hipLaunchKernelGGL((k_step<10, G>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, obs, reward, done);
-  } else {
-    constexpr int G = 32, EPB = 64 / G;
-    hipLaunchKernelGGL((k_step<20, G>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, obs, reward, done);
-  }
+  const bool newton = hd.solver == KM_SOLVER_NEWTON;
+  if (hd.nlink <= 10) { if (newton) launch_step_t<10, 16, 1>(dm, st, obs, reward, done, stream); else launch_step_t<10, 16, 0>(dm, st, obs, reward, done, stream); }
+  else { if (newton) launch_step_t<20, 32, 1>(dm, st, obs, reward, done, stream); else launch_step_t<20, 32, 0>(dm, st, obs, reward, done, stream); }
 }
 void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const uint8_t* mask,
                          int use_done_bits, double* obs, hipStream_t stream) {
   (void)use_done_bits;
-  if (hd.nlink <= 10) {
-    constexpr int G = 16, EPB = 64 / G;
-    hipLaunchKernelGGL((k_reset<10, G>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, mask, obs);
-  } else {
-    constexpr int G = 32, EPB = 64 / G;
-    hipLaunchKernelGGL((k_reset<20, G>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, mask, obs);
-  }
+  const bool newton = hd.solver == KM_SOLVER_NEWTON;
+  if (hd.nlink <= 10) { if (newton) launch_reset_t<10, 16, 1>(dm, st, mask, obs, stream); else launch_reset_t<10, 16, 0>(dm, st, mask, obs, stream); }
+  else { if (newton) launch_reset_t<20, 32, 1>(dm, st, mask, obs, stream); else launch_reset_t<20, 32, 0>(dm, st, mask, obs, stream); }
 }

@@ -115,7 +115,7 @@ class KModelDesc(C.Structure):
         ("nlink", C.c_int32), ("narm", C.c_int32), ("nsphere", C.c_int32), ("act_dim", C.c_int32),
         ("obs_dim", C.c_int32), ("max_episode_steps", C.c_int32), ("n_sub_steps", C.c_int32),
         ("solver_iterations", C.c_int32), ("touch_reward_enabled", C.c_int32), ("auto_reset", C.c_int32),
-        ("act_col", C.c_int32 * len(KM_ACT_KEYS)), ("pad0_", C.c_int32),
+        ("act_col", C.c_int32 * len(KM_ACT_KEYS)), ("solver", C.c_int32),
         ("link_parent", C.c_int32 * KM_MAX_LINKS), ("jnt_type", C.c_int32 * KM_MAX_LINKS),
         ("forcelimited", C.c_int32 * KM_MAX_LINKS), ("pad1_", C.c_int32 * KM_MAX_LINKS),
         ("link_pos", (C.c_double * 3) * KM_MAX_LINKS), ("link_quat", (C.c_double * 4) * KM_MAX_LINKS),
@@ -175,8 +175,11 @@ class CompiledModel:
     cameras: List[str] = field(default_factory=list)
 
 
+SOLVERS = {"pgs": 0, "newton": 1}
+
+
 def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool = False,
-                  solver_iterations: int = 100, solver_tolerance: float = 1e-8) -> CompiledModel:
+                  solver: str = "newton", solver_iterations: int = 100, solver_tolerance: float = 1e-8) -> CompiledModel:
     spec = ENV_SPECS[env_id_or_spec] if isinstance(env_id_or_spec, str) else env_id_or_spec
     asset = load_asset(spec.asset)
     links = asset["links"]
@@ -186,6 +189,7 @@ def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool
     d.nlink = nl
     d.max_episode_steps = spec.max_episode_steps
     d.n_sub_steps = int(round(CONTROL_TIMESTEP / MJ_TIMESTEP))
+    d.solver = SOLVERS[solver]
     d.solver_iterations = solver_iterations
     d.solver_tolerance = solver_tolerance
     d.touch_reward_enabled = int(touch_reward)

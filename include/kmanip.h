@@ -43,6 +43,7 @@ enum {
 };
 
 enum { KM_JNT_HINGE = 0, KM_JNT_SLIDE = 1 };
+enum { KM_SOLVER_PGS = 0, KM_SOLVER_NEWTON = 1 };
 
 /* done byte */
 #define KM_DONE_TRUNCATED 1u  /* step_idx reached max_episode_steps (TimeLimit, __init__.py:28,247) */
@@ -66,7 +67,7 @@ typedef struct KModelDesc {
   int32_t touch_reward_enabled;  /* 0 reproduces the reference's dead touch/lift terms (SURVEY finding 4) */
   int32_t auto_reset;            /* 1: envs whose done byte is set are reset inside kmanip_step    */
   int32_t act_col[KM_ACT_NKEYS]; /* first column of each action key, -1 if the key is absent       */
-  int32_t pad0_;
+  int32_t solver;                /* KM_SOLVER_NEWTON (MuJoCo's default, what the reference runs) or KM_SOLVER_PGS */
 
   /* ---- kinematic tree (link i <-> dof i <-> qpos i <-> actuator i), parents before children */
   int32_t link_parent[KM_MAX_LINKS];       /* -1 = fixed to world                                  */

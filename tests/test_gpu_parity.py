@@ -89,12 +89,13 @@ def test_reset_parity(env):
     dev.k_close()
 
 
+@pytest.mark.parametrize("solver", ["pgs", "newton"])
 @pytest.mark.parametrize("env,n,steps", [("KManipSoloArm", 32, 70), ("KManipDualArm", 16, 66), ("KManipTorso", 16, 66)])
-def test_step_parity_vs_oracle(env, n, steps):
+def test_step_parity_vs_oracle(env, n, steps, solver):
     """Full episodes incl. cube landing (contacts), joint-limit hits, IK-infeasible starts and the
     auto-reset at step 64, on identical seeded actions."""
     torch = _torch()
-    cm, dev, orc = _mk(env, n, seed=5, off=7, auto_reset=True)
+    cm, dev, orc = _mk(env, n, seed=5, off=7, auto_reset=True, solver=solver)
     dev.k_reset(); orc.reset()
     rng = np.random.default_rng(42)
     saw_contact = saw_reset = False
