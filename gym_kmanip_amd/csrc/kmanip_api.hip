@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -56,8 +57,20 @@ static int validate(const KModelDesc* d, std::string& err) {
 }
 
 // ancestor masks and IK chains (derived data, kept out of the ABI struct)
+static void h_quat2mat(const double* q, double* m) {
+  double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+
 static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
   memset(x, 0, sizeof(*x));
+  for (int i = 0; i < d->nlink; i++)
+    if (d->jnt_axis[i][0] != 0 || d->jnt_axis[i][1] != 0 || d->jnt_axis[i][2] != 1) {
+      err = "the IK kernel assumes joint axes along local z (true for every reference model: axis=\"0 0 1\")"; return -1;
+    }
   for (int i = 0; i < d->nlink; i++) {
     uint32_t mk = 0;
     for (int j = i; j >= 0; j = d->link_parent[j]) mk |= 1u << j;
@@ -69,12 +82,14 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
     for (int j = d->arm_site_link[a]; j >= 0; j = d->link_parent[j]) chain[n++] = j;
     if (n > KM_MAX_CHAIN) { err = "IK chain longer than KM_MAX_CHAIN"; return -1; }
     x->chain_len[a] = n;
+    h_quat2mat(d->arm_site_quat[a], x->site_R[a]);
     for (int k = 0; k < n; k++) {
       int l = chain[n - 1 - k];
       x->chain_link[a][k] = l;
       int xi = -1;
       for (int i = 0; i < d->arm_nq[a]; i++) if (d->arm_q_id[a][i] == l) xi = i;
       x->chain_xidx[a][k] = xi;
+      h_quat2mat(d->link_quat[l], x->chain_R[a][k]);
       // the kernels rely on: unknown i sits at chain position i, fixed joints (if any) come after
       if ((k < d->arm_nq[a]) != (xi == k)) { err = "IK mask must be the leading links of the site's chain, in order"; return -1; }
     }

@@ -18,6 +18,8 @@ struct KModelAux {
   int32_t chain_len[KM_MAX_ARMS];            // IK kinematic chain root -> site link
   int32_t chain_link[KM_MAX_ARMS][KM_MAX_CHAIN];
   int32_t chain_xidx[KM_MAX_ARMS][KM_MAX_CHAIN];  // index into the IK unknowns, -1 = fixed at current qpos
+  double chain_R[KM_MAX_ARMS][KM_MAX_CHAIN][9];   // constant rotation of each chain link in its parent (from link_quat)
+  double site_R[KM_MAX_ARMS][9];                  // constant rotation of the EE site in its link
 };
 
 struct KDeviceModel {

@@ -15,6 +15,26 @@
 #include "kmanip_device.hpp"
 
 #define DBL_EPS 2.220446049250313e-16
+#ifndef IK_LANE_STRIDE
+#define IK_LANE_STRIDE 4
+#endif
+
+// R x C matrix living in LDS, one instance per IK problem of the workgroup: element (r, c) of problem `slot`
+// is at ((r * C + c) * stride + slot), i.e. consecutive problems hit consecutive banks.
+template <int R, int C>
+struct LMat {
+  real* p;
+  int stride;
+  __device__ __forceinline__ real& operator()(int r, int c) const { return p[(r * C + c) * stride]; }
+};
+template <int N>
+struct IkLds {          // the three big per-problem matrices kept out of the register file
+  LMat<6, N> J;         // task Jacobian
+  LMat<N, N> A, L;      // normal matrix J_h^T J_h + C and the Cholesky factor of (A + alpha I)
+  static constexpr int WORDS = 6 * N + 2 * N * N;
+  __device__ __forceinline__ IkLds(real* base, int slot, int nslots)
+      : J{base + slot, nslots}, A{base + 6 * N * nslots + slot, nslots}, L{base + (6 * N + N * N) * nslots + slot, nslots} {}
+};
 
 template <int N>
 struct IkCtx {
@@ -29,7 +49,7 @@ struct IkCtx {
 template <int N>
 struct IkEval {
   real ft[6];        // task residual (pos, rad * subQuat)
-  real Jt[6][N];     // task Jacobian
+  LMat<6, N> Jt;     // task Jacobian (LDS view)
   real sp[3], smat[9];  // site position / rotation at the evaluated point
 };
 
@@ -38,51 +58,55 @@ template <int N, bool JAC>
 __device__ __forceinline__ void ik_eval(const IkCtx<N>& P, const real* x, IkEval<N>& E) {
   const KModelDesc* m = P.m;
   const int arm = P.arm;
-  real pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0}, mat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  // Rotation-matrix propagation (all joints rotate/slide about local z): per link one constant 3x3 product
+  // and a planar rotation of two columns -- no quaternion normalisations, one sincos per hinge.
+  real pos[3] = {0, 0, 0}, mat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   real anc[N][3], axw[N][3];
   const int clen = P.ax->chain_len[arm];
 #pragma unroll
   for (int k = 0; k < KM_MAX_CHAIN; k++) {
     if (k < clen) {
       const int l = P.ax->chain_link[arm][k];
+      const double* Rl = P.ax->chain_R[arm][k];
       real lp[3] = {m->link_pos[l][0], m->link_pos[l][1], m->link_pos[l][2]};
-      real lq[4] = {m->link_quat[l][0], m->link_quat[l][1], m->link_quat[l][2], m->link_quat[l][3]};
-      real ja[3] = {m->jnt_axis[l][0], m->jnt_axis[l][1], m->jnt_axis[l][2]};
-      real t[3], qn[4];
+      real t[3], R1[9];
       mat_vec3(t, mat, lp);
       pos[0] += t[0]; pos[1] += t[1]; pos[2] += t[2];
-      qmul(qn, quat, lq);
-      real qv = (k < N) ? x[k < N ? k : 0] : P.qfix[k];
-      real a_w[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R1[3 * i + j] = mat[3 * i] * Rl[j] + mat[3 * i + 1] * Rl[3 + j] + mat[3 * i + 2] * Rl[6 + j];
+      const real qv = (k < N) ? x[k < N ? k : 0] : P.qfix[k];
       if (m->jnt_type[l] == KM_JNT_SLIDE) {
-        quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
-        normalize4(quat);
-        quat2mat(mat, quat);
-        mat_vec3(a_w, mat, ja);
-        pos[0] += a_w[0] * qv; pos[1] += a_w[1] * qv; pos[2] += a_w[2] * qv;
+#pragma unroll
+        for (int i = 0; i < 9; i++) mat[i] = R1[i];
+        pos[0] += R1[2] * qv; pos[1] += R1[5] * qv; pos[2] += R1[8] * qv;
       } else {
-        real ql[4];
-        axis_angle2quat(ql, ja, qv);
-        qmul(quat, qn, ql);
-        normalize4(quat);
-        quat2mat(mat, quat);
-        mat_vec3(a_w, mat, ja);
+        real sn, cs;
+        sincos(qv, &sn, &cs);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          mat[3 * i] = cs * R1[3 * i] + sn * R1[3 * i + 1];
+          mat[3 * i + 1] = cs * R1[3 * i + 1] - sn * R1[3 * i];
+          mat[3 * i + 2] = R1[3 * i + 2];
+        }
       }
       if (JAC && k < N) {
         anc[k < N ? k : 0][0] = pos[0]; anc[k < N ? k : 0][1] = pos[1]; anc[k < N ? k : 0][2] = pos[2];
-        axw[k < N ? k : 0][0] = a_w[0]; axw[k < N ? k : 0][1] = a_w[1]; axw[k < N ? k : 0][2] = a_w[2];
+        axw[k < N ? k : 0][0] = mat[2]; axw[k < N ? k : 0][1] = mat[5]; axw[k < N ? k : 0][2] = mat[8];
       }
     }
   }
   // site pose
-  real sp[3], sq[4], smat[9], cur[4], rq[3];
+  real sp[3], smat[9], cur[4], rq[3];
   real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]};
-  real sqo[4] = {m->arm_site_quat[arm][0], m->arm_site_quat[arm][1], m->arm_site_quat[arm][2], m->arm_site_quat[arm][3]};
+  const double* Rs = P.ax->site_R[arm];
   mat_vec3(sp, mat, so);
   sp[0] += pos[0]; sp[1] += pos[1]; sp[2] += pos[2];
-  qmul(sq, quat, sqo);
-  normalize4(sq);
-  quat2mat(smat, sq);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) smat[3 * i + j] = mat[3 * i] * Rs[j] + mat[3 * i + 1] * Rs[3 + j] + mat[3 * i + 2] * Rs[6 + j];
   mat2quat(cur, smat);
   sub_quat(rq, P.goal_quat, cur);
   E.sp[0] = sp[0]; E.sp[1] = sp[1]; E.sp[2] = sp[2];
@@ -114,15 +138,15 @@ __device__ __forceinline__ void ik_eval(const IkCtx<N>& P, const real* x, IkEval
     for (int c = 0; c < N; c++) {
       const int l = P.ax->chain_link[arm][c];
       if (m->jnt_type[l] == KM_JNT_SLIDE) {
-        E.Jt[0][c] = axw[c][0]; E.Jt[1][c] = axw[c][1]; E.Jt[2][c] = axw[c][2];
-        E.Jt[3][c] = 0; E.Jt[4][c] = 0; E.Jt[5][c] = 0;
+        E.Jt(0, c) = axw[c][0]; E.Jt(1, c) = axw[c][1]; E.Jt(2, c) = axw[c][2];
+        E.Jt(3, c) = 0; E.Jt(4, c) = 0; E.Jt(5, c) = 0;
       } else {
         real r[3] = {sp[0] - anc[c][0], sp[1] - anc[c][1], sp[2] - anc[c][2]}, jp[3];
         cross3(jp, axw[c], r);
-        E.Jt[0][c] = jp[0]; E.Jt[1][c] = jp[1]; E.Jt[2][c] = jp[2];
-        E.Jt[3][c] = T[0] * axw[c][0] + T[1] * axw[c][1] + T[2] * axw[c][2];
-        E.Jt[4][c] = T[3] * axw[c][0] + T[4] * axw[c][1] + T[5] * axw[c][2];
-        E.Jt[5][c] = T[6] * axw[c][0] + T[7] * axw[c][1] + T[8] * axw[c][2];
+        E.Jt(0, c) = jp[0]; E.Jt(1, c) = jp[1]; E.Jt(2, c) = jp[2];
+        E.Jt(3, c) = T[0] * axw[c][0] + T[1] * axw[c][1] + T[2] * axw[c][2];
+        E.Jt(4, c) = T[3] * axw[c][0] + T[4] * axw[c][1] + T[5] * axw[c][2];
+        E.Jt(5, c) = T[6] * axw[c][0] + T[7] * axw[c][1] + T[8] * axw[c][2];
       }
     }
   }
@@ -155,7 +179,7 @@ __device__ __forceinline__ void ik_grad(const IkCtx<N>& P, const real* x, const 
   for (int c = 0; c < N; c++) {
     real s = 0;
 #pragma unroll
-    for (int r = 0; r < 6; r++) s += E.Jt[r][c] * E.ft[r];
+    for (int r = 0; r < 6; r++) s += E.Jt(r, c) * E.ft[r];
     s += P.m->ik_jac_reg * (P.m->ik_res_reg_prev * (x[c] - P.q_prev[c]) + P.m->ik_res_reg_home * (x[c] - P.q_home[c]));
     g[c] = s;
   }
@@ -163,51 +187,51 @@ __device__ __forceinline__ void ik_grad(const IkCtx<N>& P, const real* x, const 
 
 // lower Cholesky of (A + alpha I) packed full [N][N]; returns false if not numerically SPD
 template <int N>
-__device__ __forceinline__ bool chol7(const real (*A)[N], real alpha, real (*L)[N]) {
+__device__ __forceinline__ bool chol7(LMat<N, N> A, real alpha, LMat<N, N> L) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < N; j++) {
-    real s = A[j][j] + alpha;
+    real s = A(j, j) + alpha;
 #pragma unroll
-    for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+    for (int k = 0; k < j; k++) s -= L(j, k) * L(j, k);
     if (!(s > 0)) { ok = false; s = 1; }
     real d = sqrt(s), inv = 1.0 / d;
-    L[j][j] = d;
+    L(j, j) = d;
 #pragma unroll
     for (int i = j + 1; i < N; i++) {
-      real t = A[i][j];
+      real t = A(i, j);
 #pragma unroll
-      for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-      L[i][j] = t * inv;
+      for (int k = 0; k < j; k++) t -= L(i, k) * L(j, k);
+      L(i, j) = t * inv;
     }
   }
   return ok;
 }
 template <int N>
-__device__ __forceinline__ void chol_solve7(const real (*L)[N], const real* b, real* x) {
+__device__ __forceinline__ void chol_solve7(LMat<N, N> L, const real* b, real* x) {
 #pragma unroll
   for (int i = 0; i < N; i++) {
     real s = b[i];
 #pragma unroll
-    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
-    x[i] = s / L[i][i];
+    for (int k = 0; k < i; k++) s -= L(i, k) * x[k];
+    x[i] = s / L(i, i);
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; i--) {
     real s = x[i];
 #pragma unroll
-    for (int k = i + 1; k < N; k++) s -= L[k][i] * x[k];
-    x[i] = s / L[i][i];
+    for (int k = i + 1; k < N; k++) s -= L(k, i) * x[k];
+    x[i] = s / L(i, i);
   }
 }
 template <int N>
-__device__ __forceinline__ real quad_form(const real (*A)[N], const real* a, const real* b) {
+__device__ __forceinline__ real quad_form(LMat<N, N> A, const real* a, const real* b) {
   real s = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) {
     real t = 0;
 #pragma unroll
-    for (int j = 0; j < N; j++) t += A[i][j] * b[j];
+    for (int j = 0; j < N; j++) t += A(i, j) * b[j];
     s += a[i] * t;
   }
   return s;
@@ -215,8 +239,8 @@ __device__ __forceinline__ real quad_form(const real (*A)[N], const real* a, con
 
 // scipy common.py solve_lsq_trust_region restated on the normal matrix A = J_h^T J_h + diag_h
 template <int N>
-__device__ __forceinline__ void solve_tr(const real (*A)[N], const real* g_h, real Delta, real& alpha, real* p) {
-  real L[N][N], ng[N], w[N];
+__device__ __forceinline__ void solve_tr(LMat<N, N> A, LMat<N, N> L, const real* g_h, real Delta, real& alpha, real* p) {
+  real ng[N], w[N];
 #pragma unroll
   for (int i = 0; i < N; i++) ng[i] = -g_h[i];
   bool full_rank = chol7<N>(A, 0.0, L);
@@ -307,7 +331,7 @@ __device__ __forceinline__ void min_quad_1d(real a, real b, real lo, real hi, re
 
 // scipy trf.py select_step; quadratic model q(s) = 0.5 s^T A s + g_h^T s
 template <int N>
-__device__ __forceinline__ real select_step(const real* x, const real (*A)[N], const real* g_h, real* p, real* p_h,
+__device__ __forceinline__ real select_step(const real* x, LMat<N, N> A, const real* g_h, real* p, real* p_h,
                                             const real* d, real Delta, const real* lb, const real* ub, real theta,
                                             real* step, real* step_h) {
   real xp[N];
@@ -380,12 +404,14 @@ __device__ __forceinline__ real select_step(const real* x, const real (*A)[N], c
 // scipy trf.py trf_bounds (tr_solver='exact', x_scale=1, loss='linear', ftol=xtol=gtol=1e-8, max_nfev=100n).
 // x: in = strictly feasible start, out = result.x; x_last = last point the residual/Jacobian was evaluated at.
 template <int N>
-__device__ int trf_bounds(const IkCtx<N>& P, real* x, real* x_last, int* nfev_out) {
+__device__ int trf_bounds(const IkCtx<N>& P, const IkLds<N>& S, real* x, real* x_last, int* nfev_out) {
   const real ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
   const int max_nfev = 100 * N;
   const real jreg2 = 2 * P.m->ik_jac_reg * P.m->ik_jac_reg;
   IkEval<N> E;
-  real g[N], v[N], dv[N], d[N], diag_h[N], g_h[N], A[N][N];
+  E.Jt = S.J;
+  const LMat<N, N> A = S.A;
+  real g[N], v[N], dv[N], d[N], diag_h[N], g_h[N];
   real x_new[N], step[N], step_h[N], p[N], p_h[N], ft_new[6];
   ik_eval<N, true>(P, x, E);
   int nfev = 1;
@@ -425,16 +451,16 @@ __device__ int trf_bounds(const IkCtx<N>& P, real* x, real* x_last, int* nfev_ou
       for (int j = 0; j <= i; j++) {
         real s = 0;
 #pragma unroll
-        for (int r = 0; r < 6; r++) s += E.Jt[r][i] * E.Jt[r][j];
+        for (int r = 0; r < 6; r++) s += E.Jt(r, i) * E.Jt(r, j);
         if (i == j) s += jreg2;
         s *= d[i] * d[j];
         if (i == j) s += diag_h[i];
-        A[i][j] = s; A[j][i] = s;
+        A(i, j) = s; A(j, i) = s;
       }
     real theta = fmax(0.995, 1 - g_norm);
     real actual = -1;
     while (actual <= 0 && nfev < max_nfev) {
-      solve_tr<N>(A, g_h, Delta, alpha, p_h);
+      solve_tr<N>(A, S.L, g_h, Delta, alpha, p_h);
 #pragma unroll
       for (int i = 0; i < N; i++) p[i] = d[i] * p_h[i];
       real predicted = select_step<N>(x, A, g_h, p, p_h, d, Delta, P.lb, P.ub, theta, step, step_h);
@@ -442,6 +468,7 @@ __device__ int trf_bounds(const IkCtx<N>& P, real* x, real* x_last, int* nfev_ou
       for (int i = 0; i < N; i++) x_new[i] = x[i] + step[i];
       make_strictly_feasible<N>(x_new, P.lb, P.ub, 0.0);
       IkEval<N> En;
+      En.Jt = S.J;
       ik_eval<N, false>(P, x_new, En);
 #pragma unroll
       for (int r = 0; r < 6; r++) ft_new[r] = En.ft[r];
@@ -484,14 +511,14 @@ __device__ int trf_bounds(const IkCtx<N>& P, real* x, real* x_last, int* nfev_ou
 
 // ik_mujoco.py:100-155 for one (env, arm); x0 = current arm joints
 template <int N>
-__device__ __forceinline__ void ik_solve(IkCtx<N>& P, const real* x0, real* q_out, real* x_last, int* nfev, int* status) {
+__device__ __forceinline__ void ik_solve(IkCtx<N>& P, const IkLds<N>& S, const real* x0, real* q_out, real* x_last, int* nfev, int* status) {
   real x[N];
 #pragma unroll
   for (int i = 0; i < N; i++) { x[i] = x0[i]; x_last[i] = x0[i]; }
   *nfev = 0; *status = -2;
   if (in_bounds<N>(x, P.lb, P.ub)) {            // else least_squares raises ValueError -> "IK failed"
     make_strictly_feasible<N>(x, P.lb, P.ub, 1e-10);
-    *status = trf_bounds<N>(P, x, x_last, nfev);
+    *status = trf_bounds<N>(P, S, x, x_last, nfev);
   }
 #pragma unroll
   for (int i = 0; i < N; i++) q_out[i] = fmin(fmax(x[i], P.lb[i]), P.ub[i]);   // :147-152 (:140-145 is a no-op)
@@ -520,8 +547,16 @@ __global__ __launch_bounds__(64) void k_before_step(const KDeviceModel* __restri
                                                     const float* __restrict__ act) {
   const KModelDesc* m = &dm->d;
   const int NE = st.num_envs;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int env = tid % NE, arm = tid / NE;   // consecutive lanes = consecutive envs (coalesced SoA)
+  constexpr int NSLOT = 64 / IK_LANE_STRIDE;
+  __shared__ real ik_lds[IkLds<N>::WORDS * NSLOT];
+  const IkLds<N> S(ik_lds, threadIdx.x / IK_LANE_STRIDE, NSLOT);
+  // The TRF is a long data-dependent serial program: a wave runs for as long as its slowest lane.  With
+  // only num_envs * narm problems (4096..16384) against 65,536 lanes, problems are spread IK_LANE_STRIDE
+  // lanes apart so that a wave carries 64 / stride of them (shorter divergence tail, all SIMDs busy).
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gtid % IK_LANE_STRIDE) return;
+  const int tid = gtid / IK_LANE_STRIDE;
+  const int env = tid % NE, arm = tid / NE;
   if (arm >= KM_MAX_ARMS || !m->arm_present[arm]) return;
   const int nl = m->nlink;
   const float* a = act + (size_t)env * m->act_dim;
@@ -557,6 +592,7 @@ __global__ __launch_bounds__(64) void k_before_step(const KDeviceModel* __restri
     P.goal_pos[0] = 0; P.goal_pos[1] = 0; P.goal_pos[2] = 0;
     P.goal_quat[0] = 1; P.goal_quat[1] = 0; P.goal_quat[2] = 0; P.goal_quat[3] = 0;
     IkEval<N> E0;
+    E0.Jt = S.J;
     ik_eval<N, false>(P, x0, E0);
     const real* smat = E0.smat;
     // EE-delta decode (env_sim.py:60-69): euler("xyz", extrinsic) of the site matrix + delta -> quaternion
@@ -575,7 +611,7 @@ __global__ __launch_bounds__(64) void k_before_step(const KDeviceModel* __restri
     P.goal_pos[2] = (double)a[cp + 2] * m->ee_pos_delta[2] + E0.sp[2];
     real qo[N], xl[N];
     int nfev, status;
-    ik_solve<N>(P, x0, qo, xl, &nfev, &status);
+    ik_solve<N>(P, S, x0, qo, xl, &nfev, &status);
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int q = m->arm_q_id[arm][i];
@@ -612,7 +648,7 @@ void kmanip_launch_ik(const KDeviceModel* dm, const KModelDesc& hd, const KDevic
   int n0 = st.num_envs * hd.nlink;
   hipLaunchKernelGGL(k_prepare, dim3((n0 + 255) / 256), dim3(256), 0, stream, dm, st);
   int narm_slots = (hd.arm_present[1]) ? 2 : 1;
-  int nt = st.num_envs * narm_slots;
+  int nt = st.num_envs * narm_slots * IK_LANE_STRIDE;
   int nik = hd.arm_nq[0] ? hd.arm_nq[0] : hd.arm_nq[1];
   if (nik == 7) hipLaunchKernelGGL(k_before_step<7>, dim3((nt + 63) / 64), dim3(64), 0, stream, dm, st, act);
   else hipLaunchKernelGGL(k_before_step<6>, dim3((nt + 63) / 64), dim3(64), 0, stream, dm, st, act);
@@ -624,6 +660,8 @@ template <int N>
 __global__ __launch_bounds__(64) void k_ik_standalone(const KDeviceModel* __restrict__ dm, int arm, int n, int nq,
                                                       double* qpos, const double* goal_pos, const double* goal_quat,
                                                       double* q_out, int32_t* nfev_o, int32_t* status_o) {
+  __shared__ real ik_lds[IkLds<N>::WORDS * 64];
+  const IkLds<N> S(ik_lds, threadIdx.x, 64);
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   IkCtx<N> P;
@@ -641,7 +679,7 @@ __global__ __launch_bounds__(64) void k_ik_standalone(const KDeviceModel* __rest
   for (int c = 0; c < 4; c++) P.goal_quat[c] = goal_quat[4 * e + c];
   real qo[N], xl[N];
   int nfev, status;
-  ik_solve<N>(P, x0, qo, xl, &nfev, &status);
+  ik_solve<N>(P, S, x0, qo, xl, &nfev, &status);
 #pragma unroll
   for (int i = 0; i < N; i++) { q_out[(size_t)e * N + i] = qo[i]; qp[dm->d.arm_q_id[arm][i]] = xl[i]; }
   nfev_o[e] = nfev; status_o[e] = status;
