@@ -74,7 +74,7 @@ struct Ws {
   real Minv[NL][NL];       // joint-space inertia, overwritten by its inverse
   real Mm[NL][NL];         // copy of the joint-space inertia itself (Newton: Gauss term and Hessian)
   union {
-    struct { real Lw[NL][NL]; real FN[NL][6]; } f;   // Cholesky workspace, per-body bias wrenches
+    struct { union { real Lw[NL][NL]; real comp[NL][10]; }; real FN[NL][6]; } f;   // Cholesky workspace | composite inertias; bias wrenches
     real stage[4][NV];                               // staging of basis rows for B = M^-1 J^T
     ConRec rec[NC];                                  // solver records (built last)
   };
@@ -95,6 +95,34 @@ struct Ws {
 // (bb only for the slots that involve arm dofs: for table-cube slots M^-1 is diagonal, bb = jb * invm)
 template <int NC, int NCF> struct CReg { real jb[NC][4]; real bb[NCF][4]; };
 
+// ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
+// their own and never feed an output; the shipped library compiles every call away.
+#define KM_NPH 16
+#ifdef KM_PROFILE
+__device__ unsigned long long g_prof[KM_NPH];
+struct Prof {
+  unsigned long long t0, acc[KM_NPH];
+  __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void ph(int i) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[i] += t - t0; t0 = t;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void flush() { if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) atomicAdd(&g_prof[i], acc[i]); }
+};
+extern "C" int kmanip_dbg_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * KM_NPH) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[KM_NPH] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+struct Prof {
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void ph(int) {}
+  __device__ __forceinline__ void flush() {}
+};
+#endif
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // cross-lane double move with a DPP control word (row = 16 lanes)
@@ -190,28 +218,84 @@ __device__ __forceinline__ void com_jac_col(const Ws<NL>& w, const LModel<NL>& l
   }
 }
 
-// M_ij = sum over bodies b below both i and j of  m_b Jv_bi . Jv_bj + Jw_bi . I_b Jw_bj
+// Composite-rigid-body mass matrix.  Lane b first writes body b's own (mass, first moment m*c, inertia about
+// the world origin) -- 10 numbers; lane 0 then suffix-accumulates them up the tree (children into parents);
+// lane j finally projects the unit-acceleration wrench of its composite onto every ancestor joint:
+//   F = mc*a_O + alpha x h,  N_O = Io*alpha + h x a_O   (hinge: alpha = axis_j, a_O = o_j x axis_j; slide: a_O = axis_j)
+//   M_ij = axis_i . (N_O - o_i x F)  (hinge i)   |   axis_i . F  (slide i)
+template <int NL, int G>
+__device__ __forceinline__ void composite_own(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+  for (int b = sub; b < NL; b += G) {
+    const real mb = lm.mass[b];
+    const real c[3] = {w.k.cpos[b][0], w.k.cpos[b][1], w.k.cpos[b][2]};
+    const real* R = w.k.xmat[b];
+    const real I0 = lm.inertia[b][0], I1 = lm.inertia[b][1], I2 = lm.inertia[b][2];
+    const real cc = dot3(c, c);
+    real* o = w.f.comp[b];
+    o[0] = mb; o[1] = mb * c[0]; o[2] = mb * c[1]; o[3] = mb * c[2];
+    // R diag(I) R^T + m (|c|^2 1 - c c^T), packed xx xy xz yy yz zz
+    o[4] = R[0] * R[0] * I0 + R[1] * R[1] * I1 + R[2] * R[2] * I2 + mb * (cc - c[0] * c[0]);
+    o[5] = R[0] * R[3] * I0 + R[1] * R[4] * I1 + R[2] * R[5] * I2 - mb * c[0] * c[1];
+    o[6] = R[0] * R[6] * I0 + R[1] * R[7] * I1 + R[2] * R[8] * I2 - mb * c[0] * c[2];
+    o[7] = R[3] * R[3] * I0 + R[4] * R[4] * I1 + R[5] * R[5] * I2 + mb * (cc - c[1] * c[1]);
+    o[8] = R[3] * R[6] * I0 + R[4] * R[7] * I1 + R[5] * R[8] * I2 - mb * c[1] * c[2];
+    o[9] = R[6] * R[6] * I0 + R[7] * R[7] * I1 + R[8] * R[8] * I2 + mb * (cc - c[2] * c[2]);
+  }
+}
+template <int NL>
+__device__ __forceinline__ void composite_accumulate_serial(Ws<NL>& w, const LModel<NL>& lm) {
+  for (int i = NL - 1; i >= 0; i--) {
+    const int p = lm.parent[i];
+    if (p >= 0) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) w.f.comp[p][k] += w.f.comp[i][k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) w.f.FN[p][k] += w.f.FN[i][k];      // bias wrenches (about the world origin) too
+    }
+  }
+}
 template <int NL, int G>
 __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int sub) {
-  for (int idx = sub; idx < NL * NL; idx += G) {
-    const int i = idx / NL, j = idx % NL;
-    if (i > j) continue;
-    real s = 0;
-    if ((lm.anc[j] >> i) & 1u) {
-      for (int b = j; b < NL; b++) {
-        if (!((lm.anc[b] >> j) & 1u)) continue;
-        real jvi[3], jwi[3], jvj[3], jwj[3];
-        com_jac_col<NL>(w, lm, b, i, jvi, jwi);
-        com_jac_col<NL>(w, lm, b, j, jvj, jwj);
-        s += lm.mass[b] * dot3(jvi, jvj);
-        real li[3], lj[3];
-        matT_vec3(li, w.k.xmat[b], jwi);
-        matT_vec3(lj, w.k.xmat[b], jwj);
-        s += lm.inertia[b][0] * li[0] * lj[0] + lm.inertia[b][1] * li[1] * lj[1] + lm.inertia[b][2] * li[2] * lj[2];
-      }
+  for (int j = sub; j < NL; j += G) {
+    const real* o = w.f.comp[j];
+    const real ax[3] = {w.k.axis[j][0], w.k.axis[j][1], w.k.axis[j][2]};
+    const real oj[3] = {w.k.xpos[j][0], w.k.xpos[j][1], w.k.xpos[j][2]};
+    const real h[3] = {o[1], o[2], o[3]};
+    real F[3], N[3], t[3];
+    if (lm.jtype[j] == KM_JNT_SLIDE) {
+      F[0] = o[0] * ax[0]; F[1] = o[0] * ax[1]; F[2] = o[0] * ax[2];
+      cross3(N, h, ax);
+    } else {
+      real aO[3];
+      cross3(aO, oj, ax);
+      cross3(t, ax, h);
+      F[0] = o[0] * aO[0] + t[0]; F[1] = o[0] * aO[1] + t[1]; F[2] = o[0] * aO[2] + t[2];
+      N[0] = o[4] * ax[0] + o[5] * ax[1] + o[6] * ax[2];
+      N[1] = o[5] * ax[0] + o[7] * ax[1] + o[8] * ax[2];
+      N[2] = o[6] * ax[0] + o[8] * ax[1] + o[9] * ax[2];
+      cross3(t, h, aO);
+      N[0] += t[0]; N[1] += t[1]; N[2] += t[2];
     }
-    w.Minv[i][j] = s; w.Minv[j][i] = s;
+    for (int i = 0; i < NL; i++) w.Minv[i][j] = 0;            // non-ancestors (filled symmetric below)
+    for (int i = j; i >= 0; i = lm.parent[i]) {
+      real val;
+      const real ai[3] = {w.k.axis[i][0], w.k.axis[i][1], w.k.axis[i][2]};
+      if (lm.jtype[i] == KM_JNT_SLIDE) val = dot3(ai, F);
+      else {
+        const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
+        cross3(t, oi, F);
+        real mo[3] = {N[0] - t[0], N[1] - t[1], N[2] - t[2]};
+        val = dot3(ai, mo);
+      }
+      w.Minv[i][j] = val;
+    }
   }
+}
+// lower triangle from the upper one (column j only wrote rows i <= j along its ancestor path)
+template <int NL, int G>
+__device__ __forceinline__ void mass_symmetrize(Ws<NL>& w, int sub) {
+  for (int j = sub; j < NL; j += G)
+    for (int i = j + 1; i < NL; i++) w.Minv[i][j] = w.Minv[j][i];
 }
 
 // velocity-product + gravity wrenches per body (serial forward pass), then bias_j = sum_b J_bj^T wrench_b
@@ -255,8 +339,11 @@ __device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const LModel<NL>& 
 #pragma unroll
     for (int c = 0; c < 3; c++) nl3[c] += lm.inertia[i][c] * all[c];
     mat_vec3(nw, w.k.xmat[i], nl3);
+    real Fi[3] = {lm.mass[i] * (ai[0] + t1[0] + t2[0]), lm.mass[i] * (ai[1] + t1[1] + t2[1]), lm.mass[i] * (ai[2] + t1[2] + t2[2])};
+    real cpi[3] = {w.k.cpos[i][0], w.k.cpos[i][1], w.k.cpos[i][2]}, sh[3];
+    cross3(sh, cpi, Fi);                       // shift the moment from the com to the world origin
 #pragma unroll
-    for (int c = 0; c < 3; c++) { w.f.FN[i][c] = lm.mass[i] * (ai[c] + t1[c] + t2[c]); w.f.FN[i][3 + c] = nw[c]; }
+    for (int c = 0; c < 3; c++) { w.f.FN[i][c] = Fi[c]; w.f.FN[i][3 + c] = nw[c] + sh[c]; }
   }
   // cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
   real wv[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
@@ -267,16 +354,18 @@ __device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const LModel<NL>& 
 }
 template <int NL, int G>
 __device__ __forceinline__ void bias_project(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+  // FN[j] now holds the accumulated wrench of subtree(j) about the world origin
   for (int j = sub; j < NL; j += G) {
-    real s = 0;
-    for (int b = j; b < NL; b++) {
-      if (!((lm.anc[b] >> j) & 1u)) continue;
-      real jv[3], jw[3];
-      com_jac_col<NL>(w, lm, b, j, jv, jw);
-      s += jv[0] * w.f.FN[b][0] + jv[1] * w.f.FN[b][1] + jv[2] * w.f.FN[b][2];
-      s += jw[0] * w.f.FN[b][3] + jw[1] * w.f.FN[b][4] + jw[2] * w.f.FN[b][5];
+    const real aj[3] = {w.k.axis[j][0], w.k.axis[j][1], w.k.axis[j][2]};
+    const real F[3] = {w.f.FN[j][0], w.f.FN[j][1], w.f.FN[j][2]};
+    if (lm.jtype[j] == KM_JNT_SLIDE) w.bias[j] = dot3(aj, F);
+    else {
+      const real oj[3] = {w.k.xpos[j][0], w.k.xpos[j][1], w.k.xpos[j][2]};
+      real t[3];
+      cross3(t, oj, F);
+      real mo[3] = {w.f.FN[j][3] - t[0], w.f.FN[j][4] - t[1], w.f.FN[j][5] - t[2]};
+      w.bias[j] = dot3(aj, mo);
     }
-    w.bias[j] = s;
   }
 }
 
@@ -532,6 +621,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
 #pragma unroll
   for (int c = 4; c < NC; c++) {
     cr.bb[c - 4][0] = 0; cr.bb[c - 4][1] = 0; cr.bb[c - 4][2] = 0; cr.bb[c - 4][3] = 0;
+    __builtin_amdgcn_sched_barrier(0);
     if ((act >> c) & 1u) {
       if (sub < NV) {
 #pragma unroll
@@ -556,6 +646,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
   const real qv = sub < NV ? w.qvel[sub] : 0.0;
 #pragma unroll
   for (int c = 0; c < NC; c++) {
+    __builtin_amdgcn_sched_barrier(0);
     if ((act >> c) & 1u) {
       const int kind = slot_kind<NL>(c);
       real Gm[4][4], vb[4];
@@ -673,6 +764,7 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
   }
 #pragma unroll
   for (int c = 0; c < NC; c++) {
+    __builtin_amdgcn_sched_barrier(0);
     if ((act >> c) & 1u) {
       real wk[4], ak[4], F[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -736,7 +828,8 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
     }
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-      if ((act >> c) & 1u) {
+      __builtin_amdgcn_sched_barrier(0);
+    if ((act >> c) & 1u) {
         // group-uniform tables come from LDS as broadcast reads (no stores in between: freely scheduled)
         const ConRec& rr = w.rec[c];
         const real Rc = rr.R;
@@ -881,6 +974,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   const real qv = sub < NV ? w.qvel[sub] : 0.0;
 #pragma unroll
   for (int c = 0; c < NC; c++) {
+    __builtin_amdgcn_sched_barrier(0);
     if ((act >> c) & 1u) {
       const int kind = slot_kind<NL>(c);
       const bool cube = kind != 2;
@@ -979,7 +1073,7 @@ __device__ __forceinline__ real newton_eval(Ws<NL>& w, const KModelDesc* m, int 
 
 template <int NL, int G>
 __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
-                                             CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+                                             CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   // ---- actuation and smooth acceleration (as in the PGS path)
   if (sub < NV) {
@@ -1020,6 +1114,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   const real scale = 1.0 / (w.Mtrace + 3 * m->cube_mass + m->cube_inertia[0] + m->cube_inertia[1] + m->cube_inertia[2]);
   const real tol = m->solver_tolerance;
   const int maxit = m->solver_iterations;
+  pf.ph(6);
   if (sqrt(gsum<G>(grad * grad)) * scale < tol) return a;
   const int ns = w.ns;
   for (int iter = 0; iter < maxit; iter++) {
@@ -1034,7 +1129,8 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     GSYNC();
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-      if ((act >> c) & 1u) {
+      __builtin_amdgcn_sched_barrier(0);
+    if ((act >> c) & 1u) {
         const ConRec& rc = w.rec[c];
         const uint32_t qm = (uint32_t)rc.f[0];
         const real Dn = 1.0 / rc.R;
@@ -1064,9 +1160,12 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
         GSYNC();
       }
     }
+    pf.ph(7);
     // ---- p = -H^-1 grad
     chol_lds<G>(&w.h.Hm[0][0], NV, NV, sub, &w.bad);
+    pf.ph(8);
     const real p = chol_solve_lds<G>(&w.h.Hm[0][0], NV, NV, sub, -grad, w.tmp3);
+    pf.ph(9);
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
     if (sub < NV) w.tmp[sub] = p;
     GSYNC();
@@ -1077,7 +1176,8 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     // per-contact projections of a and p, parked in the (otherwise unused) inv/den slots of the records
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-      if ((act >> c) & 1u) {
+      __builtin_amdgcn_sched_barrier(0);
+    if ((act >> c) & 1u) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const real x = gsum<G>(cr.jb[c][k] * a), y = gsum<G>(cr.jb[c][k] * p);
@@ -1086,30 +1186,42 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
       }
     }
     GSYNC();
+    // this lane's share of the rows, hoisted into registers: x(alpha) = lx + alpha * ly per row
+    constexpr int NEQ = (6 * NC + G - 1) / G, NAQ = (Dim<NL>::NS + G - 1) / G;
+    real lx[NEQ], ly[NEQ], lR[NEQ];          // contact edges t = sub + G*q  (lR = 0: no row)
+    real ax[NAQ], ay[NAQ], aR[NAQ], afl[NAQ]; int aty[NAQ];   // arm single-dof rows r = sub + G*q (aR = 0: no row)
+#pragma unroll
+    for (int q = 0; q < NEQ; q++) {
+      const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
+      lx[q] = 0; ly[q] = 0; lR[q] = 0;
+      const bool valid = c < NC && ((act >> c) & 1u) && !(c >= 4 + Dim<NL>::NSPH && e >= 4);
+      if (valid) {
+        const ConRec& rc = w.rec[c];
+        const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+        lx[q] = rc.inv[0] + sm * rc.inv[k] - rc.aref[e];
+        ly[q] = rc.den[0] + sm * rc.den[k];
+        lR[q] = rc.R;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NAQ; q++) {
+      const int r = sub + G * q;
+      ax[q] = 0; ay[q] = 0; aR[q] = 0; afl[q] = 0; aty[q] = 1;
+      if (r < ns) {
+        const int j = w.s_dof[r];
+        const real sg = w.s_sign[r];
+        ax[q] = sg * w.tmp2[j] - w.s_aref[r]; ay[q] = sg * w.tmp[j]; aR[q] = w.s_R[r]; afl[q] = w.s_floss[r]; aty[q] = w.s_type[r];
+      }
+    }
+    pf.ph(10);
     real alpha = 0, lo = 0, hi = INFINITY, d1 = 0, d2 = 0, d10 = 0;
     for (int it = 0; it <= 50; it++) {
       real e1 = 0, e2 = 0;
-      for (int q = sub; q < ns; q += G) {
-        const int j = w.s_dof[q];
-        const real sg = w.s_sign[q];
-        row_ls(w.s_type[q], sg * w.tmp2[j] - w.s_aref[q] + alpha * (sg * w.tmp[j]), sg * w.tmp[j], w.s_R[q], w.s_floss[q], e1, e2);
-      }
+#pragma unroll
+      for (int q = 0; q < NAQ; q++) if (aR[q] != 0) row_ls(aty[q], ax[q] + alpha * ay[q], ay[q], aR[q], afl[q], e1, e2);
       if (my_row) row_ls(0, (a - my_aref) + alpha * p, p, my_R, my_fl, e1, e2);
 #pragma unroll
-      for (int c = 0; c < NC; c++) {
-        if ((act >> c) & 1u) {
-          const ConRec& rc = w.rec[c];
-#pragma unroll
-          for (int e = 0; e < 6; e++) {
-            if (slot_kind<NL>(c) == 2 && e >= 4) continue;
-            if (((6 * c + e) % G) != sub) continue;                   // edges strided over the lanes
-            const int k = e / 2 + 1;
-            const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
-            const real y = rc.den[0] + sm * rc.den[k];
-            row_ls(1, (rc.inv[0] + sm * rc.inv[k] - rc.aref[e]) + alpha * y, y, rc.R, 0.0, e1, e2);
-          }
-        }
-      }
+      for (int q = 0; q < NEQ; q++) if (lR[q] != 0) row_ls(1, lx[q] + alpha * ly[q], ly[q], lR[q], 0.0, e1, e2);
       d1 = gp + alpha * pMp + gsum<G>(e1);
       d2 = pMp + gsum<G>(e2);
       if (it == 0) { d10 = d1; if (!(d10 < 0)) break; }
@@ -1123,10 +1235,12 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
       if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
       alpha = an;
     }
+    pf.ph(11);
     a += alpha * p;
     const real cost_new = newton_eval<NL, G>(w, m, sub, cr, a, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad);
     const real improvement = scale * (cost - cost_new), gradient = scale * sqrt(gsum<G>(grad * grad));
     cost = cost_new;
+    pf.ph(12);
     if (improvement < tol || gradient < tol || w.bad) break;
   }
   return a;
@@ -1135,26 +1249,40 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
 // everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
-                                               CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+                                               CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
   if (sub == 0) {
     fk_serial<NL>(w, lm);
+    pf.ph(0);
     bias_bodies_serial<NL>(w, lm, m);
+    pf.ph(1);
     collide_serial<NL>(w, m);
     scalar_rows_serial<NL>(w, lm);
   }
   GSYNC();
+  pf.ph(2);
+  composite_own<NL, G>(w, lm, sub);
+  GSYNC();
+  if (sub == 0) composite_accumulate_serial<NL>(w, lm);
+  GSYNC();
   mass_matrix<NL, G>(w, lm, sub);
   bias_project<NL, G>(w, lm, sub);
   GSYNC();
+  mass_symmetrize<NL, G>(w, sub);
+  GSYNC();
+  pf.ph(3);
   invert_mass<NL, G>(w, sub);
+  pf.ph(4);
   if (SOLVER == KM_SOLVER_NEWTON) build_constraints_newton<NL, G>(w, lm, m, sub, cr, invm);
   else build_constraints<NL, G>(w, lm, m, sub, cr, invm);
+  pf.ph(5);
 }
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ real solve(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
-                                      CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
-  if (SOLVER == KM_SOLVER_NEWTON) return solve_newton<NL, G>(w, lm, m, sub, actuation, cr, invm);
-  return solve_accel<NL, G>(w, lm, m, sub, actuation, cr, invm);
+                                      CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
+  if (SOLVER == KM_SOLVER_NEWTON) return solve_newton<NL, G>(w, lm, m, sub, actuation, cr, invm, pf);
+  real a = solve_accel<NL, G>(w, lm, m, sub, actuation, cr, invm);
+  pf.ph(6);
+  return a;
 }
 
 // mj_Euler: qvel += dt*qacc, then positions with the NEW velocity (semi-implicit); free-joint quaternion
@@ -1201,7 +1329,7 @@ __device__ __forceinline__ void write_obs(const Ws<NL>& w, const LModel<NL>& lm,
 // initialize_episode (env_sim.py:23-36) + mj_forward without actuation (dm_control after_reset)
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, uint64_t seed,
-                                          int64_t genv, int episode, CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+                                          int64_t genv, int episode, CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
   constexpr int NV = Dim<NL>::NV;
   if (sub < NV) { w.qvel[sub] = 0; w.warm[sub] = 0; }
   if (sub < NL) { w.qpos[sub] = lm.q_home[sub]; w.ctrl[sub] = lm.q_home[sub]; }
@@ -1220,8 +1348,8 @@ __device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const
     w.bad = 0;
   }
   GSYNC();
-  step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm);
-  real a = solve<NL, G, SOLVER>(w, lm, m, sub, 0, cr, invm);
+  step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm, pf);
+  real a = solve<NL, G, SOLVER>(w, lm, m, sub, 0, cr, invm, pf);
   if (sub < NV) w.warm[sub] = a;
   GSYNC();
 }
@@ -1275,13 +1403,17 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   CReg<Dim<NL>::NC, Dim<NL>::NCF> cr;
   real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
+  Prof pf;
+  pf.start();
   load_state<NL, G>(w, st, env, sub);
   GSYNC();
+  pf.ph(15);
   int bad = 0;
   const int nsub = m->n_sub_steps;
   for (int s = 0; s < nsub; s++) {
-    step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm);      // s == 0: products of the pre-IK state (stale mj_step2)
-    real a = solve<NL, G, SOLVER>(w, lm, m, sub, 1, cr, invm);
+    step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm, pf);      // s == 0: products of the pre-IK state (stale mj_step2)
+    real a = solve<NL, G, SOLVER>(w, lm, m, sub, 1, cr, invm, pf);
+    pf.ph(14);
     int lb = (sub < NV) && (!isfinite(a) || fabs(a) > 1e10);   // mjWARN_BADQACC
     bad = gor<G>(lb) | w.bad;
     if (bad) break;
@@ -1290,6 +1422,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
       GSYNC();
     }
     integrate<NL, G>(w, m, sub, a);
+    pf.ph(13);
   }
   if (!bad) {
     int lb = 0;
@@ -1331,12 +1464,14 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (dn && (m->auto_reset || bad)) {
     episode += 1; step_idx = 0;
     GSYNC();
-    reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
+    reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
   }
   if (sub == 0) { reward[env] = rew; done[env] = dn; st.step_idx[env] = step_idx; st.episode[env] = episode; }
   GSYNC();
   store_state<NL, G>(w, st, env, sub);
+  pf.ph(14);
+  pf.flush();
 }
 
 // KManipEnvSim.k_reset for the envs selected by mask (NULL = all)
@@ -1357,7 +1492,9 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   real invm = 0;
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   int episode = st.episode[env] + 1;
-  reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm);
+  Prof pf;
+  pf.start();
+  reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
   if (obs) write_obs<NL, G>(w, lm, m, sub, obs + (size_t)env * m->obs_dim);
   if (sub == 0) { st.step_idx[env] = 0; st.episode[env] = episode; st.contact_mask[env] = 0; }
   GSYNC();

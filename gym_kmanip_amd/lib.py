@@ -13,7 +13,7 @@ import subprocess
 from .model import KModelDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmanip_hip.so")
+LIB_PATH = os.environ.get("KMANIP_LIB") or os.path.join(_HERE, "libkmanip_hip.so")   # KMANIP_LIB: diagnostic builds only
 _lib = None
 
 # every symbol include/kmanip.h declares (tests check the library exports all of them)

@@ -1,0 +1,33 @@
+"""Diagnostic: per-phase cycle shares of k_step from the -DKM_PROFILE build (make -C gym_kmanip_amd/csrc prof).
+Usage: KMANIP_LIB=gym_kmanip_amd/libkmanip_hip_prof.so python tools/phase_profile.py [solver]"""
+import ctypes as C, os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+os.environ.setdefault("KMANIP_LIB", os.path.join(ROOT, "gym_kmanip_amd", "libkmanip_hip_prof.so"))
+import numpy as np, torch
+from gym_kmanip_amd import env_hip
+names = ["fk", "bias_serial", "collide+rows", "mass+bias_proj", "invert_mass", "build_constraints", "solve:setup/PGS",
+         "newton:H build", "newton:chol", "newton:tri-solve", "newton:ls setup", "newton:ls loop", "newton:eval",
+         "integrate", "tail(reward/obs/store)", "load"]
+solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
+n = 4096
+env = env_hip.make("KManipSoloArm", num_envs=n, seed=0, solver=solver)
+L = env.L
+env.k_reset()
+gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+acts = [(torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1) for _ in range(8)]
+for k in range(16): env.step_flat(acts[k % 8])
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 16)()
+L.kmanip_dbg_prof(buf, 1)
+steps = 32
+for k in range(steps): env.step_flat(acts[k % 8])
+torch.cuda.synchronize()
+L.kmanip_dbg_prof(buf, 0)
+v = np.array(list(buf), dtype=np.float64)
+nblocks = n // 4
+per = v / nblocks / steps            # cycles (100 MHz memtime ticks?) per block per control step
+tot = per.sum()
+print("solver", solver, "total ticks per block per step %.0f" % tot)
+for nm, x in zip(names, per):
+    print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / tot))
