@@ -15,6 +15,35 @@
 #include "kmanip_device.hpp"
 
 #define DBL_EPS 2.220446049250313e-16
+// ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE); see kmanip_dyn.hip
+#define KM_NPH_IK 8
+#ifdef KM_PROFILE
+__device__ unsigned long long g_prof_ik[KM_NPH_IK];
+struct ProfIk {
+  unsigned long long t0, acc[KM_NPH_IK];
+  __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH_IK; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void ph(int i) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[i] += t - t0; t0 = t;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void flush() { if ((threadIdx.x & 63) == 0) for (int i = 0; i < KM_NPH_IK; i++) atomicAdd(&g_prof_ik[i], acc[i]); }
+};
+extern "C" int kmanip_dbg_prof_ik(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_ik), sizeof(unsigned long long) * KM_NPH_IK) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[KM_NPH_IK] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_ik), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+struct ProfIk {
+  __device__ __forceinline__ void start() {}
+  // in the product build a phase boundary is just a scheduling fence: it keeps the (fully unrolled) phases from
+  // being interleaved, which is what drove this kernel into scratch spills
+  __device__ __forceinline__ void ph(int) { __builtin_amdgcn_sched_barrier(0); }
+  __device__ __forceinline__ void flush() {}
+};
+#endif
 #ifndef IK_LANE_STRIDE
 #define IK_LANE_STRIDE 4
 #endif
@@ -28,12 +57,13 @@ struct LMat {
   __device__ __forceinline__ real& operator()(int r, int c) const { return p[(r * C + c) * stride]; }
 };
 template <int N>
-struct IkLds {          // the three big per-problem matrices kept out of the register file
-  LMat<6, N> J;         // task Jacobian
+struct IkLds {          // the big per-problem matrices kept out of the register file
+  LMat<6, N> J, J2;     // task Jacobian at x, and at the trial point x_new (swapped in when the step is accepted)
   LMat<N, N> A, L;      // normal matrix J_h^T J_h + C and the Cholesky factor of (A + alpha I)
-  static constexpr int WORDS = 6 * N + 2 * N * N;
+  static constexpr int WORDS = 12 * N + 2 * N * N;
   __device__ __forceinline__ IkLds(real* base, int slot, int nslots)
-      : J{base + slot, nslots}, A{base + 6 * N * nslots + slot, nslots}, L{base + (6 * N + N * N) * nslots + slot, nslots} {}
+      : J{base + slot, nslots}, J2{base + 6 * N * nslots + slot, nslots}, A{base + 12 * N * nslots + slot, nslots},
+        L{base + (12 * N + N * N) * nslots + slot, nslots} {}
 };
 
 template <int N>
@@ -404,12 +434,13 @@ __device__ __forceinline__ real select_step(const real* x, LMat<N, N> A, const r
 // scipy trf.py trf_bounds (tr_solver='exact', x_scale=1, loss='linear', ftol=xtol=gtol=1e-8, max_nfev=100n).
 // x: in = strictly feasible start, out = result.x; x_last = last point the residual/Jacobian was evaluated at.
 template <int N>
-__device__ int trf_bounds(const IkCtx<N>& P, const IkLds<N>& S, real* x, real* x_last, int* nfev_out) {
+__device__ int trf_bounds(const IkCtx<N>& P, const IkLds<N>& S, real* x, real* x_last, int* nfev_out, ProfIk& pf) {
   const real ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
   const int max_nfev = 100 * N;
   const real jreg2 = 2 * P.m->ik_jac_reg * P.m->ik_jac_reg;
-  IkEval<N> E;
+  IkEval<N> E, En;
   E.Jt = S.J;
+  LMat<6, N> Jtrial = S.J2;
   const LMat<N, N> A = S.A;
   real g[N], v[N], dv[N], d[N], diag_h[N], g_h[N];
   real x_new[N], step[N], step_h[N], p[N], p_h[N], ft_new[6];
@@ -430,6 +461,7 @@ __device__ int trf_bounds(const IkCtx<N>& P, const IkLds<N>& S, real* x, real* x
     Delta = sqrt(s); if (Delta == 0) Delta = 1.0; }
   real alpha = 0.0, cost_new = cost;
   int status = -1;
+  pf.ph(0);
 #pragma unroll
   for (int i = 0; i < N; i++) x_last[i] = x[i];
   for (;;) {
@@ -459,17 +491,22 @@ __device__ int trf_bounds(const IkCtx<N>& P, const IkLds<N>& S, real* x, real* x
       }
     real theta = fmax(0.995, 1 - g_norm);
     real actual = -1;
+    pf.ph(1);
     while (actual <= 0 && nfev < max_nfev) {
       solve_tr<N>(A, S.L, g_h, Delta, alpha, p_h);
+      pf.ph(2);
 #pragma unroll
       for (int i = 0; i < N; i++) p[i] = d[i] * p_h[i];
       real predicted = select_step<N>(x, A, g_h, p, p_h, d, Delta, P.lb, P.ub, theta, step, step_h);
+      pf.ph(3);
 #pragma unroll
       for (int i = 0; i < N; i++) x_new[i] = x[i] + step[i];
       make_strictly_feasible<N>(x_new, P.lb, P.ub, 0.0);
-      IkEval<N> En;
-      En.Jt = S.J;
-      ik_eval<N, false>(P, x_new, En);
+      // ik_res(x_new) -- and, in the same kinematics pass, what ik_jac(x_new) would recompute if the step is
+      // accepted (the reference evaluates both at the same point, ik_mujoco.py:20-97)
+      En.Jt = Jtrial;
+      ik_eval<N, true>(P, x_new, En);
+      pf.ph(4);
 #pragma unroll
       for (int r = 0; r < 6; r++) ft_new[r] = En.ft[r];
 #pragma unroll
@@ -500,9 +537,13 @@ __device__ int trf_bounds(const IkCtx<N>& P, const IkLds<N>& S, real* x, real* x
 #pragma unroll
       for (int i = 0; i < N; i++) x[i] = x_new[i];
       cost = cost_new;
-      ik_eval<N, true>(P, x, E);
+      const LMat<6, N> tmpJ = E.Jt;        // accept: the trial Jacobian becomes current, the old slot becomes trial
+      E.Jt = En.Jt; Jtrial = tmpJ;
+#pragma unroll
+      for (int r = 0; r < 6; r++) E.ft[r] = ft_new[r];
       ik_grad<N>(P, x, E, g);
     }
+    pf.ph(5);
   }
   if (status == -1) status = 0;
   *nfev_out = nfev;
@@ -511,14 +552,14 @@ __device__ int trf_bounds(const IkCtx<N>& P, const IkLds<N>& S, real* x, real* x
 
 // ik_mujoco.py:100-155 for one (env, arm); x0 = current arm joints
 template <int N>
-__device__ __forceinline__ void ik_solve(IkCtx<N>& P, const IkLds<N>& S, const real* x0, real* q_out, real* x_last, int* nfev, int* status) {
+__device__ __forceinline__ void ik_solve(IkCtx<N>& P, const IkLds<N>& S, const real* x0, real* q_out, real* x_last, int* nfev, int* status, ProfIk& pf) {
   real x[N];
 #pragma unroll
   for (int i = 0; i < N; i++) { x[i] = x0[i]; x_last[i] = x0[i]; }
   *nfev = 0; *status = -2;
   if (in_bounds<N>(x, P.lb, P.ub)) {            // else least_squares raises ValueError -> "IK failed"
     make_strictly_feasible<N>(x, P.lb, P.ub, 1e-10);
-    *status = trf_bounds<N>(P, S, x, x_last, nfev);
+    *status = trf_bounds<N>(P, S, x, x_last, nfev, pf);
   }
 #pragma unroll
   for (int i = 0; i < N; i++) q_out[i] = fmin(fmax(x[i], P.lb[i]), P.ub[i]);   // :147-152 (:140-145 is a no-op)
@@ -611,7 +652,11 @@ __global__ __launch_bounds__(64) void k_before_step(const KDeviceModel* __restri
     P.goal_pos[2] = (double)a[cp + 2] * m->ee_pos_delta[2] + E0.sp[2];
     real qo[N], xl[N];
     int nfev, status;
-    ik_solve<N>(P, S, x0, qo, xl, &nfev, &status);
+    ProfIk pf;
+    pf.start();
+    ik_solve<N>(P, S, x0, qo, xl, &nfev, &status, pf);
+    pf.ph(6);
+    pf.flush();
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int q = m->arm_q_id[arm][i];
@@ -679,7 +724,9 @@ __global__ __launch_bounds__(64) void k_ik_standalone(const KDeviceModel* __rest
   for (int c = 0; c < 4; c++) P.goal_quat[c] = goal_quat[4 * e + c];
   real qo[N], xl[N];
   int nfev, status;
-  ik_solve<N>(P, S, x0, qo, xl, &nfev, &status);
+  ProfIk pf;
+  pf.start();
+  ik_solve<N>(P, S, x0, qo, xl, &nfev, &status, pf);
 #pragma unroll
   for (int i = 0; i < N; i++) { q_out[(size_t)e * N + i] = qo[i]; qp[dm->d.arm_q_id[arm][i]] = xl[i]; }
   nfev_o[e] = nfev; status_o[e] = status;

@@ -31,3 +31,15 @@ tot = per.sum()
 print("solver", solver, "total ticks per block per step %.0f" % tot)
 for nm, x in zip(names, per):
     print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / tot))
+
+# ---- IK kernel phases
+names_ik = ["initial eval+grad", "scaling + normal matrix", "trust-region solve", "select_step", "trial eval (res+jac)", "accept/grad", "tail (divergence wait)", "-"]
+bi = (C.c_ulonglong * 8)()
+L.kmanip_dbg_prof_ik(bi, 1)
+for k in range(steps): env.step_flat(acts[k % 8])
+torch.cuda.synchronize()
+L.kmanip_dbg_prof_ik(bi, 0)
+v = np.array(list(bi), dtype=np.float64) / steps / (n * 4 / 64)
+print("IK kernel: ticks per wave per step %.0f" % v.sum())
+for nm, x in zip(names_ik, v):
+    print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / v.sum()))
