@@ -1,10 +1,11 @@
 // kmanip_api.hip -- host side of the C ABI declared in include/kmanip.h.
 // Owns the device model, the struct-of-arrays env state and the launch sequence of one control step:
-//   k_prepare (ctrl float32 round trip, qpos_ik = qpos)  ->  k_before_step (decode + IK)  ->  k_step (physics,
+//   k_prepare (ctrl float32 round trip, qpos_ik = qpos)  ->  k_before_step_coop (decode + IK)  ->  k_step (physics,
 //   reward, obs, done, auto-reset).  No CPU fallback exists: every entry point fails loudly without a HIP device.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -27,6 +28,7 @@ struct KHandle_ {
   std::vector<hipEvent_t> ev;   // 3 events per timed step
   bool timing = false;
   int timed_steps = 0;
+  bool ik_serial = false;       // KMANIP_IK_SERIAL=1: one-lane-per-problem IK kernel (A/B and cross-check only)
   std::vector<void*> allocs;
 };
 
@@ -81,6 +83,7 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
     int chain[KM_MAX_LINKS], n = 0;
     for (int j = d->arm_site_link[a]; j >= 0; j = d->link_parent[j]) chain[n++] = j;
     if (n > KM_MAX_CHAIN) { err = "IK chain longer than KM_MAX_CHAIN"; return -1; }
+    if (n > d->arm_nq[a] + 1) { err = "at most one fixed joint may follow the IK unknowns on the site's chain"; return -1; }
     x->chain_len[a] = n;
     h_quat2mat(d->arm_site_quat[a], x->site_R[a]);
     for (int k = 0; k < n; k++) {
@@ -144,6 +147,7 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.num_envs = num_envs;
   h->st.env_id_offset = env_id_offset;
   h->st.seed = seed;
+  { const char* e = getenv("KMANIP_IK_SERIAL"); h->ik_serial = e && e[0] == '1'; }
 #undef CR
   *out = h;
   return 0;
@@ -175,7 +179,8 @@ int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward
   const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
   hipEvent_t* ev = tm ? &h->ev[3 * (size_t)h->timed_steps] : nullptr;
   if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
-  kmanip_launch_ik(h->dmodel, h->desc, h->st, act_dev, s);
+  if (h->ik_serial) kmanip_launch_ik(h->dmodel, h->desc, h->st, act_dev, s);
+  else kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
   kmanip_launch_step(h->dmodel, h->desc, h->st, obs_dev, reward_dev, done_dev, s);
   if (tm) { HIPCHK(h, hipEventRecord(ev[2], s)); h->timed_steps++; }
@@ -292,7 +297,8 @@ int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos, c
   HIPCHK(h, hipMemcpy(dq, qpos, sizeof(double) * n * nq, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dgp, goal_pos, sizeof(double) * n * 3, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dgq, goal_quat, sizeof(double) * n * 4, hipMemcpyHostToDevice));
-  kmanip_launch_ik_standalone(h->dmodel, h->desc, arm, n, dq, dgp, dgq, dqo, dnf, dst, nullptr);
+  if (h->ik_serial) kmanip_launch_ik_standalone(h->dmodel, h->desc, arm, n, dq, dgp, dgq, dqo, dnf, dst, nullptr);
+  else kmanip_launch_ik_coop_standalone(h->dmodel, h->desc, arm, n, dq, dgp, dgq, dqo, dnf, dst, nullptr);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipDeviceSynchronize());
   HIPCHK(h, hipMemcpy(qpos, dq, sizeof(double) * n * nq, hipMemcpyDeviceToHost));

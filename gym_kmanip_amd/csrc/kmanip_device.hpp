@@ -109,6 +109,15 @@ __device__ __forceinline__ void sub_quat(real* res, const real* qa, const real* 
   res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
 }
 
+// cross-lane double move with a DPP control word (a DPP row is 16 lanes)
+template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+#define KM_GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 // Philox4x32-10 (Salmon et al. 2011), counter-based RNG for the cube spawn
 __device__ __host__ inline void philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
@@ -144,6 +153,11 @@ struct KDeviceState {
 
 void kmanip_launch_ik(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act,
                       hipStream_t stream);
+void kmanip_launch_ik_coop(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act,
+                           hipStream_t stream);
+void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
+                                      const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
+                                      int32_t* status, hipStream_t stream);
 void kmanip_launch_ik_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
                                  const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
                                  int32_t* status, hipStream_t stream);

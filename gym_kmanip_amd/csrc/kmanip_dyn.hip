@@ -125,13 +125,6 @@ struct Prof {
 #endif
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// cross-lane double move with a DPP control word (row = 16 lanes)
-template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
 // sum over the G lanes of a group, result identical (bitwise) in every lane.  16-lane rows use four DPP
 // steps (row_mirror, row_half_mirror, two quad_perms) instead of ds_bpermute; G = 32 adds one swizzle.
 template <int G> __device__ __forceinline__ real gsum(real v) {
