@@ -46,6 +46,7 @@ struct LModel {
   uint32_t anc[NL];
   real pos[NL][3], quat[NL][4], jaxis[NL][3], range[NL][2], floss[NL], kp[NL], ctrlrange[NL][2], forcerange[NL][2];
   real mass[NL], com[NL][3], inertia[NL][3], q_home[NL];
+  real R[NL][9];        // constant rotation of each link in its parent (from link_quat)
 };
 
 // Solver view of one pyramidal contact (group-uniform scalars).  Basis index 0 = normal, 1..2 = tangents,
@@ -151,42 +152,45 @@ template <int G> __device__ __forceinline__ int gor(int v) {
 // mj_kinematics (+ link com): serial over the tree on the group's lane 0
 template <int NL>
 __device__ __forceinline__ void fk_serial(Ws<NL>& w, const LModel<NL>& lm) {
+  // rotation-matrix propagation (all joints act about local z): one constant 3x3 product and a planar rotation
+  // of two columns per link; no quaternion products / normalisations, one sincos per hinge
   for (int i = 0; i < NL; i++) {
     const int p = lm.parent[i];
-    real pos[3], quat[4];
+    real pos[3], R1[9], mat[9];
     real lp[3] = {lm.pos[i][0], lm.pos[i][1], lm.pos[i][2]};
-    real lq[4] = {lm.quat[i][0], lm.quat[i][1], lm.quat[i][2], lm.quat[i][3]};
-    real ja[3] = {lm.jaxis[i][0], lm.jaxis[i][1], lm.jaxis[i][2]};
     if (p < 0) {
       pos[0] = lp[0]; pos[1] = lp[1]; pos[2] = lp[2];
-      quat[0] = lq[0]; quat[1] = lq[1]; quat[2] = lq[2]; quat[3] = lq[3];
+#pragma unroll
+      for (int c = 0; c < 9; c++) R1[c] = lm.R[i][c];
     } else {
-      mat_vec3(pos, w.k.xmat[p], lp);
+      const real* P = w.k.xmat[p];
+      mat_vec3(pos, P, lp);
       pos[0] += w.k.xpos[p][0]; pos[1] += w.k.xpos[p][1]; pos[2] += w.k.xpos[p][2];
-      qmul(quat, w.k.xquat[p], lq);
+#pragma unroll
+      for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) R1[3 * a + b] = P[3 * a] * lm.R[i][b] + P[3 * a + 1] * lm.R[i][3 + b] + P[3 * a + 2] * lm.R[i][6 + b];
     }
     const real q = w.qpos[i];
-    real mat[9], aw[3];
     if (lm.jtype[i] == KM_JNT_SLIDE) {
-      normalize4(quat);
-      quat2mat(mat, quat);
-      mat_vec3(aw, mat, ja);
-      pos[0] += aw[0] * q; pos[1] += aw[1] * q; pos[2] += aw[2] * q;
+#pragma unroll
+      for (int c = 0; c < 9; c++) mat[c] = R1[c];
+      pos[0] += R1[2] * q; pos[1] += R1[5] * q; pos[2] += R1[8] * q;
     } else {
-      real ql[4], qn[4];
-      axis_angle2quat(ql, ja, q);
-      qmul(qn, quat, ql);
-      quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
-      normalize4(quat);
-      quat2mat(mat, quat);
-      mat_vec3(aw, mat, ja);
+      real sn, cs;
+      sincos(q, &sn, &cs);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        mat[3 * a] = cs * R1[3 * a] + sn * R1[3 * a + 1];
+        mat[3 * a + 1] = cs * R1[3 * a + 1] - sn * R1[3 * a];
+        mat[3 * a + 2] = R1[3 * a + 2];
+      }
     }
     real cl[3] = {lm.com[i][0], lm.com[i][1], lm.com[i][2]}, cw[3];
     mat_vec3(cw, mat, cl);
 #pragma unroll
-    for (int c = 0; c < 3; c++) { w.k.xpos[i][c] = pos[c]; w.k.axis[i][c] = aw[c]; w.k.cpos[i][c] = pos[c] + cw[c]; }
-#pragma unroll
-    for (int c = 0; c < 4; c++) w.k.xquat[i][c] = quat[c];
+    for (int c = 0; c < 3; c++) { w.k.xpos[i][c] = pos[c]; w.k.cpos[i][c] = pos[c] + cw[c]; }
+    w.k.axis[i][0] = mat[2]; w.k.axis[i][1] = mat[5]; w.k.axis[i][2] = mat[8];
 #pragma unroll
     for (int c = 0; c < 9; c++) w.k.xmat[i][c] = mat[c];
   }
@@ -514,6 +518,7 @@ __device__ __forceinline__ real impedance(const real* si, real pos) {
   if (x >= 1) return dw;
   if (x <= 0) return d0;
   if (power == 1) y = x;
+  else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // MuJoCo's default power
   else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
   else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
   return d0 + y * (dw - d0);
@@ -1375,6 +1380,7 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
     lm.floss[i] = m->frictionloss[i]; lm.kp[i] = m->kp[i]; lm.mass[i] = m->mass[i]; lm.q_home[i] = m->q_home[i];
     for (int c = 0; c < 3; c++) { lm.pos[i][c] = m->link_pos[i][c]; lm.jaxis[i][c] = m->jnt_axis[i][c]; lm.com[i][c] = m->com[i][c]; lm.inertia[i][c] = m->inertia[i][c]; }
     for (int c = 0; c < 4; c++) lm.quat[i][c] = m->link_quat[i][c];
+    { real qn[4] = {m->link_quat[i][0], m->link_quat[i][1], m->link_quat[i][2], m->link_quat[i][3]}, Rm[9]; normalize4(qn); quat2mat(Rm, qn); for (int c = 0; c < 9; c++) lm.R[i][c] = Rm[c]; }
     for (int c = 0; c < 2; c++) { lm.range[i][c] = m->jnt_range[i][c]; lm.ctrlrange[i][c] = m->ctrlrange[i][c]; lm.forcerange[i][c] = m->forcerange[i][c]; }
   }
   __syncthreads();

@@ -40,6 +40,8 @@ for k in range(steps): env.step_flat(acts[k % 8])
 torch.cuda.synchronize()
 L.kmanip_dbg_prof_ik(bi, 0)
 v = np.array(list(bi), dtype=np.float64) / steps / (n * 4 / 64)
-print("IK kernel: ticks per wave per step %.0f" % v.sum())
+print("IK kernel (serial variant only; run with KMANIP_IK_SERIAL=1): ticks per wave per step %.0f" % v.sum())
+if v.sum() == 0:
+    sys.exit(0)
 for nm, x in zip(names_ik, v):
     print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / v.sum()))
