@@ -28,6 +28,26 @@ def algorithmic_bytes_per_env_step(cm):
     return 2 * state + cm.act_dim * 4 + cm.obs_dim * 8 + 8 + 1
 
 
+def measured_traffic(kernel_prefix="void k_step"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, KB units; profiles/<round>_pmc_hbm.json).  bench.py cannot run rocprofv3 on
+    itself, so the number is the last committed measurement of this kernel, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and ", 1>" in k:       # Newton instantiation
+                # FETCH_SIZE under-reports wide 16 B/lane streams by 2x on gfx950; these are 8 B/lane column reads
+                # (uncalibrated width): reported as counted, see DESIGN.md
+                return (v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024.0, os.path.basename(files[-1])
+    except Exception:  # noqa: BLE001
+        pass
+    return None, None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     try:
@@ -167,6 +187,7 @@ def main():
         bytes_per_launch = algorithmic_bytes_per_env_step(cm) * n
         dyn_avg_s = dyn_ms / max(nt, 1) * 1e-3
         achieved = bytes_per_launch / dyn_avg_s / 1e9
+        traffic, traffic_src = measured_traffic() if (args.solver == "newton" and args.env == "KManipSoloArm" and n == 4096) else (None, None)
         out = {
             "metric": "env steps/sec (whole node), KManipSoloArm @4096 envs, 1/2/4/8 MI355X",
             "value": total_env_steps / dt, "unit": "env steps/s",
@@ -178,7 +199,8 @@ def main():
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
                        "collective": "async all_gather of (reward, done) per step" if gather is not None else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_env_step": algorithmic_bytes_per_env_step(cm),
                          "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "decode_ik": ik_ms / max(nt, 1)},
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
