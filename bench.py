@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--env", default="KManipSoloArm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="also render a DxD gripper-cam depth image per env each step (BASELINE config 5)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--solver-iterations", type=int, default=100, help="solver iteration cap (MuJoCo default 100); ablation only")
     ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
@@ -153,8 +154,12 @@ def main():
         from gym_kmanip_amd.dist import RewardDoneGather
         gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist)
 
+    depth_buf = torch.empty((n, args.depth, args.depth), dtype=torch.float32, device="cuda") if args.depth else None
+
     def one_step(k):
         env.step_flat(acts[k % nbank])
+        if depth_buf is not None:
+            env.render_depth("grip_r", args.depth, args.depth, out=depth_buf)
         if gather is not None:
             gather.post(env.reward, env.done)
 
@@ -195,7 +200,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %d envs per GPU (%d total), no cameras, random U(-1,1) actions, 64-step episodes with auto-reset"
                                    % (args.env, n, world * n),
-                       "envs_per_gpu": n, "solver": args.solver, "solver_iterations": args.solver_iterations,
+                       "envs_per_gpu": n, "depth_image": ("%dx%d float32 grip_r" % (args.depth, args.depth)) if args.depth else None,
+                       "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
                        "collective": "async all_gather of (reward, done) per step" if gather is not None else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

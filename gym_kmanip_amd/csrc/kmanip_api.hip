@@ -188,6 +188,15 @@ int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward
   return 0;
 }
 
+int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream) {
+  if (!h || !depth_dev || cam < 0 || cam >= KM_MAX_ARMS || height <= 0 || width <= 0) { if (h) h->err = "kmanip_render_depth: bad arguments"; return -1; }
+  if (!h->desc.cam_present[cam]) { h->err = "kmanip_render_depth: this model has no such gripper camera"; return -1; }
+  HIPCHK(h, hipSetDevice(h->device));
+  kmanip_launch_render_depth(h->dmodel, h->st, cam, height, width, depth_dev, (hipStream_t)stream);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 int kmanip_enable_timing(KHandle h, int enable) {
   if (!h) return -1;
   HIPCHK(h, hipSetDevice(h->device));

@@ -165,3 +165,5 @@ void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDev
                         double* reward, uint8_t* done, hipStream_t stream);
 void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const uint8_t* mask,
                          int use_done_bits, double* obs, hipStream_t stream);
+void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
+                                hipStream_t stream);

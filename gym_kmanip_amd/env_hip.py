@@ -118,8 +118,20 @@ class KManipEnvHip:
         sim_time = step_idx.astype(np.float64) * CONTROL_TIMESTEP
         return terminated, self.reward, discount, self.obs_dict(), sim_time
 
-    def k_render(self, cam):
-        raise NotImplementedError("camera rendering is a 'next' row (SURVEY.md 8f rank 1), not built yet")
+    def render_depth(self, cam="grip_r", height: int = 64, width: int = 64, out=None):
+        """float32 depth image [num_envs, height, width] (metres along the optical axis) of every env's current state
+        from a gripper camera -- BASELINE.json config 5's observation (camera branch of env_sim.py:140-145)."""
+        torch = _torch()
+        ci = {"grip_r": 0, "grip_l": 1}[getattr(cam, "name", cam)]
+        if out is None:
+            out = torch.empty((self.num_envs, height, width), dtype=torch.float32, device=self.device)
+        self._check(self.L.kmanip_render_depth(self.h, ci, height, width, C.c_void_p(out.data_ptr()), self._stream()),
+                    "kmanip_render_depth")
+        return out
+
+    def k_render(self, cam, height: int = 64, width: int = 64):
+        """KManipEnvSim.k_render (env_sim.py:187-188) for the gripper cameras: depth of the surrogate scene."""
+        return self.render_depth(cam, height, width)
 
     def k_close(self):
         if getattr(self, "h", None):

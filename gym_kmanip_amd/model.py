@@ -145,6 +145,10 @@ class KModelDesc(C.Structure):
         ("max_q_vel", C.c_double), ("epsilon", C.c_double),
         ("reward_vel_penalty", C.c_double), ("reward_grip_dist", C.c_double),
         ("reward_touch_cube", C.c_double), ("reward_lift_cube", C.c_double),
+        ("cam_present", C.c_int32 * KM_MAX_ARMS), ("cam_link", C.c_int32 * KM_MAX_ARMS),
+        ("cam_target_link", C.c_int32 * KM_MAX_ARMS), ("pad3_", C.c_int32 * 2),
+        ("cam_pos", (C.c_double * 3) * KM_MAX_ARMS), ("cam_target_pos", (C.c_double * 3) * KM_MAX_ARMS),
+        ("cam_fovy", C.c_double * KM_MAX_ARMS), ("cam_znear", C.c_double), ("cam_zfar", C.c_double),
     ]
 
 
@@ -312,6 +316,22 @@ def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool
     d.epsilon = EPSILON
     d.reward_vel_penalty, d.reward_grip_dist = REWARD_VEL_PENALTY, REWARD_GRIP_DIST
     d.reward_touch_cube, d.reward_lift_cube = REWARD_TOUCH_CUBE, REWARD_LIFT_CUBE
+
+    # ---- gripper cameras (targetbody mode); znear from scene.xml:5 (<map znear="0.1"/> x extent ~1 m)
+    for ci, cname in enumerate(["grip_r", "grip_l"]):
+        cams = [c for c in asset["cameras"] if c["name"] == cname]
+        if not cams:
+            continue
+        cam = cams[0]
+        tgt = asset["targets"][cam["target"]]
+        d.cam_present[ci] = 1
+        d.cam_link[ci] = cam["link"]
+        d.cam_target_link[ci] = tgt["link"]
+        d.cam_fovy[ci] = cam["fovy"]
+        for k in range(3):
+            d.cam_pos[ci][k] = cam["pos"][k]
+            d.cam_target_pos[ci][k] = tgt["pos"][k]
+    d.cam_znear, d.cam_zfar = 0.01, 5.0
 
     obs_slices = {"q_pos": slice(0, nl), "q_vel": slice(nl, 2 * nl),
                   "cube_pos": slice(2 * nl, 2 * nl + 3), "cube_orn": slice(2 * nl + 3, 2 * nl + 7)}

@@ -133,6 +133,18 @@ typedef struct KModelDesc {
   double  max_q_vel;                            /* pi, __init__.py:31                              */
   double  epsilon;                              /* 1e-6, __init__.py:192                           */
   double  reward_vel_penalty, reward_grip_dist, reward_touch_cube, reward_lift_cube; /* :205-208  */
+
+  /* ---- gripper cameras (mode="targetbody", arm_r_body.xml:68 / arm_l_body.xml:68 / torso_body.xml:104,173);
+   * index 0 = grip_r, 1 = grip_l.  Surrogate scene for rendering = the collision primitives (cube box, table
+   * plane, finger spheres). */
+  int32_t cam_present[KM_MAX_ARMS];
+  int32_t cam_link[KM_MAX_ARMS];
+  int32_t cam_target_link[KM_MAX_ARMS];
+  int32_t pad3_[2];
+  double  cam_pos[KM_MAX_ARMS][3];          /* in cam_link's frame                                    */
+  double  cam_target_pos[KM_MAX_ARMS][3];   /* target body origin in cam_target_link's frame          */
+  double  cam_fovy[KM_MAX_ARMS];            /* degrees                                                */
+  double  cam_znear, cam_zfar;              /* metres; depth is clipped to [znear, zfar], no hit = zfar */
 } KModelDesc;
 
 typedef struct KHandle_* KHandle;
@@ -191,6 +203,12 @@ int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, int3
  * (the clipped result.x that the reference writes into ctrl). Synchronous. */
 int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos,
               const double* goal_quat, double* q_out, int32_t* nfev, int32_t* status);
+
+/* Replaces KManipEnvSim.k_render (env_sim.py:187-188) / the camera branch of get_observation
+ * (env_sim.py:140-145) for the gripper cameras, as BASELINE.json config 5 defines it: a height x width
+ * float32 DEPTH image (metres along the optical axis) of every env's current state.
+ * depth_dev: float[num_envs, height, width] device memory owned by the caller. */
+int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream);
 
 int kmanip_num_envs(KHandle h);
 const char* kmanip_last_error(KHandle h);   /* h may be NULL: error of the last failed create */

@@ -177,6 +177,11 @@ class Oracle:
         ne = nefc.value
         return dict(M=M, bias=bias, qacc_smooth=qs, qacc=qa, nefc=ne, J=J[:ne], aref=aref[:ne], R=R[:ne])
 
+    def render_depth(self, qpos, cam=0, h=64, w=64):
+        out = np.zeros((h, w), dtype=np.float32)
+        self.L.ko_render_depth(C.byref(self.desc), _p(_f64(qpos)), cam, h, w, _p(out, C.c_float))
+        return out
+
     def philox(self, ctr, key):
         c = np.ascontiguousarray(ctr, dtype=np.uint32); k = np.ascontiguousarray(key, dtype=np.uint32)
         o = np.zeros(4, dtype=np.uint32)

@@ -223,3 +223,41 @@ def test_dual_and_torso_full_size_smoke():
         assert torch.isfinite(e.obs).all() and torch.isfinite(e.reward).all()
         assert not (e.done & KM_DONE_DIVERGED).any()
         e.k_close()
+
+
+@pytest.mark.parametrize("env,cams", [("KManipSoloArm", [0]), ("KManipTorso", [0, 1])])
+def test_render_depth_parity(env, cams):
+    """Gripper-cam depth (BASELINE config 5) vs the oracle's ray caster on stepped states.  float64 maths on both
+    sides, float32 output: equal to 1e-6 m except for rays grazing a primitive's silhouette (allowed: < 0.05 % pixels)."""
+    torch = _torch()
+    cm, dev, orc = _mk(env, 6, seed=4)
+    dev.k_reset(); orc.reset()
+    rng = np.random.default_rng(3)
+    for k in range(14):
+        act = rng.uniform(-1, 1, (6, cm.act_dim)).astype(np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda()); orc.step(act)
+    qpos = orc.get_state()[0]
+    for cam in cams:
+        img = dev.render_depth(["grip_r", "grip_l"][cam], 64, 64).cpu().numpy()
+        assert img.shape == (6, 64, 64) and img.dtype == np.float32
+        for e in range(6):
+            ref = orc.render_depth(qpos[e], cam, 64, 64)
+            bad = np.abs(img[e] - ref) > 1e-6
+            assert bad.mean() < 5e-4, (cam, e, bad.sum())
+        assert (img >= cm.desc.cam_znear - 1e-6).all() and (img <= cm.desc.cam_zfar + 1e-6).all()
+        assert np.unique(np.round(img, 3)).size > 10          # a real image, not a constant
+    dev.k_close()
+
+
+def test_render_depth_config5_size():
+    """BASELINE config 5 size: 2048 envs x 64x64 depth; deterministic and finite."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    e = env_hip.make("KManipSoloArm", num_envs=2048, seed=1)
+    e.k_reset()
+    act = torch.rand((2048, 7), device="cuda") * 2 - 1
+    for k in range(3):
+        e.step_flat(act)
+    a = e.render_depth("grip_r", 64, 64); b = e.render_depth("grip_r", 64, 64)
+    assert a.shape == (2048, 64, 64) and torch.equal(a, b) and torch.isfinite(a).all()
+    e.k_close()

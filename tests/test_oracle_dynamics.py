@@ -177,3 +177,31 @@ def test_multithreaded_batch_equals_serial():
         oa = a.step(act, nthreads=1); ob = b.step(act, nthreads=4)
         for x, y in zip(oa, ob):
             assert np.array_equal(x, y)
+
+
+def test_oracle_depth_render_geometry():
+    """The targetbody camera looks at the EE site: a tiny sphere centred on the target must show up in the image
+    centre at depth |cam - target| - r; the table plane gives depth (cam_z - table_z)/cos for the downward ray."""
+    import ctypes as C
+    from gym_kmanip_amd.model import KModelDesc
+    cm = compile_model("KManipSoloArm"); o = Oracle(cm, 1)
+    nl = cm.nlink
+    qpos = np.zeros(cm.nq); qpos[:nl] = cm.spec.q_pos_home; qpos[nl:nl + 3] = [5, 5, 5]; qpos[nl + 3] = 1   # cube far away
+    xpos, xquat, sp, sm = o.fk(qpos)
+    from oracle import ik_scipy as S
+    R6 = S.quat2mat(xquat[6])
+    cam = xpos[6] + R6 @ np.array([0, 0.05, 0]); tgt = xpos[6] + R6 @ np.array([0, -0.14, -0.08])
+    assert np.abs(tgt - sp[0]).max() < 1e-12                     # camera target body == EE site body
+    # put the first finger sphere exactly on the target by editing a copy of the descriptor
+    d = KModelDesc.from_buffer_copy(cm.desc)
+    l = d.sphere_link[0]
+    Rl = S.quat2mat(xquat[l])
+    loc = Rl.T @ (tgt - xpos[l])
+    for k in range(3):
+        d.sphere_pos[0][k] = loc[k]
+    d.sphere_radius[0] = 0.004
+    cm2 = type(cm)(**{**cm.__dict__, "desc": d})
+    img = Oracle(cm2, 1).render_depth(qpos, 0, 65, 65)
+    centre = img[32, 32]
+    assert abs(centre - (np.linalg.norm(cam - tgt) - 0.004)) < 1e-4
+    assert img.min() >= d.cam_znear and img.max() <= d.cam_zfar
