@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/kmanip.h"
 
@@ -115,6 +116,26 @@ template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
   lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+// broadcast of lane K's value (K compile-time) to every lane of its G-lane group, registers only:
+// row_newbcast inside a 16-lane DPP row; for two-row groups the gfx950 v_permlane16_swap hands the even row's
+// value to the odd row (first result) or the odd row's to the even row (second result).
+template <int G, int K> __device__ __forceinline__ real gbcast(real v) {
+  static_assert(G == 8 || G == 16 || G == 32, "group = half a DPP row, one row or two rows");
+  if constexpr (G == 32) {
+    const real b = dpp_f64<0x150 + (K & 15)>(v);
+    const unsigned lo = (unsigned)__double2loint(b), hi = (unsigned)__double2hiint(b);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    constexpr int w = (K >> 4) & 1;
+    return __hiloint2double((int)rh[w], (int)rl[w]);
+  } else {
+    return dpp_f64<0x150 + K>(v);      // G == 8 callers pass K already offset into the row
+  }
+}
+// compile-time counted loop: f(std::integral_constant<int, K>) for K in [K0, N)
+template <int K0, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (K0 < N) { f(std::integral_constant<int, K0>{}); static_for<K0 + 1, N>(f); }
 }
 #define KM_GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 

@@ -25,6 +25,8 @@
 //   constraint rows  : single-dof rows + 4-vector contact bases, pyramid edges expanded on the fly
 //   PGS              : per-contact block form on the 4x4 Gram matrix (algebraically the same row order)
 #include "kmanip_device.hpp"
+#include <stdlib.h>
+#define KM_TARGET_WAVES 1024   // 256 CUs x 4 SIMDs: below this many workgroups, fewer envs per wave fills more SIMDs
 
 template <int NL> struct Dim {
   static constexpr int NV = NL + 6;
@@ -366,53 +368,44 @@ __device__ __forceinline__ void bias_project(Ws<NL>& w, const LModel<NL>& lm, in
   }
 }
 
-// Minv <- inverse of the SPD joint-space inertia held in Minv: cooperative left-looking Cholesky
-// (lane i owns row i), L^-1 by forward substitution (lane j owns column j), M^-1 = L^-T L^-1.
+// Minv <- inverse of the SPD joint-space inertia held in Minv.  Lane i takes row i into registers and the
+// group runs an in-place Gauss-Jordan sweep (no pivoting: every pivot of an SPD matrix is a positive Schur
+// complement); row k reaches the other lanes through DPP row broadcasts, so there is no LDS traffic and no
+// synchronisation inside the n^2 loop.
 template <int NL, int G>
 __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub) {
   real tr = 0;
   for (int i = 0; i < NL; i++) tr += w.Minv[i][i];
   if (sub == 0) w.Mtrace = tr;
-  if (sub < NL) for (int i = 0; i < NL; i++) w.Mm[i][sub] = w.Minv[i][sub];
-  for (int k = 0; k < NL; k++) {
-    if (sub >= k && sub < NL) {
-      real s = w.Minv[sub][k];
-      for (int t = 0; t < k; t++) s -= w.f.Lw[sub][t] * w.f.Lw[k][t];
-      w.f.Lw[sub][k] = s;
-    }
-    GSYNC();
-    real dk = w.f.Lw[k][k];
-    if (!(dk > 0)) { w.bad = 1; dk = 1; }
-    real d = sqrt(dk);
-    GSYNC();
-    if (sub == k) w.f.Lw[k][k] = d;
-    else if (sub > k && sub < NL) w.f.Lw[sub][k] = w.f.Lw[sub][k] / d;
-    GSYNC();
-  }
-  // lane j: column j of L^-1 into Minv (lower part), x_j = 1/L_jj, x_i = -(sum_{t=j}^{i-1} L_it x_t) / L_ii
+  real a[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) a[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
+  GSYNC();
   if (sub < NL) {
-    const int j = sub;
-    for (int i = 0; i < NL; i++) {
-      real x = 0;
-      if (i == j) x = 1.0 / w.f.Lw[j][j];
-      else if (i > j) {
-        real s = 0;
-        for (int t = j; t < i; t++) s += w.f.Lw[i][t] * w.Minv[t][j];
-        x = -s / w.f.Lw[i][i];
+#pragma unroll
+    for (int j = 0; j < NL; j++) w.Mm[sub][j] = a[j];
+  }
+  int bad = 0;
+  static_for<0, NL>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    real pk = gbcast<G, k>(a[k]);
+    if (!(pk > 0)) { bad = 1; pk = 1; }
+    const real d = 1.0 / pk;
+    const real aik = a[k];
+    const bool me = sub == k;
+    static_for<0, NL>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j != k) {
+        const real rkj = gbcast<G, k>(a[j]) * d;
+        a[j] = me ? rkj : a[j] - aik * rkj;
       }
-      w.Minv[i][j] = x;
-    }
-  }
-  GSYNC();
-  if (sub < NL) for (int i = 0; i < NL; i++) w.f.Lw[i][sub] = w.Minv[i][sub];
-  GSYNC();
+    });
+    a[k] = me ? d : -aik * d;
+  });
+  if (bad && sub == 0) w.bad = 1;
   if (sub < NL) {
-    const int j = sub;
-    for (int i = 0; i < NL; i++) {
-      real s = 0;
-      for (int t = (i > j ? i : j); t < NL; t++) s += w.f.Lw[t][i] * w.f.Lw[t][j];
-      w.Minv[i][j] = s;
-    }
+#pragma unroll
+    for (int j = 0; j < NL; j++) w.Minv[sub][j] = a[j];
   }
   GSYNC();
 }
@@ -872,44 +865,40 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
 // contact bases are DPP row reductions; the exact line search evaluates phi', phi'' with the rows strided
 // over the lanes.  The minimiser is unique, so parity with the oracle does not depend on iteration counts.
 
-// in-place lower Cholesky of the n x n SPD matrix A (LDS, leading dimension LD): lane i owns row i
-template <int G>
-__device__ __forceinline__ void chol_lds(real* A, int LD, int n, int sub, int* bad) {
-  for (int k = 0; k < n; k++) {
-    if (sub >= k && sub < n) {
-      real s = A[sub * LD + k];
-      for (int t = 0; t < k; t++) s -= A[sub * LD + t] * A[k * LD + t];
-      A[sub * LD + k] = s;
-    }
-    GSYNC();
-    real dk = A[k * LD + k];
-    if (!(dk > 0)) { *bad = 1; dk = 1; }
+// Cholesky of an SPD matrix held one ROW PER LANE in registers (h[j] = H[sub][j]), right-looking, in place:
+// afterwards h[j] = L[sub][j] for j <= sub (the j > sub entries are dead) and invd = 1 / L[sub][sub].
+// Column k of L reaches the other rows through DPP row broadcasts: no LDS, no synchronisation.
+template <int G, int N>
+__device__ __forceinline__ void chol_rows(real (&h)[N], real& invd, int sub, int& bad) {
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    real dk = gbcast<G, k>(h[k]);
+    if (!(dk > 0)) { bad = 1; dk = 1; }
     const real inv = 1.0 / sqrt(dk);
-    GSYNC();
-    if (sub == k) A[k * LD + k] = dk * inv;
-    else if (sub > k && sub < n) A[sub * LD + k] *= inv;
-    GSYNC();
-  }
+    const real lik = h[k] * inv;
+    h[k] = lik;
+    if (sub == k) invd = inv;
+    static_for<k + 1, N>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      h[j] -= lik * gbcast<G, j>(lik);
+    });
+  });
 }
-// x <- (L L^T)^-1 b with b distributed (lane i holds b_i); vec = n doubles of LDS scratch
-template <int G>
-__device__ __forceinline__ real chol_solve_lds(const real* L, int LD, int n, int sub, real b, real* vec) {
-  for (int k = 0; k < n; k++) {
-    if (sub == k) vec[k] = b / L[k * LD + k];
-    GSYNC();
-    if (sub > k && sub < n) b -= L[sub * LD + k] * vec[k];
-  }
-  GSYNC();
-  real z = sub < n ? vec[sub] : 0.0;
-  GSYNC();
-  for (int k = n - 1; k >= 0; k--) {
-    if (sub == k) vec[k] = z / L[k * LD + k];
-    GSYNC();
-    if (sub < k) z -= L[k * LD + sub] * vec[k];
-  }
-  GSYNC();
-  real x = sub < n ? vec[sub] : 0.0;
-  GSYNC();
+// x = (L L^T)^-1 b, b distributed one component per lane.  Forward substitution is column-oriented (z_k broadcast,
+// rows below updated); the transposed solve uses the dot form (lane i contributes L[i][k] x_i, group sum).
+template <int G, int N>
+__device__ __forceinline__ real chol_solve_rows(const real (&h)[N], real invd, int sub, real b) {
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const real zk = gbcast<G, k>(b * invd);
+    b = sub > k ? b - h[k] * zk : (sub == k ? zk : b);
+  });
+  real x = 0;
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = N - 1 - decltype(kc)::value;
+    const real s = gsum<G>(sub > k ? h[k] * x : 0.0);
+    if (sub == k) x = (b - s) * invd;
+  });
   return x;
 }
 
@@ -1116,19 +1105,21 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   if (sqrt(gsum<G>(grad * grad)) * scale < tol) return a;
   const int ns = w.ns;
   for (int iter = 0; iter < maxit; iter++) {
-    // ---- Hessian column `sub`: M, plus D on the diagonal for quadratic single-dof rows, plus J^T W J per contact
-    if (sub < NV) {
-      for (int i = 0; i < NV; i++) w.h.Hm[i][sub] = (i < NL && sub < NL) ? w.Mm[i][sub] : 0.0;
+    // ---- Hessian row `sub` in registers: M, plus D on the diagonal for quadratic single-dof rows, plus J^T W J per contact
+    real h[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) h[j] = (j < NL && sub < NL) ? w.Mm[sub][j] : 0.0;
+    {
       real dg = sub < NL ? 0.0 : mdiag;
       if (sub < NL) { for (int q = 0; q < ns; q++) if (w.s_dof[q] == sub && w.s_quad[q]) dg += 1.0 / w.s_R[q]; }
       else if (my_quad) dg += 1.0 / my_R;
-      w.h.Hm[sub][sub] += dg;
-    }
-    GSYNC();
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
+      for (int j = 0; j < NV; j++) h[j] += (j == sub) ? dg : 0.0;
+    }
+    static_for<0, NC>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
       __builtin_amdgcn_sched_barrier(0);
-    if ((act >> c) & 1u) {
+      if ((act >> c) & 1u) {
         const ConRec& rc = w.rec[c];
         const uint32_t qm = (uint32_t)rc.f[0];
         const real Dn = 1.0 / rc.R;
@@ -1147,22 +1138,23 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
 #pragma unroll
           for (int l = 0; l < 4; l++) t[k] += (k <= l ? W[k][l] : W[l][k]) * cr.jb[c][l];
         }
-        // stage the basis rows in the four vector rows that are free here (w.stage aliases the live records)
-        if (sub < NV) { w.bias[sub] = cr.jb[c][0]; w.as[sub] = cr.jb[c][1]; w.tmp[sub] = cr.jb[c][2]; w.tmp3[sub] = cr.jb[c][3]; }
-        GSYNC();
-        const int i0 = slot_kind<NL>(c) == 0 ? NL : 0;          // table-cube slots touch only the cube block
-        if (sub >= i0 && sub < NV) {
-          for (int i = i0; i < NV; i++)
-            w.h.Hm[i][sub] += w.bias[i] * t[0] + w.as[i] * t[1] + w.tmp[i] * t[2] + w.tmp3[i] * t[3];
-        }
-        GSYNC();
+        // H[sub][j] += sum_k t_k(sub) * J_k[j]: lane j's basis entries arrive by row broadcast
+        constexpr int j0 = slot_kind<NL>(c) == 0 ? NL : 0;        // table-cube slots touch only the cube block
+        static_for<j0, NV>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          h[j] += t[0] * gbcast<G, j>(cr.jb[c][0]) + t[1] * gbcast<G, j>(cr.jb[c][1]) + t[2] * gbcast<G, j>(cr.jb[c][2]) +
+                  t[3] * gbcast<G, j>(cr.jb[c][3]);
+        });
       }
-    }
+    });
     pf.ph(7);
     // ---- p = -H^-1 grad
-    chol_lds<G>(&w.h.Hm[0][0], NV, NV, sub, &w.bad);
+    real invd = 1;
+    int hbad = 0;
+    chol_rows<G, NV>(h, invd, sub, hbad);
+    if (hbad && sub == 0) w.bad = 1;
     pf.ph(8);
-    const real p = chol_solve_lds<G>(&w.h.Hm[0][0], NV, NV, sub, -grad, w.tmp3);
+    const real p = chol_solve_rows<G, NV>(h, invd, sub, -grad);
     pf.ph(9);
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
     if (sub < NV) w.tmp[sub] = p;
@@ -1264,8 +1256,6 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   GSYNC();
   mass_matrix<NL, G>(w, lm, sub);
   bias_project<NL, G>(w, lm, sub);
-  GSYNC();
-  mass_symmetrize<NL, G>(w, sub);
   GSYNC();
   pf.ph(3);
   invert_mass<NL, G>(w, sub);
@@ -1387,17 +1377,19 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NL, int G, int SOLVER>
+// EPB = envs per single-wave workgroup (<= 64 / G).  Fewer envs per wave = more waves per SIMD: the kernel is
+// bound by LDS/dependent-issue latency, so waves of different envs hide each other's waits.
+template <int NL, int G, int SOLVER, int EPB>
 __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm, KDeviceState st, double* __restrict__ obs,
                                              double* __restrict__ reward, uint8_t* __restrict__ done) {
-  constexpr int EPB = 64 / G, NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
+  constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
   __shared__ Ws<NL> ws[EPB];
   __shared__ LModel<NL> lm;
   stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const int env = blockIdx.x * EPB + grp;
-  if (env >= st.num_envs) return;     // whole group exits together
+  if (grp >= EPB || env >= st.num_envs) return;     // whole group exits together
   Ws<NL>& w = ws[grp];
   CReg<Dim<NL>::NC, Dim<NL>::NCF> cr;
   real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
@@ -1474,17 +1466,17 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
 }
 
 // KManipEnvSim.k_reset for the envs selected by mask (NULL = all)
-template <int NL, int G, int SOLVER>
+template <int NL, int G, int SOLVER, int EPB>
 __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ dm, KDeviceState st,
                                               const uint8_t* __restrict__ mask, double* __restrict__ obs) {
-  constexpr int EPB = 64 / G, NV = Dim<NL>::NV;
+  constexpr int NV = Dim<NL>::NV;
   __shared__ Ws<NL> ws[EPB];
   __shared__ LModel<NL> lm;
   stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const int env = blockIdx.x * EPB + grp;
-  if (env >= st.num_envs) return;
+  if (grp >= EPB || env >= st.num_envs) return;
   if (mask && !mask[env]) return;
   Ws<NL>& w = ws[grp];
   CReg<Dim<NL>::NC, Dim<NL>::NCF> cr;
@@ -1500,15 +1492,36 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   store_state<NL, G>(w, st, env, sub);
 }
 
+// envs per workgroup: as many waves as the chip has SIMD slots for, but no more lanes idle than needed.
+static int pick_epb(int num_envs, int max_epb) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("KMANIP_EPB"); forced = e ? atoi(e) : 0; }
+  if (forced > 0) return forced < max_epb ? forced : max_epb;
+  int epb = max_epb;
+  while (epb > 1 && (num_envs + epb - 1) / epb < KM_TARGET_WAVES) epb >>= 1;
+  return epb;
+}
+template <int NL, int G, int SOLVER, int EPB>
+static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
+  hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, obs, reward, done);
+}
+template <int NL, int G, int SOLVER, int EPB>
+static void launch_reset_e(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
+  hipLaunchKernelGGL((k_reset<NL, G, SOLVER, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, mask, obs);
+}
 template <int NL, int G, int SOLVER>
 static void launch_step_t(const KDeviceModel* dm, const KDeviceState& st, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
-  constexpr int EPB = 64 / G;
-  hipLaunchKernelGGL((k_step<NL, G, SOLVER>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, obs, reward, done);
+  const int epb = pick_epb(st.num_envs, 64 / G);
+  if constexpr (64 / G >= 4) if (epb == 4) return launch_step_e<NL, G, SOLVER, 4>(dm, st, obs, reward, done, stream);
+  if (epb == 2) return launch_step_e<NL, G, SOLVER, 2>(dm, st, obs, reward, done, stream);
+  launch_step_e<NL, G, SOLVER, 1>(dm, st, obs, reward, done, stream);
 }
 template <int NL, int G, int SOLVER>
 static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
-  constexpr int EPB = 64 / G;
-  hipLaunchKernelGGL((k_reset<NL, G, SOLVER>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, mask, obs);
+  const int epb = pick_epb(st.num_envs, 64 / G);
+  if constexpr (64 / G >= 4) if (epb == 4) return launch_reset_e<NL, G, SOLVER, 4>(dm, st, mask, obs, stream);
+  if (epb == 2) return launch_reset_e<NL, G, SOLVER, 2>(dm, st, mask, obs, stream);
+  launch_reset_e<NL, G, SOLVER, 1>(dm, st, mask, obs, stream);
 }
 void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs, double* reward,
                         uint8_t* done, hipStream_t stream) {

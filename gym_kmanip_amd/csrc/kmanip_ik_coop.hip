@@ -16,6 +16,7 @@
 // Nothing of the TRF state is a 7-vector in one lane any more, which is what pushed the one-lane-per-problem
 // kernel into 0.5-1.5 KB of scratch per lane.
 #include "kmanip_device.hpp"
+#include <stdlib.h>
 
 #define GI 8            // lanes per problem
 #define PPW (64 / GI)   // problems per wave / workgroup
@@ -501,15 +502,17 @@ __device__ __forceinline__ real f32r_c(real x) { return (real)(float)x; }
 
 // ---------------------------------------------------------------------------------------------
 // before_step for every env: decode + IK + ctrl; 8 lanes per (env, arm) problem
-template <int N>
+// PPB = problems per single-wave workgroup (<= PPW): the kernel needs > 256 registers, i.e. one wave per SIMD, so a
+// batch with fewer than 1024 full waves is spread over more, emptier waves (less lock-step divergence too).
+template <int N, int PPB>
 __global__ __launch_bounds__(64) void k_before_step_coop(const KDeviceModel* __restrict__ dm, KDeviceState st,
                                                          const float* __restrict__ act, int nprob) {
-  __shared__ CoopLds<N> lds[PPW];
+  __shared__ CoopLds<N> lds[PPB];
   const KModelDesc* m = &dm->d;
   const int NE = st.num_envs;
   const int slot = threadIdx.x / GI, c = threadIdx.x % GI;
-  const int prob = blockIdx.x * PPW + slot;
-  if (prob >= nprob) return;                     // whole group exits together
+  const int prob = blockIdx.x * PPB + slot;
+  if (slot >= PPB || prob >= nprob) return;      // whole group exits together
   const int env = prob % NE, arm = prob / NE;
   if (!m->arm_present[arm]) return;
   const float* a = act + (size_t)env * m->act_dim;
@@ -585,9 +588,15 @@ void kmanip_launch_ik_coop(const KDeviceModel* dm, const KModelDesc& hd, const K
   int narm_slots = (hd.arm_present[1]) ? 2 : 1;
   int nprob = st.num_envs * narm_slots;
   int nik = hd.arm_nq[0] ? hd.arm_nq[0] : hd.arm_nq[1];
-  dim3 grid((nprob + PPW - 1) / PPW);
-  if (nik == 7) hipLaunchKernelGGL(k_before_step_coop<7>, grid, dim3(64), 0, stream, dm, st, act, nprob);
-  else hipLaunchKernelGGL(k_before_step_coop<6>, grid, dim3(64), 0, stream, dm, st, act, nprob);
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("KMANIP_IK_PPB"); forced = e ? atoi(e) : 0; }
+  int ppb = PPW;
+  if (forced > 0) ppb = forced;
+  else while (ppb > 2 && (nprob + ppb - 1) / ppb < 1024) ppb >>= 1;   // 1024 = SIMDs on the chip
+#define KM_IK_LAUNCH(NN, PP) hipLaunchKernelGGL((k_before_step_coop<NN, PP>), dim3((nprob + PP - 1) / PP), dim3(64), 0, stream, dm, st, act, nprob)
+  if (nik == 7) { if (ppb >= 8) KM_IK_LAUNCH(7, 8); else if (ppb >= 4) KM_IK_LAUNCH(7, 4); else KM_IK_LAUNCH(7, 2); }
+  else { if (ppb >= 8) KM_IK_LAUNCH(6, 8); else if (ppb >= 4) KM_IK_LAUNCH(6, 4); else KM_IK_LAUNCH(6, 2); }
+#undef KM_IK_LAUNCH
 }
 
 // standalone batched ik() for parity tests: qpos env-major [n][nq] (mutated like the reference)
