@@ -19,9 +19,10 @@
 // s_barrier: all its lanes sit in one wave.
 //
 // Formulations deliberately differ from the oracle's (so parity is a cross-check, not a re-run):
-//   mass matrix      : sum over bodies of COM-Jacobian outer products (oracle: composite-body CRBA)
+//   mass matrix      : composite inertias about the world origin, one column per lane (oracle: link-frame CRBA)
 //   bias forces      : per-body bias wrenches projected with J^T   (oracle: RNE backward recursion)
-//   M^-1             : explicit inverse via cooperative Cholesky    (oracle: factor + solves)
+//   M^-1             : explicit inverse, Gauss-Jordan on register rows (oracle: Cholesky factor + solves)
+//   Newton           : Hessian rows / Cholesky / solves in registers, DPP row broadcasts (oracle: dense LDS-free C)
 //   constraint rows  : single-dof rows + 4-vector contact bases, pyramid edges expanded on the fly
 //   PGS              : per-contact block form on the 4x4 Gram matrix (algebraically the same row order)
 #include "kmanip_device.hpp"
@@ -96,13 +97,21 @@ struct Ws {
 
 // this lane's column of every contact basis: J (jb) and M^-1 J^T (bb); compile-time indexed only
 // (bb only for the slots that involve arm dofs: for table-cube slots M^-1 is diagonal, bb = jb * invm)
-template <int NC, int NCF> struct CReg { real jb[NC][4]; real bb[NCF][4]; };
+// Newton path only: mrow = this lane's row of the arm inertia M; the lane's OWN single-dof constraint rows
+// (dof `sub`: friction loss and, when violated, its joint limit) -- no row tables in LDS.
+template <int NL> struct CReg {
+  real jb[Dim<NL>::NC][4];
+  real bb[Dim<NL>::NCF][4];
+  real mrow[NL];
+  real fl, Rf, areff;        // friction-loss row x = a - areff          (fl = 0: no row)
+  real sg, Rl, arefl;        // limit row         x = sg * a - arefl     (sg = 0: no row)
+};
 
 // ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
 // their own and never feed an output; the shipped library compiles every call away.
 #define KM_NPH 16
 #ifdef KM_PROFILE
-__device__ unsigned long long g_prof[KM_NPH];
+__device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
 struct Prof {
   unsigned long long t0, acc[KM_NPH];
   __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
@@ -114,11 +123,13 @@ struct Prof {
   }
   __device__ __forceinline__ void flush() { if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) atomicAdd(&g_prof[i], acc[i]); }
 };
+#if KM_VAR_NL == 10 && KM_VAR_SOLVER == 1
 extern "C" int kmanip_dbg_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * KM_NPH) != hipSuccess) return -1;
   if (reset) { unsigned long long z[KM_NPH] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1; }
   return 0;
 }
+#endif
 #else
 struct Prof {
   __device__ __forceinline__ void start() {}
@@ -373,7 +384,7 @@ __device__ __forceinline__ void bias_project(Ws<NL>& w, const LModel<NL>& lm, in
 // complement); row k reaches the other lanes through DPP row broadcasts, so there is no LDS traffic and no
 // synchronisation inside the n^2 loop.
 template <int NL, int G>
-__device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub) {
+__device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
   real tr = 0;
   for (int i = 0; i < NL; i++) tr += w.Minv[i][i];
   if (sub == 0) w.Mtrace = tr;
@@ -381,6 +392,8 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub) {
 #pragma unroll
   for (int j = 0; j < NL; j++) a[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
   GSYNC();
+#pragma unroll
+  for (int j = 0; j < NL; j++) cr.mrow[j] = a[j];
   if (sub < NL) {
 #pragma unroll
     for (int j = 0; j < NL; j++) w.Mm[sub][j] = a[j];
@@ -571,7 +584,7 @@ __device__ __forceinline__ void scalar_rows_serial(Ws<NL>& w, const LModel<NL>& 
 // Gram / edge tables (group-uniform) in LDS.
 template <int NL, int G>
 __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
-                                                  CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+                                                  CReg<NL>& cr, real invm) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   for (int r = sub; r < w.ns; r += G) {
     const int j = w.s_dof[r];
@@ -702,7 +715,7 @@ __device__ __forceinline__ real pgs_row(real Ja, real aref, real R, real den, re
 // lane's component of qacc (lane `sub` owns dof `sub`).
 template <int NL, int G>
 __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
-                                            CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+                                            CReg<NL>& cr, real invm) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   // ---- actuation (position servos on actuator_length = q at mj_step1 time) and smooth acceleration
   if (sub < NV) {
@@ -924,19 +937,34 @@ __device__ __forceinline__ real row_eval(int type, real x, real R, real fl, real
 }
 
 // Constraint assembly for Newton: like build_constraints but no B = M^-1 J^T / Gram tables -- only the
-// first-edge diagonal (for MuJoCo's pyramidal regulariser) and the velocity projections (for aref).
+// first-edge diagonal (for MuJoCo's pyramidal regulariser) and the velocity projections (for aref).  The
+// single-dof rows (friction loss, joint limits) of dof `sub` are built into this lane's registers: the primal
+// cost is a sum over rows, so mj_makeConstraint's row order does not matter here (it does for PGS).
 template <int NL, int G>
 __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
-                                                         CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm) {
+                                                         CReg<NL>& cr, real invm) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
-  for (int r = sub; r < w.ns; r += G) {
-    const int j = w.s_dof[r];
-    real Ad = w.Minv[j][j];
-    real pos = w.s_pos[r];
-    real imp = impedance(m->con_def_solimp, pos), kk, bb;
+  cr.fl = 0; cr.Rf = 1; cr.areff = 0; cr.sg = 0; cr.Rl = 1; cr.arefl = 0;
+  if (sub < NV) {
+    const real Ad = sub < NL ? w.Minv[sub][sub] : invm;
+    const real qv = w.qvel[sub];
+    real kk, bb;
     get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
-    w.s_R[r] = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
-    w.s_aref[r] = -bb * (w.s_sign[r] * w.qvel[j]) - kk * imp * pos;
+    const real fl = sub < NL ? lm.floss[sub] : m->cube_frictionloss;
+    if (fl > 0) {
+      const real imp = impedance(m->con_def_solimp, 0.0);
+      cr.fl = fl; cr.Rf = fmax(MJ_MINVAL, (1 - imp) / imp * Ad); cr.areff = -bb * qv;
+    }
+    if (sub < NL) {
+      const real dl = w.qpos[sub] - lm.range[sub][0], du = lm.range[sub][1] - w.qpos[sub];
+      const real pos = dl < 0 ? dl : du;
+      if (pos < 0) {                                       // (lower and upper cannot both be violated: range lo < hi)
+        const real imp = impedance(m->con_def_solimp, pos);
+        cr.sg = dl < 0 ? 1.0 : -1.0;
+        cr.Rl = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+        cr.arefl = -bb * (cr.sg * qv) - kk * imp * pos;
+      }
+    }
   }
   const uint32_t act = w.cact;
 #pragma unroll
@@ -1001,66 +1029,72 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   GSYNC();
 }
 
-// cost, forces, gradient at a (lane component); also stages a in w.tmp2 and leaves M(a - a_s) in Mr
+// M x for a vector distributed one component per lane: arm block from the lane's register row of M
+// (components arrive by DPP row broadcast), cube block diagonal
 template <int NL, int G>
-__device__ __forceinline__ real newton_eval(Ws<NL>& w, const KModelDesc* m, int sub, const CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr,
-                                            real a, real a_s, real mdiag, bool my_row, real my_aref, real my_R, real my_fl,
-                                            real& Mr, real& grad, real& my_f, int& my_quad) {
-  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+__device__ __forceinline__ real mass_mul(const CReg<NL>& cr, int sub, real mdiag, real x) {
+  real s = 0;
+  static_for<0, NL>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    s += cr.mrow[j] * gbcast<G, j>(x);
+  });
+  return sub < NL ? s : mdiag * x;
+}
+
+// Newton state at the current point: a, Mr = M (a - a_s) (lane components) and, per active contact, the basis
+// projections u_k = J_k a in the record's inv[] slots (group-uniform, LDS).  PROJECT = recompute them from a
+// (start points); otherwise they were advanced incrementally (u += alpha * J p), as MuJoCo does.
+// Returns the cost; sets the lane's gradient component, the quadratic-zone flags of its own rows and the
+// active-edge mask of every contact (computed redundantly by all lanes, so no exchange).
+template <int NL, int G, bool PROJECT>
+__device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
+                                            real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC]) {
+  constexpr int NC = Dim<NL>::NC;
   const uint32_t act = w.cact;
-  const real r = a - a_s;
-  if (sub < NV) { w.tmp[sub] = r; w.tmp2[sub] = a; }
-  GSYNC();
-  Mr = 0;
-  if (sub < NL) { for (int j = 0; j < NL; j++) Mr += w.Mm[sub][j] * w.tmp[j]; }
-  else if (sub < NV) Mr = mdiag * r;
-  real cost = 0.5 * r * Mr;                 // per-lane share; summed at the end
+  real cost = 0.5 * (a - a_s) * Mr;        // per-lane share; summed at the end
   grad = Mr;
-  // arm single-dof rows, strided over lanes
-  const int ns = w.ns;
-  for (int q = sub; q < ns; q += G) {
-    const int j = w.s_dof[q];
-    real f; int quad;
-    cost += row_eval(w.s_type[q], w.s_sign[q] * w.tmp2[j] - w.s_aref[q], w.s_R[q], w.s_floss[q], f, quad);
-    w.s_f[q] = f; w.s_quad[q] = quad;
-  }
-  // the cube friction-loss row owned by this lane
-  my_f = 0; my_quad = 0;
-  if (my_row) { cost += row_eval(0, a - my_aref, my_R, my_fl, my_f, my_quad); grad -= my_f; }
-  // contacts: basis projections, edge forces (identical on every lane; lane 0 books the cost)
-#pragma unroll
-  for (int c = 0; c < NC; c++) {
+  qf = 0; ql = 0;
+  if (cr.fl > 0) { real f; cost += row_eval(0, a - cr.areff, cr.Rf, cr.fl, f, qf); grad -= f; }
+  if (cr.sg != 0) { real f; cost += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, 0.0, f, ql); grad -= cr.sg * f; }
+  static_for<0, NC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    qm[c] = 0;
     if ((act >> c) & 1u) {
       const ConRec& rc = w.rec[c];
       real u[4], F[4] = {0, 0, 0, 0};
+      if constexpr (PROJECT) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
+        for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
+        if (sub == 0) { w.rec[c].inv[0] = u[0]; w.rec[c].inv[1] = u[1]; w.rec[c].inv[2] = u[2]; w.rec[c].inv[3] = u[3]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) u[k] = rc.inv[k];
+      }
       const real R = rc.R;
-      uint32_t qm = 0;
+      uint32_t q = 0;
+      real ce = 0;
 #pragma unroll
       for (int e = 0; e < 6; e++) {
         if (slot_kind<NL>(c) == 2 && e >= 4) continue;
         const int k = e / 2 + 1;
         const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
         real f; int quad;
-        const real ce = row_eval(1, u[0] + sm * u[k] - rc.aref[e], R, 0.0, f, quad);
-        if (sub == 0) cost += ce;
+        ce += row_eval(1, u[0] + sm * u[k] - rc.aref[e], R, 0.0, f, quad);
         F[0] += f; F[k] += sm * f;
-        qm |= (uint32_t)quad << e;
+        q |= (uint32_t)quad << e;
       }
-      if (sub == 0) w.rec[c].f[0] = (real)qm;   // active-edge mask (a small integer stored in a double)
+      if (sub == 0) cost += ce;             // identical on every lane; lane 0 books it
+      qm[c] = q;
 #pragma unroll
       for (int k = 0; k < 4; k++) grad -= cr.jb[c][k] * F[k];
     }
-  }
-  GSYNC();
-  if (sub < NL) { for (int q = 0; q < ns; q++) if (w.s_dof[q] == sub) grad -= w.s_sign[q] * w.s_f[q]; }
+  });
   return gsum<G>(cost);
 }
 
 template <int NL, int G>
 __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
-                                             CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
+                                             CReg<NL>& cr, real invm, Prof& pf) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   // ---- actuation and smooth acceleration (as in the PGS path)
   if (sub < NV) {
@@ -1077,58 +1111,44 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   real a_s = 0;
   if (sub < NL) { for (int j = 0; j < NL; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
   else if (sub < NV) a_s = w.tmp[sub] * invm;
-  GSYNC();
   const uint32_t act = w.cact;
   const real warm = sub < NV ? w.warm[sub] : 0.0;
   const real mdiag = (sub >= NL && sub < NV) ? 1.0 / invm : 0.0;
-  // the cube friction-loss row owned by this lane (registers only)
-  const bool my_row = sub >= NL && sub < NV && m->cube_frictionloss > 0;
-  real my_aref = 0, my_R = 1;
-  const real my_fl = m->cube_frictionloss;
-  if (my_row) {
-    real imp = impedance(m->con_def_solimp, 0.0), kk, bb;
-    get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
-    my_R = fmax(MJ_MINVAL, (1 - imp) / imp * invm);
-    my_aref = -bb * w.qvel[sub];
-  }
-  real Mr, grad, my_f; int my_quad;
-  // ---- warm start: the better of qacc_warmstart and qacc_smooth (primal costs)
-  const real cw = newton_eval<NL, G>(w, m, sub, cr, warm, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad);
-  const real cs = newton_eval<NL, G>(w, m, sub, cr, a_s, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad);
-  real a = a_s;
-  real cost = cs;
-  if (cw < cs) { a = warm; cost = newton_eval<NL, G>(w, m, sub, cr, a, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad); }
+  real grad; int qf, ql; uint32_t qm[NC];
+  // ---- warm start: the better of qacc_warmstart and qacc_smooth (primal costs).  qacc_smooth first, so that in
+  // the usual case (the warm start wins) the state left behind is already the starting point.
+  const real cs = newton_eval<NL, G, true>(w, sub, cr, a_s, a_s, 0.0, grad, qf, ql, qm);
+  real a = warm;
+  real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
+  real cost = newton_eval<NL, G, true>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm);
+  if (!(cost < cs)) { a = a_s; Mr = 0; cost = newton_eval<NL, G, true>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm); }
   const real scale = 1.0 / (w.Mtrace + 3 * m->cube_mass + m->cube_inertia[0] + m->cube_inertia[1] + m->cube_inertia[2]);
   const real tol = m->solver_tolerance;
   const int maxit = m->solver_iterations;
   pf.ph(6);
   if (sqrt(gsum<G>(grad * grad)) * scale < tol) return a;
-  const int ns = w.ns;
   for (int iter = 0; iter < maxit; iter++) {
-    // ---- Hessian row `sub` in registers: M, plus D on the diagonal for quadratic single-dof rows, plus J^T W J per contact
+    // ---- Hessian row `sub` in registers: M, plus D on the diagonal for the lane's own quadratic rows, plus J^T W J per contact
     real h[NV];
-#pragma unroll
-    for (int j = 0; j < NV; j++) h[j] = (j < NL && sub < NL) ? w.Mm[sub][j] : 0.0;
     {
       real dg = sub < NL ? 0.0 : mdiag;
-      if (sub < NL) { for (int q = 0; q < ns; q++) if (w.s_dof[q] == sub && w.s_quad[q]) dg += 1.0 / w.s_R[q]; }
-      else if (my_quad) dg += 1.0 / my_R;
+      if (qf) dg += 1.0 / cr.Rf;
+      if (ql) dg += 1.0 / cr.Rl;
 #pragma unroll
-      for (int j = 0; j < NV; j++) h[j] += (j == sub) ? dg : 0.0;
+      for (int j = 0; j < NV; j++) h[j] = (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0);
     }
     static_for<0, NC>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       __builtin_amdgcn_sched_barrier(0);
       if ((act >> c) & 1u) {
         const ConRec& rc = w.rec[c];
-        const uint32_t qm = (uint32_t)rc.f[0];
         const real Dn = 1.0 / rc.R;
         real W[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
         for (int e = 0; e < 6; e++) {
           const int k = e / 2 + 1;
           const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
-          const real d = ((qm >> e) & 1u) ? Dn : 0.0;
+          const real d = ((qm[c] >> e) & 1u) ? Dn : 0.0;
           W[0][0] += d; W[0][k] += d * sm; W[k][k] += d * sm * sm;
         }
         real t[4];
@@ -1157,29 +1177,22 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     const real p = chol_solve_rows<G, NV>(h, invd, sub, -grad);
     pf.ph(9);
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
-    if (sub < NV) w.tmp[sub] = p;
-    GSYNC();
-    real Mp = 0;
-    if (sub < NL) { for (int j = 0; j < NL; j++) Mp += w.Mm[sub][j] * w.tmp[j]; }
-    else if (sub < NV) Mp = mdiag * p;
+    const real Mp = mass_mul<NL, G>(cr, sub, mdiag, p);
     const real gp = gsum<G>(p * Mr), pMp = gsum<G>(p * Mp);
-    // per-contact projections of a and p, parked in the (otherwise unused) inv/den slots of the records
+    // per-contact projections of p, parked next to those of a in the records (den[] slots)
+    static_for<0, NC>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if ((act >> c) & 1u) {
+        real y[4];
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-      __builtin_amdgcn_sched_barrier(0);
-    if ((act >> c) & 1u) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const real x = gsum<G>(cr.jb[c][k] * a), y = gsum<G>(cr.jb[c][k] * p);
-          if (sub == 0) { w.rec[c].inv[k] = x; w.rec[c].den[k] = y; }
-        }
+        for (int k = 0; k < 4; k++) y[k] = gsum<G>(cr.jb[c][k] * p);
+        if (sub == 0) { w.rec[c].den[0] = y[0]; w.rec[c].den[1] = y[1]; w.rec[c].den[2] = y[2]; w.rec[c].den[3] = y[3]; }
       }
-    }
+    });
     GSYNC();
-    // this lane's share of the rows, hoisted into registers: x(alpha) = lx + alpha * ly per row
-    constexpr int NEQ = (6 * NC + G - 1) / G, NAQ = (Dim<NL>::NS + G - 1) / G;
+    // this lane's share of the contact edges, hoisted into registers: x(alpha) = lx + alpha * ly per row
+    constexpr int NEQ = (6 * NC + G - 1) / G;
     real lx[NEQ], ly[NEQ], lR[NEQ];          // contact edges t = sub + G*q  (lR = 0: no row)
-    real ax[NAQ], ay[NAQ], aR[NAQ], afl[NAQ]; int aty[NAQ];   // arm single-dof rows r = sub + G*q (aR = 0: no row)
 #pragma unroll
     for (int q = 0; q < NEQ; q++) {
       const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
@@ -1193,23 +1206,13 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
         lR[q] = rc.R;
       }
     }
-#pragma unroll
-    for (int q = 0; q < NAQ; q++) {
-      const int r = sub + G * q;
-      ax[q] = 0; ay[q] = 0; aR[q] = 0; afl[q] = 0; aty[q] = 1;
-      if (r < ns) {
-        const int j = w.s_dof[r];
-        const real sg = w.s_sign[r];
-        ax[q] = sg * w.tmp2[j] - w.s_aref[r]; ay[q] = sg * w.tmp[j]; aR[q] = w.s_R[r]; afl[q] = w.s_floss[r]; aty[q] = w.s_type[r];
-      }
-    }
+    const real xf = a - cr.areff, xl = cr.sg * a - cr.arefl, yl = cr.sg * p;
     pf.ph(10);
     real alpha = 0, lo = 0, hi = INFINITY, d1 = 0, d2 = 0, d10 = 0;
     for (int it = 0; it <= 50; it++) {
       real e1 = 0, e2 = 0;
-#pragma unroll
-      for (int q = 0; q < NAQ; q++) if (aR[q] != 0) row_ls(aty[q], ax[q] + alpha * ay[q], ay[q], aR[q], afl[q], e1, e2);
-      if (my_row) row_ls(0, (a - my_aref) + alpha * p, p, my_R, my_fl, e1, e2);
+      if (cr.fl > 0) row_ls(0, xf + alpha * p, p, cr.Rf, cr.fl, e1, e2);
+      if (cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, 0.0, e1, e2);
 #pragma unroll
       for (int q = 0; q < NEQ; q++) if (lR[q] != 0) row_ls(1, lx[q] + alpha * ly[q], ly[q], lR[q], 0.0, e1, e2);
       d1 = gp + alpha * pMp + gsum<G>(e1);
@@ -1226,8 +1229,17 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
       alpha = an;
     }
     pf.ph(11);
+    // ---- advance the point and everything linear in it
     a += alpha * p;
-    const real cost_new = newton_eval<NL, G>(w, m, sub, cr, a, a_s, mdiag, my_row, my_aref, my_R, my_fl, Mr, grad, my_f, my_quad);
+    Mr += alpha * Mp;
+    if (sub < 4) {
+      static_for<0, NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if ((act >> c) & 1u) w.rec[c].inv[sub] += alpha * w.rec[c].den[sub];
+      });
+    }
+    GSYNC();
+    const real cost_new = newton_eval<NL, G, false>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm);
     const real improvement = scale * (cost - cost_new), gradient = scale * sqrt(gsum<G>(grad * grad));
     cost = cost_new;
     pf.ph(12);
@@ -1239,14 +1251,14 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
 // everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
-                                               CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
+                                               CReg<NL>& cr, real invm, Prof& pf) {
   if (sub == 0) {
     fk_serial<NL>(w, lm);
     pf.ph(0);
     bias_bodies_serial<NL>(w, lm, m);
     pf.ph(1);
     collide_serial<NL>(w, m);
-    scalar_rows_serial<NL>(w, lm);
+    if (SOLVER != KM_SOLVER_NEWTON) scalar_rows_serial<NL>(w, lm);
   }
   GSYNC();
   pf.ph(2);
@@ -1258,7 +1270,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   bias_project<NL, G>(w, lm, sub);
   GSYNC();
   pf.ph(3);
-  invert_mass<NL, G>(w, sub);
+  invert_mass<NL, G>(w, sub, cr);
   pf.ph(4);
   if (SOLVER == KM_SOLVER_NEWTON) build_constraints_newton<NL, G>(w, lm, m, sub, cr, invm);
   else build_constraints<NL, G>(w, lm, m, sub, cr, invm);
@@ -1266,7 +1278,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
 }
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ real solve(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
-                                      CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
+                                      CReg<NL>& cr, real invm, Prof& pf) {
   if (SOLVER == KM_SOLVER_NEWTON) return solve_newton<NL, G>(w, lm, m, sub, actuation, cr, invm, pf);
   real a = solve_accel<NL, G>(w, lm, m, sub, actuation, cr, invm);
   pf.ph(6);
@@ -1317,7 +1329,7 @@ __device__ __forceinline__ void write_obs(const Ws<NL>& w, const LModel<NL>& lm,
 // initialize_episode (env_sim.py:23-36) + mj_forward without actuation (dm_control after_reset)
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, uint64_t seed,
-                                          int64_t genv, int episode, CReg<Dim<NL>::NC, Dim<NL>::NCF>& cr, real invm, Prof& pf) {
+                                          int64_t genv, int episode, CReg<NL>& cr, real invm, Prof& pf) {
   constexpr int NV = Dim<NL>::NV;
   if (sub < NV) { w.qvel[sub] = 0; w.warm[sub] = 0; }
   if (sub < NL) { w.qpos[sub] = lm.q_home[sub]; w.ctrl[sub] = lm.q_home[sub]; }
@@ -1391,7 +1403,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   const int env = blockIdx.x * EPB + grp;
   if (grp >= EPB || env >= st.num_envs) return;     // whole group exits together
   Ws<NL>& w = ws[grp];
-  CReg<Dim<NL>::NC, Dim<NL>::NCF> cr;
+  CReg<NL> cr;
   real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   Prof pf;
@@ -1479,7 +1491,7 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   if (grp >= EPB || env >= st.num_envs) return;
   if (mask && !mask[env]) return;
   Ws<NL>& w = ws[grp];
-  CReg<Dim<NL>::NC, Dim<NL>::NCF> cr;
+  CReg<NL> cr;
   real invm = 0;
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   int episode = st.episode[env] + 1;
@@ -1523,16 +1535,17 @@ static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const
   if (epb == 2) return launch_reset_e<NL, G, SOLVER, 2>(dm, st, mask, obs, stream);
   launch_reset_e<NL, G, SOLVER, 1>(dm, st, mask, obs, stream);
 }
-void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs, double* reward,
-                        uint8_t* done, hipStream_t stream) {
-  const bool newton = hd.solver == KM_SOLVER_NEWTON;
-  if (hd.nlink <= 10) { if (newton) launch_step_t<10, 16, 1>(dm, st, obs, reward, done, stream); else launch_step_t<10, 16, 0>(dm, st, obs, reward, done, stream); }
-  else { if (newton) launch_step_t<20, 32, 1>(dm, st, obs, reward, done, stream); else launch_step_t<20, 32, 0>(dm, st, obs, reward, done, stream); }
+// ---- one (NL, G, SOLVER) variant per translation unit (the Makefile compiles this file four times, in parallel)
+#ifndef KM_VAR_NL
+#error "compile with -DKM_VAR_NL=<10|20> -DKM_VAR_G=<16|32> -DKM_VAR_SOLVER=<0|1>"
+#endif
+#define KM_CAT4_(a, b, c, d) a##b##_##c##_##d
+#define KM_CAT4(a, b, c, d) KM_CAT4_(a, b, c, d)
+void KM_CAT4(kmanip_launch_step_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st, double* obs,
+                                                                    double* reward, uint8_t* done, hipStream_t stream) {
+  launch_step_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, obs, reward, done, stream);
 }
-void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const uint8_t* mask,
-                         int use_done_bits, double* obs, hipStream_t stream) {
-  (void)use_done_bits;
-  const bool newton = hd.solver == KM_SOLVER_NEWTON;
-  if (hd.nlink <= 10) { if (newton) launch_reset_t<10, 16, 1>(dm, st, mask, obs, stream); else launch_reset_t<10, 16, 0>(dm, st, mask, obs, stream); }
-  else { if (newton) launch_reset_t<20, 32, 1>(dm, st, mask, obs, stream); else launch_reset_t<20, 32, 0>(dm, st, mask, obs, stream); }
+void KM_CAT4(kmanip_launch_reset_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st,
+                                                                     const uint8_t* mask, double* obs, hipStream_t stream) {
+  launch_reset_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, mask, obs, stream);
 }
