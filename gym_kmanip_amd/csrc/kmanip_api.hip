@@ -28,6 +28,7 @@ struct KHandle_ {
   std::vector<hipEvent_t> ev;   // 3 events per timed step
   bool timing = false;
   int timed_steps = 0;
+  bool ik_unfused = false;      // KMANIP_IK_UNFUSED=1: before_step as its own launch (A/B timing only)
   bool ik_serial = false;       // KMANIP_IK_SERIAL=1: one-lane-per-problem IK kernel (A/B and cross-check only)
   std::vector<void*> allocs;
 };
@@ -148,6 +149,7 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.env_id_offset = env_id_offset;
   h->st.seed = seed;
   { const char* e = getenv("KMANIP_IK_SERIAL"); h->ik_serial = e && e[0] == '1'; }
+  { const char* e = getenv("KMANIP_IK_UNFUSED"); h->ik_unfused = e && e[0] == '1'; }
 #undef CR
   *out = h;
   return 0;
@@ -179,10 +181,13 @@ int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward
   const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
   hipEvent_t* ev = tm ? &h->ev[3 * (size_t)h->timed_steps] : nullptr;
   if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
+  // product path: ONE launch, before_step (decode + IK) fused into k_step so that no device-wide barrier sits between
+  // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1 / KMANIP_IK_SERIAL=1)
+  const bool split = h->ik_serial || h->ik_unfused;
   if (h->ik_serial) kmanip_launch_ik(h->dmodel, h->desc, h->st, act_dev, s);
-  else kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
+  else if (h->ik_unfused) kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
-  kmanip_launch_step(h->dmodel, h->desc, h->st, obs_dev, reward_dev, done_dev, s);
+  kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, s);
   if (tm) { HIPCHK(h, hipEventRecord(ev[2], s)); h->timed_steps++; }
   HIPCHK(h, hipGetLastError());
   return 0;

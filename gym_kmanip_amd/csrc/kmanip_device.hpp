@@ -182,7 +182,8 @@ void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& 
 void kmanip_launch_ik_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
                                  const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
                                  int32_t* status, hipStream_t stream);
-void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs,
+// act != NULL: the decode + IK of before_step run inside k_step (product path); NULL: they already ran
+void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act, double* obs,
                         double* reward, uint8_t* done, hipStream_t stream);
 void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const uint8_t* mask,
                          int use_done_bits, double* obs, hipStream_t stream);

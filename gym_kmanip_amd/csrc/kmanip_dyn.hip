@@ -25,7 +25,7 @@
 //   Newton           : Hessian rows / Cholesky / solves in registers, DPP row broadcasts (oracle: dense LDS-free C)
 //   constraint rows  : single-dof rows + 4-vector contact bases, pyramid edges expanded on the fly
 //   PGS              : per-contact block form on the 4x4 Gram matrix (algebraically the same row order)
-#include "kmanip_device.hpp"
+#include "kmanip_ik_coop.hpp"
 #include <stdlib.h>
 #define KM_TARGET_WAVES 1024   // 256 CUs x 4 SIMDs: below this many workgroups, fewer envs per wave fills more SIMDs
 
@@ -72,8 +72,8 @@ struct Ws {
     struct { real xpos[NL][3], xquat[NL][4], xmat[NL][9], axis[NL][3], cpos[NL][3], cube_mat[9]; } k;
     // ... then the same bytes hold the per-edge Gram rows Ge[c][e][l] = J_l . M^-1 (J_0 + sm J_k)^T for PGS
     struct { real Ge[NC][6][4]; } p;
-    // ... or, for the Newton solver, the nv x nv Hessian M + J^T D J and its Cholesky factor (in place)
-    struct { real Hm[NV][NV]; } h;
+    // ... and, before any of that, the per-arm scratch of the fused decode + IK (before_step)
+    CoopLds<7> ik[NL > 10 ? 2 : 1];
   };
   real Minv[NL][NL];       // joint-space inertia, overwritten by its inverse
   real Mm[NL][NL];         // copy of the joint-space inertia itself (Newton: Gauss term and Hessian)
@@ -1354,15 +1354,30 @@ __device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const
   GSYNC();
 }
 
+// fused = before_step runs in this kernel: ctrl <- float32(ctrl) (env_sim.py:40) and qpos_ik <- qpos here
 template <int NL, int G>
-__device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, int env, int sub) {
+__device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, int env, int sub, bool fused) {
   constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
   const int NE = st.num_envs;
-  for (int i = sub; i < NQ; i += G) w.qpos[i] = st.qpos[(size_t)i * NE + env];
+  for (int i = sub; i < NQ; i += G) { const real q = st.qpos[(size_t)i * NE + env]; w.qpos[i] = q; if (fused && i < NL) w.qpos_ik[i] = q; }
   for (int i = sub; i < NV; i += G) { w.qvel[i] = st.qvel[(size_t)i * NE + env]; w.warm[i] = st.warm[(size_t)i * NE + env]; }
-  for (int i = sub; i < NL; i += G) { w.ctrl[i] = st.ctrl[(size_t)i * NE + env]; w.qpos_ik[i] = st.qpos_ik[(size_t)i * NE + env]; }
+  for (int i = sub; i < NL; i += G) {
+    const real c = st.ctrl[(size_t)i * NE + env];
+    w.ctrl[i] = fused ? (real)(float)c : c;
+    if (!fused) w.qpos_ik[i] = st.qpos_ik[(size_t)i * NE + env];
+  }
   if (sub == 0) w.bad = 0;
 }
+// state accessor of the fused before_step: the env's LDS workspace (diagnostics go straight to HBM)
+template <int NL> struct LdsIO {
+  Ws<NL>& w; const KDeviceState& st; int env;
+  __device__ __forceinline__ real qpos(int i) const { return w.qpos[i]; }
+  __device__ __forceinline__ void set_ctrl(int i, real v) { w.ctrl[i] = v; }
+  __device__ __forceinline__ void set_qpos_ik(int i, real v) { w.qpos_ik[i] = v; }
+  __device__ __forceinline__ void set_diag(int arm, int nfev, int status) {
+    st.ik_nfev[(size_t)arm * st.num_envs + env] = nfev; st.ik_status[(size_t)arm * st.num_envs + env] = status;
+  }
+};
 template <int NL, int G>
 __device__ __forceinline__ void store_state(const Ws<NL>& w, const KDeviceState& st, int env, int sub) {
   constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
@@ -1392,8 +1407,8 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
 // EPB = envs per single-wave workgroup (<= 64 / G).  Fewer envs per wave = more waves per SIMD: the kernel is
 // bound by LDS/dependent-issue latency, so waves of different envs hide each other's waits.
 template <int NL, int G, int SOLVER, int EPB>
-__global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm, KDeviceState st, double* __restrict__ obs,
-                                             double* __restrict__ reward, uint8_t* __restrict__ done) {
+__global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm, KDeviceState st, const float* __restrict__ act,
+                                             double* __restrict__ obs, double* __restrict__ reward, uint8_t* __restrict__ done) {
   constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
   __shared__ Ws<NL> ws[EPB];
   __shared__ LModel<NL> lm;
@@ -1408,9 +1423,23 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   Prof pf;
   pf.start();
-  load_state<NL, G>(w, st, env, sub);
+  load_state<NL, G>(w, st, env, sub, act != nullptr);
   GSYNC();
   pf.ph(15);
+  if (act != nullptr) {
+    // ---- KManipTask.before_step: 8 lanes per arm (lanes 0-7 of the group: right arm, 8-15: left arm), the rest idle.
+    // Fused here so that an env whose IK needs many evaluations delays only its own wave, not the whole batch.
+    const int arm = sub / GI;
+    if (arm < KM_MAX_ARMS && (NL > 10 || arm == 0) && m->arm_present[arm]) {
+      LdsIO<NL> io{w, st, env};
+      const float* arow = act + (size_t)env * m->act_dim;
+      CoopLds<7>* L = &w.ik[NL > 10 ? arm : 0];
+      if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, L, arm, sub % GI, arow, io);
+      else coop_before_step<6>(dm, reinterpret_cast<CoopLds<6>*>(L), arm, sub % GI, arow, io);
+    }
+    GSYNC();
+    pf.ph(15);
+  }
   int bad = 0;
   const int nsub = m->n_sub_steps;
   for (int s = 0; s < nsub; s++) {
@@ -1514,19 +1543,19 @@ static int pick_epb(int num_envs, int max_epb) {
   return epb;
 }
 template <int NL, int G, int SOLVER, int EPB>
-static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
-  hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, obs, reward, done);
+static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
+  hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, act, obs, reward, done);
 }
 template <int NL, int G, int SOLVER, int EPB>
 static void launch_reset_e(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
   hipLaunchKernelGGL((k_reset<NL, G, SOLVER, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, mask, obs);
 }
 template <int NL, int G, int SOLVER>
-static void launch_step_t(const KDeviceModel* dm, const KDeviceState& st, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
+static void launch_step_t(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
   const int epb = pick_epb(st.num_envs, 64 / G);
-  if constexpr (64 / G >= 4) if (epb == 4) return launch_step_e<NL, G, SOLVER, 4>(dm, st, obs, reward, done, stream);
-  if (epb == 2) return launch_step_e<NL, G, SOLVER, 2>(dm, st, obs, reward, done, stream);
-  launch_step_e<NL, G, SOLVER, 1>(dm, st, obs, reward, done, stream);
+  if constexpr (64 / G >= 4) if (epb == 4) return launch_step_e<NL, G, SOLVER, 4>(dm, st, act, obs, reward, done, stream);
+  if (epb == 2) return launch_step_e<NL, G, SOLVER, 2>(dm, st, act, obs, reward, done, stream);
+  launch_step_e<NL, G, SOLVER, 1>(dm, st, act, obs, reward, done, stream);
 }
 template <int NL, int G, int SOLVER>
 static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
@@ -1541,9 +1570,9 @@ static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const
 #endif
 #define KM_CAT4_(a, b, c, d) a##b##_##c##_##d
 #define KM_CAT4(a, b, c, d) KM_CAT4_(a, b, c, d)
-void KM_CAT4(kmanip_launch_step_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st, double* obs,
-                                                                    double* reward, uint8_t* done, hipStream_t stream) {
-  launch_step_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, obs, reward, done, stream);
+void KM_CAT4(kmanip_launch_step_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st, const float* act,
+                                                                    double* obs, double* reward, uint8_t* done, hipStream_t stream) {
+  launch_step_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, act, obs, reward, done, stream);
 }
 void KM_CAT4(kmanip_launch_reset_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st,
                                                                      const uint8_t* mask, double* obs, hipStream_t stream) {

@@ -1,0 +1,563 @@
+// kmanip_ik_coop.hpp -- cooperative batched action decode + bounded trust-region-reflective IK (gfx950).
+//
+// Same reference semantics as kmanip_ik.hip (KManipTask.before_step env_sim.py:38-108; ik_mujoco.py:20-155;
+// scipy least_squares(method='trf', tr_solver='exact', bounds=jnt_range)), different mapping:
+//
+//   8 lanes per IK problem (env, arm), 8 problems per wave.  Lane c owns unknown c: x_c, its bounds, its
+//   Coleman-Li scaling v_c / d_c, gradient g_c, step components, and COLUMN c of the 6 x n task Jacobian.
+//   * forward kinematics: the n sincos run in parallel (one per lane) and are all-gathered through LDS; the
+//     chain product (a 3x3 constant rotation + a planar rotation per link) is then redundant on every lane,
+//     each lane keeping the anchor/axis of ITS joint on the way.
+//   * J^T f, costs, norms, step-to-bound ratios: per-lane scalars + 3-step DPP reductions over 8 lanes
+//     (row_half_mirror, quad_perm, quad_perm) -- every lane gets the bitwise-identical result, so all control
+//     flow (TRF branches, More iterations, termination tests) is uniform inside a problem.
+//   * the 7x7 normal matrix J_h^T J_h + C is built row-per-lane into LDS (one copy per problem); its
+//     Cholesky factor and the triangular solves are redundant per lane in registers (28 doubles).
+// Nothing of the TRF state is a 7-vector in one lane any more, which is what pushed the one-lane-per-problem
+// kernel into 0.5-1.5 KB of scratch per lane.
+#pragma once
+#include "kmanip_device.hpp"
+
+#define GI 8            // lanes per problem
+#define PPW (64 / GI)   // problems per wave / workgroup
+
+// ---- 8-lane group collectives (DPP half-row patterns); results identical in all 8 lanes
+__device__ __forceinline__ real gsum8(real v) {
+  v += dpp_f64<0x141>(v);   // row_half_mirror: i <-> 7 - i
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ real gmin8(real v) {
+  v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v));
+  return v;
+}
+__device__ __forceinline__ real gmax8(real v) {
+  v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v));
+  return v;
+}
+// true iff pred holds on every lane of the 8-lane group (lanes c >= n pass `true`)
+__device__ __forceinline__ bool gall8(bool pred) {
+  const unsigned long long b = __ballot(pred);
+  const int sh = (threadIdx.x & 63) & ~7;
+  return ((b >> sh) & 0xFFull) == 0xFFull;
+}
+
+// per-problem LDS scratch
+template <int N>
+struct CoopLds {
+  real A[N][N];        // normal matrix J_h^T J_h + C (row c written by lane c)
+  real J[6][GI];       // all-gather of the task Jacobian (column c written by lane c)
+  real v0[GI], v1[GI], v2[GI];   // all-gather buffers for n-vectors
+};
+
+template <int N>
+struct CoopCtx {
+  const KModelDesc* m;
+  const KModelAux* ax;
+  CoopLds<N>* L;
+  int arm, c;                 // arm index, lane index inside the problem (unknown index)
+  bool on;                    // c < N
+  real goal_pos[3], goal_quat[4];
+  real qfix;                  // joint value of the (at most one) chain link beyond the unknowns
+  real q_prev, q_home, lb, ub;
+};
+
+// all-gather of one value per lane into out[0..N)
+template <int N>
+__device__ __forceinline__ void allgather(real* buf, int c, real v, real* out) {
+  buf[c] = v;
+  KM_GSYNC();
+#pragma unroll
+  for (int i = 0; i < N; i++) out[i] = buf[i];
+  KM_GSYNC();
+}
+
+// ik_res (+ ik_jac when JAC): residual task part ft[6] (uniform), this lane's Jacobian column Jc[6],
+// site position / rotation (uniform).  x = this lane's unknown.
+template <int N, bool JAC>
+__device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft, real* Jc, real* sp_out, real* smat_out) {
+  const KModelDesc* m = P.m;
+  const int arm = P.arm;
+  real sn = 0, cs = 1;
+  if (P.on) sincos(x, &sn, &cs);
+  real sn_all[N], cs_all[N];
+  allgather<N>(P.L->v0, P.c, sn, sn_all);
+  allgather<N>(P.L->v1, P.c, cs, cs_all);
+  real pos[3] = {0, 0, 0}, mat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  real anc[3] = {0, 0, 0}, axw[3] = {0, 0, 0};
+  const int clen = P.ax->chain_len[arm];
+#pragma unroll
+  for (int k = 0; k < KM_MAX_CHAIN; k++) {
+    if (k < clen) {
+      const int l = P.ax->chain_link[arm][k];
+      const double* Rl = P.ax->chain_R[arm][k];
+      real lp[3] = {m->link_pos[l][0], m->link_pos[l][1], m->link_pos[l][2]};
+      real t[3], R1[9];
+      mat_vec3(t, mat, lp);
+      pos[0] += t[0]; pos[1] += t[1]; pos[2] += t[2];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) R1[3 * i + j] = mat[3 * i] * Rl[j] + mat[3 * i + 1] * Rl[3 + j] + mat[3 * i + 2] * Rl[6 + j];
+      if (m->jnt_type[l] == KM_JNT_SLIDE) {
+        // (no slide joint sits on any reference IK chain; kept for generality: unknown value needed, not its sincos)
+        real qv = P.qfix;
+        if (k < N) { real xs[N]; allgather<N>(P.L->v2, P.c, x, xs); qv = xs[k < N ? k : 0]; }
+#pragma unroll
+        for (int i = 0; i < 9; i++) mat[i] = R1[i];
+        pos[0] += R1[2] * qv; pos[1] += R1[5] * qv; pos[2] += R1[8] * qv;
+      } else {
+        real s_k, c_k;
+        if (k < N) { s_k = sn_all[k < N ? k : 0]; c_k = cs_all[k < N ? k : 0]; }
+        else sincos(P.qfix, &s_k, &c_k);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          mat[3 * i] = c_k * R1[3 * i] + s_k * R1[3 * i + 1];
+          mat[3 * i + 1] = c_k * R1[3 * i + 1] - s_k * R1[3 * i];
+          mat[3 * i + 2] = R1[3 * i + 2];
+        }
+      }
+      if (JAC && k < N && P.c == k) { anc[0] = pos[0]; anc[1] = pos[1]; anc[2] = pos[2]; axw[0] = mat[2]; axw[1] = mat[5]; axw[2] = mat[8]; }
+    }
+  }
+  real sp[3], smat[9], cur[4], rq[3];
+  real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]};
+  const double* Rs = P.ax->site_R[arm];
+  mat_vec3(sp, mat, so);
+  sp[0] += pos[0]; sp[1] += pos[1]; sp[2] += pos[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) smat[3 * i + j] = mat[3 * i] * Rs[j] + mat[3 * i + 1] * Rs[3 + j] + mat[3 * i + 2] * Rs[6 + j];
+  mat2quat(cur, smat);
+  sub_quat(rq, P.goal_quat, cur);
+  if (sp_out) { sp_out[0] = sp[0]; sp_out[1] = sp[1]; sp_out[2] = sp[2]; }
+  if (smat_out) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) smat_out[i] = smat[i];
+  }
+  ft[0] = sp[0] - P.goal_pos[0]; ft[1] = sp[1] - P.goal_pos[1]; ft[2] = sp[2] - P.goal_pos[2];
+  ft[3] = rq[0] * m->ik_res_rad; ft[4] = rq[1] * m->ik_res_rad; ft[5] = rq[2] * m->ik_res_rad;
+  if (JAC) {
+    // mjd_subQuat: Da = I + h K + (1 - h / tan h) K^2, D_ee = -Da^T; mat = rad * D_ee^T * site_xmat^T
+    real axs[3] = {rq[0], rq[1], rq[2]};
+    real half = 0.5 * normalize3(axs);
+    real K[9] = {0, -axs[2], axs[1], axs[2], 0, -axs[0], -axs[1], axs[0], 0};
+    real coef = 1.0 - (half < 6e-8 ? 1.0 : half / tan(half));
+    real Da[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        real kk = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+        Da[3 * i + j] = (i == j ? 1.0 : 0.0) + half * K[3 * i + j] + coef * kk;
+      }
+    real T[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        T[3 * i + j] = -m->ik_jac_rad * (Da[3 * i] * smat[3 * j] + Da[3 * i + 1] * smat[3 * j + 1] + Da[3 * i + 2] * smat[3 * j + 2]);
+    const int l = P.ax->chain_link[arm][P.on ? P.c : 0];
+    if (!P.on) { Jc[0] = 0; Jc[1] = 0; Jc[2] = 0; Jc[3] = 0; Jc[4] = 0; Jc[5] = 0; }
+    else if (m->jnt_type[l] == KM_JNT_SLIDE) { Jc[0] = axw[0]; Jc[1] = axw[1]; Jc[2] = axw[2]; Jc[3] = 0; Jc[4] = 0; Jc[5] = 0; }
+    else {
+      real r[3] = {sp[0] - anc[0], sp[1] - anc[1], sp[2] - anc[2]}, jp[3];
+      cross3(jp, axw, r);
+      Jc[0] = jp[0]; Jc[1] = jp[1]; Jc[2] = jp[2];
+      Jc[3] = T[0] * axw[0] + T[1] * axw[1] + T[2] * axw[2];
+      Jc[4] = T[3] * axw[0] + T[4] * axw[1] + T[5] * axw[2];
+      Jc[5] = T[6] * axw[0] + T[7] * axw[1] + T[8] * axw[2];
+    }
+  }
+}
+
+// cost = 0.5 |f|^2 (task + both regulariser blocks, ik_mujoco.py:48-53)
+template <int N>
+__device__ __forceinline__ real coop_cost(const CoopCtx<N>& P, real x, const real* ft) {
+  real a = P.m->ik_res_reg_prev * (x - P.q_prev), b = P.m->ik_res_reg_home * (x - P.q_home);
+  real loc = P.on ? a * a + b * b : 0.0;
+  real s = gsum8(loc);
+#pragma unroll
+  for (int r = 0; r < 6; r++) s += ft[r] * ft[r];
+  return 0.5 * s;
+}
+template <int N>
+__device__ __forceinline__ real coop_grad(const CoopCtx<N>& P, real x, const real* ft, const real* Jc) {
+  if (!P.on) return 0.0;
+  real s = 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++) s += Jc[r] * ft[r];
+  return s + P.m->ik_jac_reg * (P.m->ik_res_reg_prev * (x - P.q_prev) + P.m->ik_res_reg_home * (x - P.q_home));
+}
+
+// redundant-per-lane Cholesky of (A + alpha I) with A read from the problem's LDS copy; L in registers
+template <int N>
+__device__ __forceinline__ bool chol_reg(const real (*A)[N], real alpha, real (*L)[N]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    real s = A[j][j] + alpha;
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+    if (!(s > 0)) { ok = false; s = 1; }
+    real d = sqrt(s), inv = 1.0 / d;
+    L[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < N; i++) {
+      real t = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+      L[i][j] = t * inv;
+    }
+  }
+  return ok;
+}
+template <int N>
+__device__ __forceinline__ void chol_solve_reg(const real (*L)[N], const real* b, real* x) {
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    real s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
+    x[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+    real s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < N; k++) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+}
+template <int N> __device__ __forceinline__ real vdotN(const real* a, const real* b) {
+  real s = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) s += a[i] * b[i];
+  return s;
+}
+
+// scipy common.py solve_lsq_trust_region on the normal matrix (redundant per lane; full vectors in registers)
+template <int N>
+__device__ __forceinline__ void solve_tr_reg(const real (*A)[N], const real* g_h, real Delta, real& alpha, real* p) {
+  real L[N][N], ng[N], w[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) ng[i] = -g_h[i];
+  bool full_rank = chol_reg<N>(A, 0.0, L);
+  if (full_rank) {
+    chol_solve_reg<N>(L, ng, p);
+    if (sqrt(vdotN<N>(p, p)) <= Delta) { alpha = 0.0; return; }
+  }
+  real alpha_upper = sqrt(vdotN<N>(g_h, g_h)) / Delta, alpha_lower = 0.0;
+  if (full_rank) {
+    real pn = sqrt(vdotN<N>(p, p));
+    chol_solve_reg<N>(L, p, w);
+    real phi = pn - Delta, phip = -vdotN<N>(p, w) / pn;
+    alpha_lower = -phi / phip;
+  }
+  if (!full_rank && alpha == 0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+  for (int it = 0; it < 10; it++) {
+    if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    chol_reg<N>(A, alpha, L);
+    chol_solve_reg<N>(L, ng, p);
+    real pn = sqrt(vdotN<N>(p, p));
+    chol_solve_reg<N>(L, p, w);
+    real phi = pn - Delta, phip = -vdotN<N>(p, w) / pn;
+    if (phi < 0) alpha_upper = alpha;
+    real ratio = phi / phip;
+    alpha_lower = fmax(alpha_lower, alpha - ratio);
+    alpha -= (phi + Delta) * ratio / Delta;
+    if (fabs(phi) < 0.01 * Delta) break;
+  }
+  chol_reg<N>(A, alpha, L);
+  chol_solve_reg<N>(L, ng, p);
+  real sc = Delta / sqrt(vdotN<N>(p, p));
+#pragma unroll
+  for (int i = 0; i < N; i++) p[i] *= sc;
+}
+
+__device__ __forceinline__ void min_quad_1d_c(real a, real b, real lo, real hi, real c, real& t_out, real& y_out) {
+  real tb = lo, yb = lo * (a * lo + b) + c;
+  real y1 = hi * (a * hi + b) + c;
+  if (y1 < yb) { yb = y1; tb = hi; }
+  if (a != 0) {
+    real ex = -0.5 * b / a;
+    if (lo < ex && ex < hi) { real y2 = ex * (a * ex + b) + c; if (y2 < yb) { yb = y2; tb = ex; } }
+  }
+  t_out = tb; y_out = yb;
+}
+
+// (A v)_c for this lane's row of A (A in LDS), v given as a full vector
+template <int N>
+__device__ __forceinline__ real arow_dot(const CoopCtx<N>& P, const real* vfull) {
+  if (!P.on) return 0.0;
+  real s = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) s += P.L->A[P.c][j] * vfull[j];
+  return s;
+}
+// step size to the bound along s for this lane (INF if none)
+template <int N>
+__device__ __forceinline__ real lane_step_to_bound(const CoopCtx<N>& P, real x, real s) {
+  return (P.on && s != 0) ? fmax((P.lb - x) / s, (P.ub - x) / s) : INFINITY;
+}
+
+// scipy trf.py select_step in per-lane form.  Inputs: this lane's x, d, p_h, g_h; full p_h / g_h vectors.
+// Output: this lane's step_h (step = d * step_h); returns the predicted reduction (uniform).
+template <int N>
+__device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, real x, real d, real ph, real gh, const real* ph_full,
+                                                 const real* gh_full, real Delta, real theta, real& step_h) {
+  real* buf = P.L->v2;
+  const real Aph = arow_dot<N>(P, ph_full);
+  const real xp = x + d * ph;
+  if (gall8(!P.on || (xp >= P.lb && xp <= P.ub))) {
+    const real pv = 0.5 * gsum8(ph * Aph) + gsum8(gh * ph);
+    step_h = ph;
+    return -pv;
+  }
+  const real st = lane_step_to_bound<N>(P, x, d * ph);
+  const real p_stride = gmin8(st);
+  const bool hit = P.on && (d * ph != 0) && st == p_stride;
+  real rh = hit ? -ph : ph;
+  const real phs = ph * p_stride;            // trust-region step restricted to hit the bound
+  const real xb = x + d * phs;
+  real to_tr;
+  {
+    const real a = gsum8(rh * rh), b = gsum8(phs * rh), c = gsum8(phs * phs) - Delta * Delta;
+    const real dd = sqrt(b * b - a * c);
+    const real q = -(b + copysign(dd, b));
+    const real t1 = q / a, t2 = c / q;
+    to_tr = t1 < t2 ? t2 : t1;
+  }
+  const real to_bound = gmin8(lane_step_to_bound<N>(P, xb, d * rh));
+  real r_stride = fmin(to_bound, to_tr), rl, ru;
+  if (r_stride > 0) { rl = (1 - theta) * p_stride / r_stride; ru = (r_stride == to_bound) ? theta * to_bound : to_tr; }
+  else { rl = 0; ru = -1; }
+  real r_value = INFINITY;
+  const real Aphs = Aph * p_stride;          // A (p_h * stride) row value
+  if (rl <= ru) {
+    real rh_full[N];
+    allgather<N>(buf, P.c, rh, rh_full);
+    const real Arh = arow_dot<N>(P, rh_full);
+    const real a = 0.5 * gsum8(rh * Arh);
+    const real b = gsum8(gh * rh) + gsum8(phs * Arh);
+    const real c = 0.5 * gsum8(phs * Aphs) + gsum8(gh * phs);
+    min_quad_1d_c(a, b, rl, ru, c, r_stride, r_value);
+    rh = rh * r_stride + phs;
+  }
+  const real pht = phs * theta;              // strictly interior version of the restricted step
+  const real p_value = 0.5 * gsum8(pht * (Aphs * theta)) + gsum8(gh * pht);
+  real agh = -gh;
+  const real to_tr2 = Delta / sqrt(gsum8(agh * agh));
+  const real to_bound2 = gmin8(lane_step_to_bound<N>(P, x, d * agh));
+  real ag_stride = (to_bound2 < to_tr2) ? theta * to_bound2 : to_tr2;
+  real ag_value;
+  {
+    real ngh_full[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) ngh_full[i] = -gh_full[i];
+    const real Aag = arow_dot<N>(P, ngh_full);
+    const real a = 0.5 * gsum8(agh * Aag), b = gsum8(gh * agh);
+    min_quad_1d_c(a, b, 0, ag_stride, 0, ag_stride, ag_value);
+  }
+  agh *= ag_stride;
+  if (p_value < r_value && p_value < ag_value) { step_h = pht; return -p_value; }
+  if (r_value < p_value && r_value < ag_value) { step_h = rh; return -r_value; }
+  step_h = agh;
+  return -ag_value;
+}
+
+// make_strictly_feasible for this lane's component
+__device__ __forceinline__ real lane_strictly_feasible(real x, real lb, real ub, real rstep) {
+  real xn = x;
+  if (rstep == 0) {
+    if (x <= lb) xn = nextafter(lb, ub);
+    if (x >= ub) xn = nextafter(ub, lb);
+  } else {
+    real ld = x - lb, ud = ub - x;
+    real lt = rstep * fmax(1.0, fabs(lb)), ut = rstep * fmax(1.0, fabs(ub));
+    if (ld <= fmin(ud, lt)) xn = lb + lt;
+    if (ud <= fmin(ld, ut)) xn = ub - ut;
+  }
+  if (xn < lb || xn > ub) xn = 0.5 * (lb + ub);
+  return xn;
+}
+
+// scipy trf.py trf_bounds, cooperative form.  x: this lane's unknown (in: strictly feasible start, out: result.x);
+// x_last: the last evaluated point.  Returns status (uniform).
+template <int N>
+__device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_out) {
+  const real ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+  const int max_nfev = 100 * N;
+  const real jreg2 = 2 * P.m->ik_jac_reg * P.m->ik_jac_reg;
+  real ft[6], Jc[6], ft_new[6], Jn[6];
+  coop_eval<N, true>(P, x, ft, Jc, nullptr, nullptr);
+  int nfev = 1;
+  real cost = coop_cost<N>(P, x, ft);
+  real g = coop_grad<N>(P, x, ft, Jc);
+  real v = 1;
+  if (g < 0) v = P.ub - x;
+  if (g > 0) v = x - P.lb;
+  real Delta = sqrt(gsum8(P.on ? x * x / v : 0.0));
+  if (Delta == 0) Delta = 1.0;
+  real alpha = 0.0, cost_new = cost;
+  int status = -1;
+  x_last = x;
+  for (;;) {
+    real dv = 0;
+    v = 1;
+    if (g < 0) { v = P.ub - x; dv = -1; }
+    if (g > 0) { v = x - P.lb; dv = 1; }
+    const real g_norm = gmax8(P.on ? fabs(g * v) : 0.0);
+    if (g_norm < gtol) status = 1;
+    if (status != -1 || nfev == max_nfev) break;
+    const real d = sqrt(v), diag_h = g * dv, g_h = d * g;
+    // ---- normal matrix row c into LDS: A[c][j] = d_c d_j (J_c . J_j + 2 reg^2 [c==j]) + diag_h [c==j]
+    if (P.on) {
+#pragma unroll
+      for (int r = 0; r < 6; r++) P.L->J[r][P.c] = Jc[r];
+    }
+    real d_full[N], gh_full[N];
+    allgather<N>(P.L->v0, P.c, d, d_full);       // (the sync inside also publishes J)
+    allgather<N>(P.L->v1, P.c, g_h, gh_full);
+    if (P.on) {
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        real s = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) s += Jc[r] * P.L->J[r][j];
+        if (j == P.c) s += jreg2;
+        s *= d * d_full[j];
+        if (j == P.c) s += diag_h;
+        P.L->A[P.c][j] = s;
+      }
+    }
+    KM_GSYNC();
+    const real theta = fmax(0.995, 1 - g_norm);
+    real actual = -1, x_new = x;
+    while (actual <= 0 && nfev < max_nfev) {
+      real ph_full[N];
+      solve_tr_reg<N>(P.L->A, gh_full, Delta, alpha, ph_full);
+      real ph = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) if (P.c == i) ph = ph_full[i];
+      real step_h;
+      const real predicted = coop_select_step<N>(P, x, d, ph, g_h, ph_full, gh_full, Delta, theta, step_h);
+      if (!P.on) step_h = 0;
+      const real step = d * step_h;
+      x_new = P.on ? lane_strictly_feasible(x + step, P.lb, P.ub, 0.0) : x;
+      // ik_res(x_new) and, in the same kinematics pass, what ik_jac(x_new) recomputes if the step is accepted
+      coop_eval<N, true>(P, x_new, ft_new, Jn, nullptr, nullptr);
+      x_last = x_new;
+      nfev++;
+      const real shn = sqrt(gsum8(step_h * step_h));
+      bool fin = true;
+#pragma unroll
+      for (int r = 0; r < 6; r++) fin = fin && isfinite(ft_new[r]);
+      if (!fin) { Delta = 0.25 * shn; continue; }
+      cost_new = coop_cost<N>(P, x_new, ft_new);
+      actual = cost - cost_new;
+      real ratio, Delta_new = Delta;
+      if (predicted > 0) ratio = actual / predicted;
+      else if (predicted == 0 && actual == 0) ratio = 1;
+      else ratio = 0;
+      if (ratio < 0.25) Delta_new = 0.25 * shn;
+      else if (ratio > 0.75 && shn > 0.95 * Delta) Delta_new = Delta * 2.0;
+      const real sn = sqrt(gsum8(step * step)), xn = sqrt(gsum8(P.on ? x * x : 0.0));
+      const bool ft_ok = (actual < ftol * cost) && (ratio > 0.25);
+      const bool xt_ok = sn < xtol * (xtol + xn);
+      if (ft_ok && xt_ok) status = 4; else if (ft_ok) status = 2; else if (xt_ok) status = 3;
+      if (status != -1) break;
+      alpha *= Delta / Delta_new;
+      Delta = Delta_new;
+    }
+    if (actual > 0) {
+      x = x_new;
+      cost = cost_new;
+#pragma unroll
+      for (int r = 0; r < 6; r++) { ft[r] = ft_new[r]; Jc[r] = Jn[r]; }
+      g = coop_grad<N>(P, x, ft, Jc);
+    }
+  }
+  if (status == -1) status = 0;
+  *nfev_out = nfev;
+  return status;
+}
+
+// ik_mujoco.py:100-155 for one problem; returns q_out component of this lane
+template <int N>
+__device__ __forceinline__ real coop_ik_solve(const CoopCtx<N>& P, real x0, real& x_last, int* nfev, int* status) {
+  real x = x0;
+  x_last = x0;
+  *nfev = 0; *status = -2;
+  if (gall8(!P.on || (x >= P.lb && x <= P.ub))) {      // else least_squares raises ValueError -> "IK failed"
+    if (P.on) x = lane_strictly_feasible(x, P.lb, P.ub, 1e-10);
+    *status = coop_trf<N>(P, x, x_last, nfev);
+  }
+  return fmin(fmax(x, P.lb), P.ub);                      // :147-152 (:140-145 is a no-op)
+}
+
+__device__ __forceinline__ real f32r_c(real x) { return (real)(float)x; }
+
+// ---------------------------------------------------------------------------------------------
+// KManipTask.before_step (env_sim.py:38-108) for ONE (env, arm) problem on its 8 lanes: grip decode, EE-delta decode
+// + IK, or the joint-delta modes.  IO abstracts where the env's state lives (global SoA columns for the
+// stand-alone kernel, the LDS workspace when fused into k_step):
+//   real IO::qpos(int i); void IO::set_ctrl(int i, real v); void IO::set_qpos_ik(int i, real v); void IO::set_diag(int arm, int nfev, int status)
+template <int N, class IO>
+__device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds<N>* L, int arm, int c, const float* a, IO& io) {
+  const KModelDesc* m = &dm->d;
+  const int grip_key[2] = {KM_ACT_GRIP_R, KM_ACT_GRIP_L};
+  const int pos_key[2] = {KM_ACT_EER_POS, KM_ACT_EEL_POS};
+  const int orn_key[2] = {KM_ACT_EER_ORN, KM_ACT_EEL_ORN};
+  const int qp_key[2] = {KM_ACT_QPOS_R, KM_ACT_QPOS_L};
+  // ---- grip (env_sim.py:41-59): float32 arithmetic exactly as numpy does it
+  const int cg = m->act_col[grip_key[arm]];
+  if (cg >= 0 && c == 0) {
+    int g0 = m->arm_grip_id[arm][0], g1 = m->arm_grip_id[arm][1];
+    float g = a[cg] * (float)m->ee_s_delta;
+    g = (float)((double)g + io.qpos(g0));
+    g = fminf(fmaxf(g, (float)m->ee_s_min), (float)m->ee_s_max);
+    io.set_ctrl(g0, (double)g);
+    io.set_ctrl(g1, (double)g);
+  }
+  CoopCtx<N> P;
+  P.m = m; P.ax = &dm->x; P.L = L; P.arm = arm; P.c = c; P.on = c < N;
+  const int q = m->arm_q_id[arm][P.on ? c : 0];
+  const real x0 = P.on ? io.qpos(q) : 0.0;
+  P.q_prev = x0; P.q_home = m->q_home[q]; P.lb = m->jnt_range[q][0]; P.ub = m->jnt_range[q][1];
+  const int clen = dm->x.chain_len[arm];
+  P.qfix = (clen > N) ? io.qpos(dm->x.chain_link[arm][clen - 1]) : 0.0;
+  const int cp = m->act_col[pos_key[arm]], co = m->act_col[orn_key[arm]], cq = m->act_col[qp_key[arm]];
+  if (cp >= 0) {
+    // current site pose: one kinematics pass at x0
+    P.goal_pos[0] = 0; P.goal_pos[1] = 0; P.goal_pos[2] = 0;
+    P.goal_quat[0] = 1; P.goal_quat[1] = 0; P.goal_quat[2] = 0; P.goal_quat[3] = 0;
+    real ft0[6], sp[3], smat[9];
+    coop_eval<N, false>(P, x0, ft0, nullptr, sp, smat);
+    // EE-delta decode (env_sim.py:60-69): euler("xyz", extrinsic) of the site matrix + delta -> quaternion
+    real e0 = atan2(smat[7], smat[8]);
+    real e1 = atan2(-smat[6], sqrt(smat[7] * smat[7] + smat[8] * smat[8]));
+    real e2 = atan2(smat[3], smat[0]);
+    e0 += (double)a[co] * m->ee_orn_delta[0];
+    e1 += (double)a[co + 1] * m->ee_orn_delta[1];
+    e2 += (double)a[co + 2] * m->ee_orn_delta[2];
+    real qx[4] = {cos(e0 * 0.5), sin(e0 * 0.5), 0, 0}, qy[4] = {cos(e1 * 0.5), 0, sin(e1 * 0.5), 0};
+    real qz[4] = {cos(e2 * 0.5), 0, 0, sin(e2 * 0.5)}, t4[4];
+    qmul(t4, qy, qx);
+    qmul(P.goal_quat, qz, t4);
+    P.goal_pos[0] = (double)a[cp] * m->ee_pos_delta[0] + sp[0];
+    P.goal_pos[1] = (double)a[cp + 1] * m->ee_pos_delta[1] + sp[1];
+    P.goal_pos[2] = (double)a[cp + 2] * m->ee_pos_delta[2] + sp[2];
+    real xl;
+    int nfev, status;
+    const real qo = coop_ik_solve<N>(P, x0, xl, &nfev, &status);
+    if (P.on) { io.set_ctrl(q, f32r_c(qo)); io.set_qpos_ik(q, xl); }
+    if (c == 0) io.set_diag(arm, nfev, status);
+  } else {
+    if (c == 0) io.set_diag(arm, 0, -3);
+    if (cq >= 0 && P.on)    // joint-delta modes, env_sim.py:100-103
+      io.set_ctrl(q, f32r_c(x0 + (double)(a[cq + c] * (float)m->q_pos_delta)));
+  }
+}
