@@ -204,11 +204,11 @@ def main():
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
                        "collective": "async all_gather of (reward, done) per step" if gather is not None else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_env_step": algorithmic_bytes_per_env_step(cm),
-                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "decode_ik": ik_ms / max(nt, 1)},
+                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1)},
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }
         if not args.no_pgs_variant and args.solver == "newton":
