@@ -79,6 +79,20 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
     for (int j = i; j >= 0; j = d->link_parent[j]) mk |= 1u << j;
     x->anc_mask[i] = mk;
   }
+  int depth = 1;
+  for (int i = 0; i < d->nlink; i++) {
+    int dep = 0;
+    for (int j = i; j >= 0; j = d->link_parent[j]) { x->desc_mask[j] |= 1u << i; dep++; }
+    if (dep > depth) depth = dep;
+    for (int k = 0; k < 4; k++) {
+      int a = i;
+      for (int t = 0; t < (1 << k) && a >= 0; t++) a = d->link_parent[a];
+      x->jump[k][i] = a;
+    }
+  }
+  if (depth > 16) { err = "kinematic tree deeper than 16 links"; return -1; }
+  x->fk_rounds = 0;
+  while ((1 << x->fk_rounds) < depth) x->fk_rounds++;
   for (int a = 0; a < KM_MAX_ARMS; a++) {
     if (!d->arm_present[a]) continue;
     int chain[KM_MAX_LINKS], n = 0;

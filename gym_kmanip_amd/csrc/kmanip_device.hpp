@@ -16,6 +16,9 @@
 // Host-precomputed lookup data that is derived from KModelDesc (kept out of the ABI struct).
 struct KModelAux {
   uint32_t anc_mask[KM_MAX_LINKS];           // bit j set <=> dof j is link i or one of its ancestors
+  uint32_t desc_mask[KM_MAX_LINKS];          // bit j set <=> link j is link i or one of its descendants
+  int32_t jump[4][KM_MAX_LINKS];             // jump[k][i] = the 2^k-th ancestor of link i (-1: none) -- FK pointer jumping
+  int32_t fk_rounds;                         // ceil(log2(tree depth)) <= 4
   int32_t chain_len[KM_MAX_ARMS];            // IK kinematic chain root -> site link
   int32_t chain_link[KM_MAX_ARMS][KM_MAX_CHAIN];
   int32_t chain_xidx[KM_MAX_ARMS][KM_MAX_CHAIN];  // index into the IK unknowns, -1 = fixed at current qpos

@@ -46,7 +46,8 @@ template <int NL> __device__ __forceinline__ constexpr int slot_sphere(int c) { 
 template <int NL>
 struct LModel {
   int parent[NL], jtype[NL], forcelimited[NL];
-  uint32_t anc[NL];
+  uint32_t anc[NL], desc[NL];
+  int jump[4][NL], fk_rounds;
   real pos[NL][3], quat[NL][4], jaxis[NL][3], range[NL][2], floss[NL], kp[NL], ctrlrange[NL][2], forcerange[NL][2];
   real mass[NL], com[NL][3], inertia[NL][3], q_home[NL];
   real R[NL][9];        // constant rotation of each link in its parent (from link_quat)
@@ -161,57 +162,74 @@ template <int G> __device__ __forceinline__ int gor(int v) {
   return v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// mj_kinematics (+ link com): serial over the tree on the group's lane 0
-template <int NL>
-__device__ __forceinline__ void fk_serial(Ws<NL>& w, const LModel<NL>& lm) {
-  // rotation-matrix propagation (all joints act about local z): one constant 3x3 product and a planar rotation
-  // of two columns per link; no quaternion products / normalisations, one sincos per hinge
-  for (int i = 0; i < NL; i++) {
-    const int p = lm.parent[i];
-    real pos[3], R1[9], mat[9];
-    real lp[3] = {lm.pos[i][0], lm.pos[i][1], lm.pos[i][2]};
-    if (p < 0) {
-      pos[0] = lp[0]; pos[1] = lp[1]; pos[2] = lp[2];
+// mj_kinematics, all links at once: lane i builds link i's transform in its parent (constant rotation times the
+// planar joint rotation; one sincos per lane instead of NL in a row), then ceil(log2(depth)) rounds of pointer
+// jumping compose it with the transform of the 2^k-th ancestor (staged in the link's own xmat/xpos slots).
+template <int NL, int G>
+__device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+  real R[9], p[3];
+  const bool on = sub < NL;
+  if (on) {
+    const real q = w.qpos[sub];
+    p[0] = lm.pos[sub][0]; p[1] = lm.pos[sub][1]; p[2] = lm.pos[sub][2];
+    if (lm.jtype[sub] == KM_JNT_SLIDE) {
 #pragma unroll
-      for (int c = 0; c < 9; c++) R1[c] = lm.R[i][c];
-    } else {
-      const real* P = w.k.xmat[p];
-      mat_vec3(pos, P, lp);
-      pos[0] += w.k.xpos[p][0]; pos[1] += w.k.xpos[p][1]; pos[2] += w.k.xpos[p][2];
-#pragma unroll
-      for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) R1[3 * a + b] = P[3 * a] * lm.R[i][b] + P[3 * a + 1] * lm.R[i][3 + b] + P[3 * a + 2] * lm.R[i][6 + b];
-    }
-    const real q = w.qpos[i];
-    if (lm.jtype[i] == KM_JNT_SLIDE) {
-#pragma unroll
-      for (int c = 0; c < 9; c++) mat[c] = R1[c];
-      pos[0] += R1[2] * q; pos[1] += R1[5] * q; pos[2] += R1[8] * q;
+      for (int c = 0; c < 9; c++) R[c] = lm.R[sub][c];
+      p[0] += R[2] * q; p[1] += R[5] * q; p[2] += R[8] * q;
     } else {
       real sn, cs;
       sincos(q, &sn, &cs);
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        mat[3 * a] = cs * R1[3 * a] + sn * R1[3 * a + 1];
-        mat[3 * a + 1] = cs * R1[3 * a + 1] - sn * R1[3 * a];
-        mat[3 * a + 2] = R1[3 * a + 2];
+        const real c0 = lm.R[sub][3 * a], c1 = lm.R[sub][3 * a + 1];
+        R[3 * a] = cs * c0 + sn * c1;
+        R[3 * a + 1] = cs * c1 - sn * c0;
+        R[3 * a + 2] = lm.R[sub][3 * a + 2];
       }
     }
-    real cl[3] = {lm.com[i][0], lm.com[i][1], lm.com[i][2]}, cw[3];
-    mat_vec3(cw, mat, cl);
 #pragma unroll
-    for (int c = 0; c < 3; c++) { w.k.xpos[i][c] = pos[c]; w.k.cpos[i][c] = pos[c] + cw[c]; }
-    w.k.axis[i][0] = mat[2]; w.k.axis[i][1] = mat[5]; w.k.axis[i][2] = mat[8];
+    for (int c = 0; c < 9; c++) w.k.xmat[sub][c] = R[c];
+    w.k.xpos[sub][0] = p[0]; w.k.xpos[sub][1] = p[1]; w.k.xpos[sub][2] = p[2];
+  } else if (sub == NL) {
+    real cq[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]}, cm[9];
+    normalize4(cq);
+    quat2mat(cm, cq);
 #pragma unroll
-    for (int c = 0; c < 9; c++) w.k.xmat[i][c] = mat[c];
+    for (int c = 0; c < 9; c++) w.k.cube_mat[c] = cm[c];
   }
-  real cq[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]}, cm[9];
-  normalize4(cq);
-  quat2mat(cm, cq);
+  GSYNC();
+  const int rounds = lm.fk_rounds;
+  for (int k = 0; k < rounds; k++) {
+    const int a = on ? lm.jump[k][sub] : -1;
+    if (a >= 0) {
+      real A[9], pa[3], Rn[9], t[3];
 #pragma unroll
-  for (int c = 0; c < 9; c++) w.k.cube_mat[c] = cm[c];
+      for (int c = 0; c < 9; c++) A[c] = w.k.xmat[a][c];
+      pa[0] = w.k.xpos[a][0]; pa[1] = w.k.xpos[a][1]; pa[2] = w.k.xpos[a][2];
+      mat_vec3(t, A, p);
+      p[0] = t[0] + pa[0]; p[1] = t[1] + pa[1]; p[2] = t[2] + pa[2];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rn[3 * i + j] = A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j] + A[3 * i + 2] * R[6 + j];
+#pragma unroll
+      for (int c = 0; c < 9; c++) R[c] = Rn[c];
+    }
+    GSYNC();
+    if (a >= 0) {
+#pragma unroll
+      for (int c = 0; c < 9; c++) w.k.xmat[sub][c] = R[c];
+      w.k.xpos[sub][0] = p[0]; w.k.xpos[sub][1] = p[1]; w.k.xpos[sub][2] = p[2];
+    }
+    GSYNC();
+  }
+  if (on) {
+    real cl[3] = {lm.com[sub][0], lm.com[sub][1], lm.com[sub][2]}, cw[3];
+    mat_vec3(cw, R, cl);
+    w.k.cpos[sub][0] = p[0] + cw[0]; w.k.cpos[sub][1] = p[1] + cw[1]; w.k.cpos[sub][2] = p[2] + cw[2];
+    w.k.axis[sub][0] = R[2]; w.k.axis[sub][1] = R[5]; w.k.axis[sub][2] = R[8];
+  }
+  GSYNC();
 }
 
 // column j of the com Jacobian of body b (world frame): linear part jv, angular part jw
@@ -252,16 +270,30 @@ __device__ __forceinline__ void composite_own(Ws<NL>& w, const LModel<NL>& lm, i
     o[9] = R[6] * R[6] * I0 + R[7] * R[7] * I1 + R[8] * R[8] * I2 + mb * (cc - c[2] * c[2]);
   }
 }
-template <int NL>
-__device__ __forceinline__ void composite_accumulate_serial(Ws<NL>& w, const LModel<NL>& lm) {
-  for (int i = NL - 1; i >= 0; i--) {
-    const int p = lm.parent[i];
-    if (p >= 0) {
+// subtree sums, one link per lane: comp/FN of link i += those of its proper descendants (read-all, sync, write)
+template <int NL, int G>
+__device__ __forceinline__ void composite_accumulate(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+  real acc[16];
+  const bool on = sub < NL;
+  if (on) {
 #pragma unroll
-      for (int k = 0; k < 10; k++) w.f.comp[p][k] += w.f.comp[i][k];
+    for (int k = 0; k < 10; k++) acc[k] = w.f.comp[sub][k];
 #pragma unroll
-      for (int k = 0; k < 6; k++) w.f.FN[p][k] += w.f.FN[i][k];      // bias wrenches (about the world origin) too
+    for (int k = 0; k < 6; k++) acc[10 + k] = w.f.FN[sub][k];
+    for (uint32_t mk = lm.desc[sub] & ~(1u << sub); mk; mk &= mk - 1) {
+      const int j = __ffs(mk) - 1;
+#pragma unroll
+      for (int k = 0; k < 10; k++) acc[k] += w.f.comp[j][k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[10 + k] += w.f.FN[j][k];
     }
+  }
+  GSYNC();
+  if (on) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) w.f.comp[sub][k] = acc[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) w.f.FN[sub][k] = acc[10 + k];
   }
 }
 template <int NL, int G>
@@ -308,36 +340,59 @@ __device__ __forceinline__ void mass_symmetrize(Ws<NL>& w, int sub) {
     for (int i = j + 1; i < NL; i++) w.Minv[i][j] = w.Minv[j][i];
 }
 
-// velocity-product + gravity wrenches per body (serial forward pass), then bias_j = sum_b J_bj^T wrench_b
-template <int NL>
-__device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m) {
-  real* scratch = &w.f.Lw[0][0];   // (omega, alpha, a_origin) per link: 9 numbers each
-  for (int i = 0; i < NL; i++) {
-    const int p = lm.parent[i];
-    real wp[3] = {0, 0, 0}, alp[3] = {0, 0, 0}, ap[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]}, op[3] = {0, 0, 0};
-    if (p >= 0) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) { wp[c] = scratch[9 * p + c]; alp[c] = scratch[9 * p + 3 + c]; ap[c] = scratch[9 * p + 6 + c]; op[c] = w.k.xpos[p][c]; }
-    }
-    real r[3] = {w.k.xpos[i][0] - op[0], w.k.xpos[i][1] - op[1], w.k.xpos[i][2] - op[2]};
-    real t1[3], t2[3], ai[3], wi[3], ali[3];
+// ---------------------------------------------------------------------------------------------
+// Velocity-product + gravity wrench of every body (then bias_j = sum_b J_bj^T wrench_b), one link per lane.  omega, alpha and the origin acceleration of a link are sums of per-link
+// increments over its ancestors, so each lane first publishes its increment (LDS), then sums along its own
+// ancestor mask in root-to-leaf order (the order of the serial recursion):
+//   omega_i = sum_j wv_j,          wv_j = axis_j qvel_j (hinge)
+//   alpha_i = sum_j cz_j (hinge),  cz_j = omega_parent(j) x wv_j
+//   a_i     = -g + sum_j d_j,      d_j  = alpha_p x r_j + omega_p x (omega_p x r_j) (+ 2 cz_j for a slide)
+template <int NL, int G>
+__device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub) {
+  real* wvb = &w.f.Lw[0][0];            // [NL][3] each
+  real* czb = wvb + 3 * NL;
+  real* dbb = czb + 3 * NL;
+  static_assert(9 * NL <= NL * NL, "bias scratch must fit the Cholesky workspace it aliases");
+  const bool on = sub < NL;
+  const bool slide = on && lm.jtype[sub] == KM_JNT_SLIDE;
+  const uint32_t up = on ? (lm.anc[sub] & ~(1u << sub)) : 0u;       // proper ancestors
+  real ax[3] = {0, 0, 0};
+  if (on) {
+    const real qv = w.qvel[sub];
+    ax[0] = w.k.axis[sub][0] * qv; ax[1] = w.k.axis[sub][1] * qv; ax[2] = w.k.axis[sub][2] * qv;
+    wvb[3 * sub] = slide ? 0.0 : ax[0]; wvb[3 * sub + 1] = slide ? 0.0 : ax[1]; wvb[3 * sub + 2] = slide ? 0.0 : ax[2];
+  }
+  GSYNC();
+  real wp[3] = {0, 0, 0}, cz[3] = {0, 0, 0};
+  if (on) {
+    for (uint32_t mk = up; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; wp[0] += wvb[3 * j]; wp[1] += wvb[3 * j + 1]; wp[2] += wvb[3 * j + 2]; }
+    cross3(cz, wp, ax);
+    czb[3 * sub] = slide ? 0.0 : cz[0]; czb[3 * sub + 1] = slide ? 0.0 : cz[1]; czb[3 * sub + 2] = slide ? 0.0 : cz[2];
+  }
+  GSYNC();
+  real alp[3] = {0, 0, 0};
+  if (on) {
+    for (uint32_t mk = up; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; alp[0] += czb[3 * j]; alp[1] += czb[3 * j + 1]; alp[2] += czb[3 * j + 2]; }
+    const int p = lm.parent[sub];
+    real op[3] = {0, 0, 0};
+    if (p >= 0) { op[0] = w.k.xpos[p][0]; op[1] = w.k.xpos[p][1]; op[2] = w.k.xpos[p][2]; }
+    real r[3] = {w.k.xpos[sub][0] - op[0], w.k.xpos[sub][1] - op[1], w.k.xpos[sub][2] - op[2]}, t1[3], t2[3];
     cross3(t1, alp, r);
     cross3(t2, wp, r); cross3(t2, wp, t2);
-    const real qv = w.qvel[i];
-    real ax[3] = {w.k.axis[i][0] * qv, w.k.axis[i][1] * qv, w.k.axis[i][2] * qv}, cz[3];
-    cross3(cz, wp, ax);
 #pragma unroll
-    for (int c = 0; c < 3; c++) { ai[c] = ap[c] + t1[c] + t2[c]; wi[c] = wp[c]; ali[c] = alp[c]; }
-    if (lm.jtype[i] == KM_JNT_SLIDE) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) ai[c] += 2 * cz[c];
-    } else {
+    for (int c = 0; c < 3; c++) dbb[3 * sub + c] = t1[c] + t2[c] + (slide ? 2 * cz[c] : 0.0);
+  }
+  GSYNC();
+  if (on) {
+    real ai[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]};
+    for (uint32_t mk = lm.anc[sub]; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; ai[0] += dbb[3 * j]; ai[1] += dbb[3 * j + 1]; ai[2] += dbb[3 * j + 2]; }
+    real wi[3] = {wp[0], wp[1], wp[2]}, ali[3] = {alp[0], alp[1], alp[2]};
+    if (!slide) {
 #pragma unroll
       for (int c = 0; c < 3; c++) { wi[c] += ax[c]; ali[c] += cz[c]; }
     }
-#pragma unroll
-    for (int c = 0; c < 3; c++) { scratch[9 * i + c] = wi[c]; scratch[9 * i + 3 + c] = ali[c]; scratch[9 * i + 6 + c] = ai[c]; }
-    real cr[3] = {w.k.cpos[i][0] - w.k.xpos[i][0], w.k.cpos[i][1] - w.k.xpos[i][1], w.k.cpos[i][2] - w.k.xpos[i][2]};
+    const int i = sub;
+    real cr[3] = {w.k.cpos[i][0] - w.k.xpos[i][0], w.k.cpos[i][1] - w.k.xpos[i][1], w.k.cpos[i][2] - w.k.xpos[i][2]}, t1[3], t2[3];
     cross3(t1, ali, cr);
     cross3(t2, wi, cr); cross3(t2, wi, t2);
     real wl[3], all[3], Iw[3], nl3[3], nw[3];
@@ -354,14 +409,16 @@ __device__ __forceinline__ void bias_bodies_serial(Ws<NL>& w, const LModel<NL>& 
     cross3(sh, cpi, Fi);                       // shift the moment from the com to the world origin
 #pragma unroll
     for (int c = 0; c < 3; c++) { w.f.FN[i][c] = Fi[c]; w.f.FN[i][3 + c] = nw[c] + sh[c]; }
-  }
-  // cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
-  real wv[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
-  real Iw[3] = {m->cube_inertia[0] * wv[0], m->cube_inertia[1] * wv[1], m->cube_inertia[2] * wv[2]}, t[3];
-  cross3(t, wv, Iw);
+  } else if (sub == NL) {
+    // cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
+    real wv[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
+    real Iw[3] = {m->cube_inertia[0] * wv[0], m->cube_inertia[1] * wv[1], m->cube_inertia[2] * wv[2]}, t[3];
+    cross3(t, wv, Iw);
 #pragma unroll
-  for (int c = 0; c < 3; c++) { w.bias[NL + c] = -m->cube_mass * m->gravity[c]; w.bias[NL + 3 + c] = t[c]; }
+    for (int c = 0; c < 3; c++) { w.bias[NL + c] = -m->cube_mass * m->gravity[c]; w.bias[NL + 3 + c] = t[c]; }
+  }
 }
+
 template <int NL, int G>
 __device__ __forceinline__ void bias_project(Ws<NL>& w, const LModel<NL>& lm, int sub) {
   // FN[j] now holds the accumulated wrench of subtree(j) about the world origin
@@ -1252,19 +1309,19 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
                                                CReg<NL>& cr, real invm, Prof& pf) {
+  fk_parallel<NL, G>(w, lm, sub);
+  pf.ph(0);
+  bias_bodies_parallel<NL, G>(w, lm, m, sub);
+  pf.ph(1);
   if (sub == 0) {
-    fk_serial<NL>(w, lm);
-    pf.ph(0);
-    bias_bodies_serial<NL>(w, lm, m);
-    pf.ph(1);
     collide_serial<NL>(w, m);
     if (SOLVER != KM_SOLVER_NEWTON) scalar_rows_serial<NL>(w, lm);
   }
   GSYNC();
   pf.ph(2);
-  composite_own<NL, G>(w, lm, sub);
+  composite_own<NL, G>(w, lm, sub);      // (comp aliases the bias scratch: its last reader is before the barrier above)
   GSYNC();
-  if (sub == 0) composite_accumulate_serial<NL>(w, lm);
+  composite_accumulate<NL, G>(w, lm, sub);
   GSYNC();
   mass_matrix<NL, G>(w, lm, sub);
   bias_project<NL, G>(w, lm, sub);
@@ -1393,7 +1450,9 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
   const KModelDesc* m = &dm->d;
   for (int i = threadIdx.x; i < NL; i += 64) {
     lm.parent[i] = m->link_parent[i]; lm.jtype[i] = m->jnt_type[i]; lm.forcelimited[i] = m->forcelimited[i];
-    lm.anc[i] = dm->x.anc_mask[i];
+    lm.anc[i] = dm->x.anc_mask[i]; lm.desc[i] = dm->x.desc_mask[i];
+    for (int k = 0; k < 4; k++) lm.jump[k][i] = dm->x.jump[k][i];
+    if (i == 0) lm.fk_rounds = dm->x.fk_rounds;
     lm.floss[i] = m->frictionloss[i]; lm.kp[i] = m->kp[i]; lm.mass[i] = m->mass[i]; lm.q_home[i] = m->q_home[i];
     for (int c = 0; c < 3; c++) { lm.pos[i][c] = m->link_pos[i][c]; lm.jaxis[i][c] = m->jnt_axis[i][c]; lm.com[i][c] = m->com[i][c]; lm.inertia[i][c] = m->inertia[i][c]; }
     for (int c = 0; c < 4; c++) lm.quat[i][c] = m->link_quat[i][c];
@@ -1466,7 +1525,8 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   double* obs_row = obs + (size_t)env * m->obs_dim;
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
-    if (sub == 0) { fk_serial<NL>(w, lm); collide_serial<NL>(w, m); }
+    fk_parallel<NL, G>(w, lm, sub);
+    if (sub == 0) collide_serial<NL>(w, m);
     real v2 = gsum<G>(sub < NV ? w.qvel[sub] * w.qvel[sub] : 0.0);
     GSYNC();
     // get_reward, env_sim.py:148-179
