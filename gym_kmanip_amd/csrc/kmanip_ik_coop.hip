@@ -71,11 +71,11 @@ __global__ __launch_bounds__(64) void k_ik_coop_standalone(const KDeviceModel* _
   double* qp = qpos + (size_t)e * nq;
   CoopCtx<N> P;
   P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N;
+  coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? qp[q] : 0.0;
   P.q_prev = x0; P.q_home = m->q_home[q]; P.lb = m->jnt_range[q][0]; P.ub = m->jnt_range[q][1];
-  const int clen = dm->x.chain_len[arm];
-  P.qfix = (clen > N) ? qp[dm->x.chain_link[arm][clen - 1]] : 0.0;
+  P.qfix = (P.clen > N) ? qp[dm->x.chain_link[arm][P.clen - 1]] : 0.0;
   for (int k = 0; k < 3; k++) P.goal_pos[k] = goal_pos[3 * e + k];
   for (int k = 0; k < 4; k++) P.goal_quat[k] = goal_quat[4 * e + k];
   real xl;

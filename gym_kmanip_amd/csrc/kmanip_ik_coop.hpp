@@ -61,7 +61,23 @@ struct CoopCtx {
   real goal_pos[3], goal_quat[4];
   real qfix;                  // joint value of the (at most one) chain link beyond the unknowns
   real q_prev, q_home, lb, ub;
+  // this lane's chain link (position c of the root -> site chain): constant rotation / offset in its parent
+  real cR[9], cp[3];
+  int clen, cslide;           // chain length; 1 if this lane's link is a slide joint
 };
+// per-problem constants of lane c (call once per problem, after arm / c / m / ax are set)
+template <int N>
+__device__ __forceinline__ void coop_chain_setup(CoopCtx<N>& P) {
+  P.clen = P.ax->chain_len[P.arm];
+  const int k = P.c < P.clen ? P.c : 0;
+  const int l = P.ax->chain_link[P.arm][k];
+#pragma unroll
+  for (int i = 0; i < 9; i++) P.cR[i] = P.ax->chain_R[P.arm][k][i];
+  P.cp[0] = P.m->link_pos[l][0]; P.cp[1] = P.m->link_pos[l][1]; P.cp[2] = P.m->link_pos[l][2];
+  P.cslide = P.m->jnt_type[l] == KM_JNT_SLIDE;
+}
+// value of lane (c - S) of the same 8-lane problem (garbage for c < S: callers mask); DPP row_shr
+template <int S> __device__ __forceinline__ real shr8(real v) { return dpp_f64<0x110 + S>(v); }
 
 // all-gather of one value per lane into out[0..N)
 template <int N>
@@ -75,52 +91,68 @@ __device__ __forceinline__ void allgather(real* buf, int c, real v, real* out) {
 
 // ik_res (+ ik_jac when JAC): residual task part ft[6] (uniform), this lane's Jacobian column Jc[6],
 // site position / rotation (uniform).  x = this lane's unknown.
+// Kinematics: lane c builds the transform of chain link c in its parent (its own sincos), an inclusive prefix
+// product over the 8 lanes (3 DPP row-shift rounds) turns it into the link's world transform -- exactly the
+// anchor and axis this lane's Jacobian column needs; the last link's transform is published through LDS.
 template <int N, bool JAC>
 __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft, real* Jc, real* sp_out, real* smat_out) {
   const KModelDesc* m = P.m;
   const int arm = P.arm;
-  real sn = 0, cs = 1;
-  if (P.on) sincos(x, &sn, &cs);
-  real sn_all[N], cs_all[N];
-  allgather<N>(P.L->v0, P.c, sn, sn_all);
-  allgather<N>(P.L->v1, P.c, cs, cs_all);
-  real pos[3] = {0, 0, 0}, mat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  real anc[3] = {0, 0, 0}, axw[3] = {0, 0, 0};
-  const int clen = P.ax->chain_len[arm];
+  const int clen = P.clen;
+  real R[9], p[3];
+  {
+    const real q = P.on ? x : P.qfix;                   // (lane N holds the one fixed link behind the unknowns, if any)
+    p[0] = P.cp[0]; p[1] = P.cp[1]; p[2] = P.cp[2];
+    if (P.c >= clen) {
+      R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+      p[0] = 0; p[1] = 0; p[2] = 0;
+    } else if (P.cslide) {
 #pragma unroll
-  for (int k = 0; k < KM_MAX_CHAIN; k++) {
-    if (k < clen) {
-      const int l = P.ax->chain_link[arm][k];
-      const double* Rl = P.ax->chain_R[arm][k];
-      real lp[3] = {m->link_pos[l][0], m->link_pos[l][1], m->link_pos[l][2]};
-      real t[3], R1[9];
-      mat_vec3(t, mat, lp);
-      pos[0] += t[0]; pos[1] += t[1]; pos[2] += t[2];
+      for (int i = 0; i < 9; i++) R[i] = P.cR[i];
+      p[0] += R[2] * q; p[1] += R[5] * q; p[2] += R[8] * q;
+    } else {
+      real sn, cs;
+      sincos(q, &sn, &cs);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        R[3 * i] = cs * P.cR[3 * i] + sn * P.cR[3 * i + 1];
+        R[3 * i + 1] = cs * P.cR[3 * i + 1] - sn * P.cR[3 * i];
+        R[3 * i + 2] = P.cR[3 * i + 2];
+      }
+    }
+  }
+  static_for<0, 3>([&](auto rc) {
+    constexpr int S = 1 << decltype(rc)::value;
+    real A[9], pa[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) A[i] = shr8<S>(R[i]);
+    pa[0] = shr8<S>(p[0]); pa[1] = shr8<S>(p[1]); pa[2] = shr8<S>(p[2]);
+    if (P.c >= S) {
+      real t[3], Rn[9];
+      mat_vec3(t, A, p);
+      p[0] = t[0] + pa[0]; p[1] = t[1] + pa[1]; p[2] = t[2] + pa[2];
 #pragma unroll
       for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) R1[3 * i + j] = mat[3 * i] * Rl[j] + mat[3 * i + 1] * Rl[3 + j] + mat[3 * i + 2] * Rl[6 + j];
-      if (m->jnt_type[l] == KM_JNT_SLIDE) {
-        // (no slide joint sits on any reference IK chain; kept for generality: unknown value needed, not its sincos)
-        real qv = P.qfix;
-        if (k < N) { real xs[N]; allgather<N>(P.L->v2, P.c, x, xs); qv = xs[k < N ? k : 0]; }
+        for (int j = 0; j < 3; j++) Rn[3 * i + j] = A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j] + A[3 * i + 2] * R[6 + j];
 #pragma unroll
-        for (int i = 0; i < 9; i++) mat[i] = R1[i];
-        pos[0] += R1[2] * qv; pos[1] += R1[5] * qv; pos[2] += R1[8] * qv;
-      } else {
-        real s_k, c_k;
-        if (k < N) { s_k = sn_all[k < N ? k : 0]; c_k = cs_all[k < N ? k : 0]; }
-        else sincos(P.qfix, &s_k, &c_k);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          mat[3 * i] = c_k * R1[3 * i] + s_k * R1[3 * i + 1];
-          mat[3 * i + 1] = c_k * R1[3 * i + 1] - s_k * R1[3 * i];
-          mat[3 * i + 2] = R1[3 * i + 2];
-        }
-      }
-      if (JAC && k < N && P.c == k) { anc[0] = pos[0]; anc[1] = pos[1]; anc[2] = pos[2]; axw[0] = mat[2]; axw[1] = mat[5]; axw[2] = mat[8]; }
+      for (int i = 0; i < 9; i++) R[i] = Rn[i];
     }
+  });
+  // lane GI-1 holds the product over the whole chain (positions >= clen are identities)
+  real* pub = &P.L->J[0][0];
+  if (P.c == GI - 1) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) pub[i] = R[i];
+    pub[9] = p[0]; pub[10] = p[1]; pub[11] = p[2];
   }
+  KM_GSYNC();
+  real mat[9], pos[3];
+#pragma unroll
+  for (int i = 0; i < 9; i++) mat[i] = pub[i];
+  pos[0] = pub[9]; pos[1] = pub[10]; pos[2] = pub[11];
+  KM_GSYNC();
+  const real anc[3] = {p[0], p[1], p[2]}, axw[3] = {R[2], R[5], R[8]};
   real sp[3], smat[9], cur[4], rq[3];
   real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]};
   const double* Rs = P.ax->site_R[arm];
@@ -192,7 +224,15 @@ __device__ __forceinline__ real coop_grad(const CoopCtx<N>& P, real x, const rea
   return s + P.m->ik_jac_reg * (P.m->ik_res_reg_prev * (x - P.q_prev) + P.m->ik_res_reg_home * (x - P.q_home));
 }
 
-// redundant-per-lane Cholesky of (A + alpha I) with A read from the problem's LDS copy; L in registers
+// 1/sqrt(s) to double precision: hardware estimate + two Newton steps (no IEEE sqrt / divide sequences)
+__device__ __forceinline__ real rsqrt_nr(real s) {
+  real y = __builtin_amdgcn_rsq(s);
+  y = y * (1.5 - 0.5 * s * y * y);
+  y = y * (1.5 - 0.5 * s * y * y);
+  return y;
+}
+// redundant-per-lane Cholesky of (A + alpha I) with A read from the problem's LDS copy; L in registers, the
+// diagonal stored INVERTED (L[j][j] = 1 / l_jj) so that the triangular solves multiply instead of divide
 template <int N>
 __device__ __forceinline__ bool chol_reg(const real (*A)[N], real alpha, real (*L)[N]) {
   bool ok = true;
@@ -202,8 +242,8 @@ __device__ __forceinline__ bool chol_reg(const real (*A)[N], real alpha, real (*
 #pragma unroll
     for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
     if (!(s > 0)) { ok = false; s = 1; }
-    real d = sqrt(s), inv = 1.0 / d;
-    L[j][j] = d;
+    const real inv = rsqrt_nr(s);
+    L[j][j] = inv;
 #pragma unroll
     for (int i = j + 1; i < N; i++) {
       real t = A[i][j];
@@ -221,14 +261,14 @@ __device__ __forceinline__ void chol_solve_reg(const real (*L)[N], const real* b
     real s = b[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
-    x[i] = s / L[i][i];
+    x[i] = s * L[i][i];
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; i--) {
     real s = x[i];
 #pragma unroll
     for (int k = i + 1; k < N; k++) s -= L[k][i] * x[k];
-    x[i] = s / L[i][i];
+    x[i] = s * L[i][i];
   }
 }
 template <int N> __device__ __forceinline__ real vdotN(const real* a, const real* b) {
@@ -524,11 +564,11 @@ __device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds
   }
   CoopCtx<N> P;
   P.m = m; P.ax = &dm->x; P.L = L; P.arm = arm; P.c = c; P.on = c < N;
+  coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? io.qpos(q) : 0.0;
   P.q_prev = x0; P.q_home = m->q_home[q]; P.lb = m->jnt_range[q][0]; P.ub = m->jnt_range[q][1];
-  const int clen = dm->x.chain_len[arm];
-  P.qfix = (clen > N) ? io.qpos(dm->x.chain_link[arm][clen - 1]) : 0.0;
+  P.qfix = (P.clen > N) ? io.qpos(dm->x.chain_link[arm][P.clen - 1]) : 0.0;
   const int cp = m->act_col[pos_key[arm]], co = m->act_col[orn_key[arm]], cq = m->act_col[qp_key[arm]];
   if (cp >= 0) {
     // current site pose: one kinematics pass at x0
