@@ -113,6 +113,14 @@ __device__ __forceinline__ void sub_quat(real* res, const real* qa, const real* 
   res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
 }
 
+// 1/sqrt(s) to double precision: hardware estimate + two Newton steps (no IEEE sqrt / divide sequences)
+__device__ __forceinline__ real rsqrt_nr(real s) {
+  real y = __builtin_amdgcn_rsq(s);
+  y = y * (1.5 - 0.5 * s * y * y);
+  y = y * (1.5 - 0.5 * s * y * y);
+  return y;
+}
+
 // cross-lane double move with a DPP control word (a DPP row is 16 lanes)
 template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
   int lo = __double2loint(v), hi = __double2hiint(v);

@@ -58,6 +58,7 @@ struct LModel {
 struct ConRec {
   real mu[3];
   real R;          // regulariser shared by all edges (MuJoCo pyramidal rule)
+  real D;          // 1 / R
   real inv[6];     // 1 / (A_ee + R); 0 for the unused edges of a condim-3 pair
   real den[6];     // A_ee + R
   real aref[6];    // reference acceleration of the edge
@@ -104,8 +105,8 @@ template <int NL> struct CReg {
   real jb[Dim<NL>::NC][4];
   real bb[Dim<NL>::NCF][4];
   real mrow[NL];
-  real fl, Rf, areff;        // friction-loss row x = a - areff          (fl = 0: no row)
-  real sg, Rl, arefl;        // limit row         x = sg * a - arefl     (sg = 0: no row)
+  real fl, Rf, Df, areff;    // friction-loss row x = a - areff          (fl = 0: no row); Df = 1 / Rf
+  real sg, Rl, Dl, arefl;    // limit row         x = sg * a - arefl     (sg = 0: no row); Dl = 1 / Rl
 };
 
 // ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
@@ -944,7 +945,7 @@ __device__ __forceinline__ void chol_rows(real (&h)[N], real& invd, int sub, int
     constexpr int k = decltype(kc)::value;
     real dk = gbcast<G, k>(h[k]);
     if (!(dk > 0)) { bad = 1; dk = 1; }
-    const real inv = 1.0 / sqrt(dk);
+    const real inv = rsqrt_nr(dk);
     const real lik = h[k] * inv;
     h[k] = lik;
     if (sub == k) invd = inv;
@@ -973,8 +974,7 @@ __device__ __forceinline__ real chol_solve_rows(const real (&h)[N], real invd, i
 }
 
 // s_i'(x) and s_i''(x) contributions of one row to the line-search derivatives
-__device__ __forceinline__ void row_ls(int type, real x, real y, real R, real fl, real& d1, real& d2) {
-  const real Dn = 1.0 / R;
+__device__ __forceinline__ void row_ls(int type, real x, real y, real R, real Dn, real fl, real& d1, real& d2) {
   if (type == 0) {
     if (x <= -R * fl) d1 += -fl * y;
     else if (x >= R * fl) d1 += fl * y;
@@ -982,8 +982,7 @@ __device__ __forceinline__ void row_ls(int type, real x, real y, real R, real fl
   } else if (x < 0) { d1 += Dn * x * y; d2 += Dn * y * y; }
 }
 // cost / force / quadratic-zone flag of one row
-__device__ __forceinline__ real row_eval(int type, real x, real R, real fl, real& f, int& quad) {
-  const real Dn = 1.0 / R;
+__device__ __forceinline__ real row_eval(int type, real x, real R, real Dn, real fl, real& f, int& quad) {
   if (type == 0) {
     if (x <= -R * fl) { f = fl; quad = 0; return fl * (-0.5 * R * fl - x); }
     if (x >= R * fl) { f = -fl; quad = 0; return fl * (-0.5 * R * fl + x); }
@@ -1001,7 +1000,7 @@ template <int NL, int G>
 __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
                                                          CReg<NL>& cr, real invm) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
-  cr.fl = 0; cr.Rf = 1; cr.areff = 0; cr.sg = 0; cr.Rl = 1; cr.arefl = 0;
+  cr.fl = 0; cr.Rf = 1; cr.Df = 1; cr.areff = 0; cr.sg = 0; cr.Rl = 1; cr.Dl = 1; cr.arefl = 0;
   if (sub < NV) {
     const real Ad = sub < NL ? w.Minv[sub][sub] : invm;
     const real qv = w.qvel[sub];
@@ -1010,7 +1009,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
     const real fl = sub < NL ? lm.floss[sub] : m->cube_frictionloss;
     if (fl > 0) {
       const real imp = impedance(m->con_def_solimp, 0.0);
-      cr.fl = fl; cr.Rf = fmax(MJ_MINVAL, (1 - imp) / imp * Ad); cr.areff = -bb * qv;
+      cr.fl = fl; cr.Rf = fmax(MJ_MINVAL, (1 - imp) / imp * Ad); cr.Df = 1.0 / cr.Rf; cr.areff = -bb * qv;
     }
     if (sub < NL) {
       const real dl = w.qpos[sub] - lm.range[sub][0], du = lm.range[sub][1] - w.qpos[sub];
@@ -1019,6 +1018,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
         const real imp = impedance(m->con_def_solimp, pos);
         cr.sg = dl < 0 ? 1.0 : -1.0;
         cr.Rl = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+        cr.Dl = 1.0 / cr.Rl;
         cr.arefl = -bb * (cr.sg * qv) - kk * imp * pos;
       }
     }
@@ -1073,6 +1073,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       if (sub == 0) {
         ConRec& rc = w.rec[c];
         rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+        rc.D = 1.0 / rc.R;
         rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2];
 #pragma unroll
         for (int e = 0; e < 6; e++) {
@@ -1111,8 +1112,8 @@ __device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
   real cost = 0.5 * (a - a_s) * Mr;        // per-lane share; summed at the end
   grad = Mr;
   qf = 0; ql = 0;
-  if (cr.fl > 0) { real f; cost += row_eval(0, a - cr.areff, cr.Rf, cr.fl, f, qf); grad -= f; }
-  if (cr.sg != 0) { real f; cost += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, 0.0, f, ql); grad -= cr.sg * f; }
+  if (cr.fl > 0) { real f; cost += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
+  if (cr.sg != 0) { real f; cost += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     qm[c] = 0;
@@ -1127,7 +1128,7 @@ __device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
 #pragma unroll
         for (int k = 0; k < 4; k++) u[k] = rc.inv[k];
       }
-      const real R = rc.R;
+      const real R = rc.R, Dn = rc.D;
       uint32_t q = 0;
       real ce = 0;
 #pragma unroll
@@ -1136,7 +1137,7 @@ __device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
         const int k = e / 2 + 1;
         const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
         real f; int quad;
-        ce += row_eval(1, u[0] + sm * u[k] - rc.aref[e], R, 0.0, f, quad);
+        ce += row_eval(1, u[0] + sm * u[k] - rc.aref[e], R, Dn, 0.0, f, quad);
         F[0] += f; F[k] += sm * f;
         q |= (uint32_t)quad << e;
       }
@@ -1189,8 +1190,8 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     real h[NV];
     {
       real dg = sub < NL ? 0.0 : mdiag;
-      if (qf) dg += 1.0 / cr.Rf;
-      if (ql) dg += 1.0 / cr.Rl;
+      if (qf) dg += cr.Df;
+      if (ql) dg += cr.Dl;
 #pragma unroll
       for (int j = 0; j < NV; j++) h[j] = (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0);
     }
@@ -1199,7 +1200,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
       __builtin_amdgcn_sched_barrier(0);
       if ((act >> c) & 1u) {
         const ConRec& rc = w.rec[c];
-        const real Dn = 1.0 / rc.R;
+        const real Dn = rc.D;
         real W[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
         for (int e = 0; e < 6; e++) {
@@ -1249,18 +1250,18 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     GSYNC();
     // this lane's share of the contact edges, hoisted into registers: x(alpha) = lx + alpha * ly per row
     constexpr int NEQ = (6 * NC + G - 1) / G;
-    real lx[NEQ], ly[NEQ], lR[NEQ];          // contact edges t = sub + G*q  (lR = 0: no row)
+    real lx[NEQ], ly[NEQ], lR[NEQ], lD[NEQ]; // contact edges t = sub + G*q  (lR = 0: no row)
 #pragma unroll
     for (int q = 0; q < NEQ; q++) {
       const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
-      lx[q] = 0; ly[q] = 0; lR[q] = 0;
+      lx[q] = 0; ly[q] = 0; lR[q] = 0; lD[q] = 0;
       const bool valid = c < NC && ((act >> c) & 1u) && !(c >= 4 + Dim<NL>::NSPH && e >= 4);
       if (valid) {
         const ConRec& rc = w.rec[c];
         const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
         lx[q] = rc.inv[0] + sm * rc.inv[k] - rc.aref[e];
         ly[q] = rc.den[0] + sm * rc.den[k];
-        lR[q] = rc.R;
+        lR[q] = rc.R; lD[q] = rc.D;
       }
     }
     const real xf = a - cr.areff, xl = cr.sg * a - cr.arefl, yl = cr.sg * p;
@@ -1268,10 +1269,10 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     real alpha = 0, lo = 0, hi = INFINITY, d1 = 0, d2 = 0, d10 = 0;
     for (int it = 0; it <= 50; it++) {
       real e1 = 0, e2 = 0;
-      if (cr.fl > 0) row_ls(0, xf + alpha * p, p, cr.Rf, cr.fl, e1, e2);
-      if (cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, 0.0, e1, e2);
+      if (cr.fl > 0) row_ls(0, xf + alpha * p, p, cr.Rf, cr.Df, cr.fl, e1, e2);
+      if (cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, cr.Dl, 0.0, e1, e2);
 #pragma unroll
-      for (int q = 0; q < NEQ; q++) if (lR[q] != 0) row_ls(1, lx[q] + alpha * ly[q], ly[q], lR[q], 0.0, e1, e2);
+      for (int q = 0; q < NEQ; q++) if (lR[q] != 0) row_ls(1, lx[q] + alpha * ly[q], ly[q], lR[q], lD[q], 0.0, e1, e2);
       d1 = gp + alpha * pMp + gsum<G>(e1);
       d2 = pMp + gsum<G>(e2);
       if (it == 0) { d10 = d1; if (!(d10 < 0)) break; }

@@ -224,13 +224,6 @@ __device__ __forceinline__ real coop_grad(const CoopCtx<N>& P, real x, const rea
   return s + P.m->ik_jac_reg * (P.m->ik_res_reg_prev * (x - P.q_prev) + P.m->ik_res_reg_home * (x - P.q_home));
 }
 
-// 1/sqrt(s) to double precision: hardware estimate + two Newton steps (no IEEE sqrt / divide sequences)
-__device__ __forceinline__ real rsqrt_nr(real s) {
-  real y = __builtin_amdgcn_rsq(s);
-  y = y * (1.5 - 0.5 * s * y * y);
-  y = y * (1.5 - 0.5 * s * y * y);
-  return y;
-}
 // redundant-per-lane Cholesky of (A + alpha I) with A read from the problem's LDS copy; L in registers, the
 // diagonal stored INVERTED (L[j][j] = 1 / l_jj) so that the triangular solves multiply instead of divide
 template <int N>
