@@ -51,6 +51,9 @@ struct LModel {
   real pos[NL][3], quat[NL][4], jaxis[NL][3], range[NL][2], floss[NL], kp[NL], ctrlrange[NL][2], forcerange[NL][2];
   real mass[NL], com[NL][3], inertia[NL][3], q_home[NL];
   real R[NL][9];        // constant rotation of each link in its parent (from link_quat)
+  // soft-constraint constants of the two parameter sets (0 = default pairs / joint rows, 1 = pairs with the cube):
+  // stiffness k, damping b (mj_makeImpedance / solref), impedance at zero distance
+  real kb[2][2], imp0[2];
 };
 
 // Solver view of one pyramidal contact (group-uniform scalars).  Basis index 0 = normal, 1..2 = tangents,
@@ -493,33 +496,43 @@ __device__ __forceinline__ void make_frame(real* fr) {
   cross3(fr + 6, fr, fr + 3);
 }
 
+// contact frame of every contact whose normal is the table normal (+z): mju_makeFrame((0,0,1)) = rows n, t1, t2
+#define KM_PLANE_FRAME {0, 0, 1, 0, 1, 0, -1, 0, 0}
 // narrow phase for the fixed candidate set, written into fixed slots: plane-box (first 4 corners below the
-// table -> slots 0..3 in corner order), sphere-box (slot 4 + s), plane-sphere (slot 4 + NSPH + s)
-template <int NL>
-__device__ __forceinline__ void collide_serial(Ws<NL>& w, const KModelDesc* m) {
+// table -> slots 0..3 in corner order), sphere-box (slot 4 + s), plane-sphere (slot 4 + NSPH + s).
+// One candidate per lane: lanes 0..7 test the cube corners (slot = rank among the penetrating corners, from the
+// group's ballot bits), lanes 8..8+NSPH-1 their finger sphere against cube and table.
+template <int NL, int G>
+__device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub) {
   constexpr int NSPH = Dim<NL>::NSPH;
-  int cnt = 0;
+  static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
-  int tfc = 0, tct = 0;
-  real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
-  for (int i = 0; i < 8 && cnt < 4; i++) {
-    real loc[3] = {(i & 1 ? 1 : -1) * m->cube_half[0], (i & 2 ? 1 : -1) * m->cube_half[1], (i & 4 ? 1 : -1) * m->cube_half[2]}, c[3];
+  const real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
+  bool below = false;
+  real c[3] = {0, 0, 0}, dist = 0;
+  if (sub < 8) {
+    const real loc[3] = {(sub & 1 ? 1 : -1) * m->cube_half[0], (sub & 2 ? 1 : -1) * m->cube_half[1], (sub & 4 ? 1 : -1) * m->cube_half[2]};
     mat_vec3(c, w.k.cube_mat, loc);
     c[0] += cp[0]; c[1] += cp[1]; c[2] += cp[2];
-    real dist = c[2] - m->table_z;
-    if (dist < 0) {
-      const int n = cnt;
-      real fr[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0};
-      make_frame(fr);
+    dist = c[2] - m->table_z;
+    below = dist < 0;
+  }
+  const unsigned long long bal = __ballot(below);
+  const uint32_t m8 = (uint32_t)(bal >> ((threadIdx.x & 63) - sub)) & 0xFFu;
+  if (below) {
+    const int n = __popc(m8 & ((1u << sub) - 1u));
+    if (n < 4) {
+      const real fr[9] = KM_PLANE_FRAME;
 #pragma unroll
       for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
       w.c_dist[n] = dist;
       w.c_pos[n][0] = c[0]; w.c_pos[n][1] = c[1]; w.c_pos[n][2] = c[2] - 0.5 * dist;
-      mask |= KM_CON_CUBE_TABLE(i); act |= 1u << n; tct = 1; cnt++;
+      mask |= KM_CON_CUBE_TABLE(sub); act |= 1u << n;
     }
   }
   const int nsph = m->nsphere < NSPH ? m->nsphere : NSPH;
-  for (int s = 0; s < nsph; s++) {
+  if (sub >= 8 && sub < 8 + nsph) {
+    const int s = sub - 8;
     const int l = m->sphere_link[s];
     real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, ctr[3], rel[3], loc[3], cl[3];
     mat_vec3(ctr, w.k.xmat[l], sl);
@@ -531,11 +544,11 @@ __device__ __forceinline__ void collide_serial(Ws<NL>& w, const KModelDesc* m) {
     bool inside = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) { cl[a] = fmin(fmax(loc[a], -m->cube_half[a]), m->cube_half[a]); if (cl[a] != loc[a]) inside = false; }
-    real nloc[3], dist;
+    real nloc[3], d1;
     if (!inside) {
       nloc[0] = cl[0] - loc[0]; nloc[1] = cl[1] - loc[1]; nloc[2] = cl[2] - loc[2];
       real dn = normalize3(nloc);
-      dist = dn - rad;
+      d1 = dn - rad;
     } else {
       int best = 0; real bd = INFINITY;
 #pragma unroll
@@ -543,34 +556,38 @@ __device__ __forceinline__ void collide_serial(Ws<NL>& w, const KModelDesc* m) {
       nloc[0] = 0; nloc[1] = 0; nloc[2] = 0;
       real sg = (best == 0 ? loc[0] : (best == 1 ? loc[1] : loc[2])) >= 0 ? -1.0 : 1.0;
       if (best == 0) nloc[0] = sg; else if (best == 1) nloc[1] = sg; else nloc[2] = sg;
-      dist = -bd - rad;
+      d1 = -bd - rad;
     }
-    if (dist < 0) {
+    if (d1 < 0) {
       const int n = 4 + s;
       real fr[9];
       mat_vec3(fr, w.k.cube_mat, nloc);
       make_frame(fr);
 #pragma unroll
       for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
-      w.c_dist[n] = dist;
+      w.c_dist[n] = d1;
 #pragma unroll
-      for (int a = 0; a < 3; a++) w.c_pos[n][a] = ctr[a] + fr[a] * (rad + 0.5 * dist);
-      mask |= KM_CON_FINGER_CUBE(s); act |= 1u << n; tfc = 1;
+      for (int a = 0; a < 3; a++) w.c_pos[n][a] = ctr[a] + fr[a] * (rad + 0.5 * d1);
+      mask |= KM_CON_FINGER_CUBE(s); act |= 1u << n;
     }
     // table plane (geom1) - sphere (geom2)
-    real dist2 = ctr[2] - m->table_z - rad;
-    if (dist2 < 0) {
+    const real d2 = ctr[2] - m->table_z - rad;
+    if (d2 < 0) {
       const int n = 4 + NSPH + s;
-      real fr[9] = {0, 0, 1, 0, 0, 0, 0, 0, 0};
-      make_frame(fr);
+      const real fr[9] = KM_PLANE_FRAME;
 #pragma unroll
       for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
-      w.c_dist[n] = dist2;
-      w.c_pos[n][0] = ctr[0]; w.c_pos[n][1] = ctr[1]; w.c_pos[n][2] = ctr[2] - (rad + 0.5 * dist2);
+      w.c_dist[n] = d2;
+      w.c_pos[n][0] = ctr[0]; w.c_pos[n][1] = ctr[1]; w.c_pos[n][2] = ctr[2] - (rad + 0.5 * d2);
       mask |= KM_CON_FINGER_TABLE(s); act |= 1u << n;
     }
   }
-  w.cact = act; w.contact_mask = mask; w.touch_fc = tfc; w.touch_ct = tct;
+  mask = (uint32_t)gor<G>((int)mask);
+  act = (uint32_t)gor<G>((int)act);
+  if (sub == 0) {
+    w.cact = act; w.contact_mask = mask;
+    w.touch_fc = (mask & (0xFu << 8)) != 0; w.touch_ct = (mask & 0xFFu) != 0;
+  }
 }
 
 // MuJoCo impedance / reference acceleration parameters
@@ -992,6 +1009,25 @@ __device__ __forceinline__ real row_eval(int type, real x, real R, real Dn, real
   f = 0; quad = 0; return 0;
 }
 
+// The six cube components of a lane-distributed vector, on every lane: linear part and the angular part turned
+// into the world frame (the free joint's angular velocity is expressed in the body frame).
+template <int NL, int G>
+__device__ __forceinline__ void cube_part(const Ws<NL>& w, real x, real* lin, real* angw) {
+  lin[0] = gbcast<G, NL>(x); lin[1] = gbcast<G, NL + 1>(x); lin[2] = gbcast<G, NL + 2>(x);
+  const real ab[3] = {gbcast<G, NL + 3>(x), gbcast<G, NL + 4>(x), gbcast<G, NL + 5>(x)};
+  mat_vec3(angw, w.k.cube_mat, ab);
+}
+// J_c x for a table-cube contact (slots 0..3: only the cube moves, plane frame): the velocity of the contact point
+// read off in the frame -- no cross-lane reduction.  u = (normal, tangent 1, tangent 2, torsion).
+template <int NL>
+__device__ __forceinline__ void plane_proj(const Ws<NL>& w, int c, const real* lin, const real* angw, real* u) {
+  const real r[3] = {w.c_pos[c][0] - w.qpos[NL], w.c_pos[c][1] - w.qpos[NL + 1], w.c_pos[c][2] - w.qpos[NL + 2]};
+  real v[3];
+  cross3(v, angw, r);
+  v[0] += lin[0]; v[1] += lin[1]; v[2] += lin[2];
+  u[0] = v[2]; u[1] = v[1]; u[2] = -v[0]; u[3] = angw[2];     // KM_PLANE_FRAME rows
+}
+
 // Constraint assembly for Newton: like build_constraints but no B = M^-1 J^T / Gram tables -- only the
 // first-edge diagonal (for MuJoCo's pyramidal regulariser) and the velocity projections (for aref).  The
 // single-dof rows (friction loss, joint limits) of dof `sub` are built into this lane's registers: the primal
@@ -1004,11 +1040,10 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   if (sub < NV) {
     const real Ad = sub < NL ? w.Minv[sub][sub] : invm;
     const real qv = w.qvel[sub];
-    real kk, bb;
-    get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
+    const real kk = lm.kb[0][0], bb = lm.kb[0][1];
     const real fl = sub < NL ? lm.floss[sub] : m->cube_frictionloss;
     if (fl > 0) {
-      const real imp = impedance(m->con_def_solimp, 0.0);
+      const real imp = lm.imp0[0];
       cr.fl = fl; cr.Rf = fmax(MJ_MINVAL, (1 - imp) / imp * Ad); cr.Df = 1.0 / cr.Rf; cr.areff = -bb * qv;
     }
     if (sub < NL) {
@@ -1044,6 +1079,8 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   }
   GSYNC();
   const real qv = sub < NV ? w.qvel[sub] : 0.0;
+  real qlin[3], qangw[3];
+  cube_part<NL, G>(w, qv, qlin, qangw);
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     __builtin_amdgcn_sched_barrier(0);
@@ -1065,11 +1102,14 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       }
       const real Ad = gsum<G>(v * Mv);
       real vb[4];
+      if (kind == 0) plane_proj<NL>(w, c, qlin, qangw, vb);
+      else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) vb[k] = gsum<G>(cr.jb[c][k] * qv);
+        for (int k = 0; k < 4; k++) vb[k] = gsum<G>(cr.jb[c][k] * qv);
+      }
       const real dist = w.c_dist[c];
-      real imp = impedance(si, dist), kk, bb;
-      get_kb(m, sr, si, kk, bb);
+      const real imp = impedance(si, dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
+      (void)sr;
       if (sub == 0) {
         ConRec& rc = w.rec[c];
         rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
@@ -1109,6 +1149,8 @@ __device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
                                             real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC]) {
   constexpr int NC = Dim<NL>::NC;
   const uint32_t act = w.cact;
+  real alin[3] = {0, 0, 0}, aangw[3] = {0, 0, 0};
+  if constexpr (PROJECT) cube_part<NL, G>(w, a, alin, aangw);
   real cost = 0.5 * (a - a_s) * Mr;        // per-lane share; summed at the end
   grad = Mr;
   qf = 0; ql = 0;
@@ -1121,8 +1163,11 @@ __device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
       const ConRec& rc = w.rec[c];
       real u[4], F[4] = {0, 0, 0, 0};
       if constexpr (PROJECT) {
+        if constexpr (slot_kind<NL>(c) == 0) plane_proj<NL>(w, c, alin, aangw, u);
+        else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
+          for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
+        }
         if (sub == 0) { w.rec[c].inv[0] = u[0]; w.rec[c].inv[1] = u[1]; w.rec[c].inv[2] = u[2]; w.rec[c].inv[3] = u[3]; }
       } else {
 #pragma unroll
@@ -1238,12 +1283,17 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     const real Mp = mass_mul<NL, G>(cr, sub, mdiag, p);
     const real gp = gsum<G>(p * Mr), pMp = gsum<G>(p * Mp);
     // per-contact projections of p, parked next to those of a in the records (den[] slots)
+    real plin[3], pangw[3];
+    cube_part<NL, G>(w, p, plin, pangw);
     static_for<0, NC>([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       if ((act >> c) & 1u) {
         real y[4];
+        if constexpr (slot_kind<NL>(c) == 0) plane_proj<NL>(w, c, plin, pangw, y);
+        else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) y[k] = gsum<G>(cr.jb[c][k] * p);
+          for (int k = 0; k < 4; k++) y[k] = gsum<G>(cr.jb[c][k] * p);
+        }
         if (sub == 0) { w.rec[c].den[0] = y[0]; w.rec[c].den[1] = y[1]; w.rec[c].den[2] = y[2]; w.rec[c].den[3] = y[3]; }
       }
     });
@@ -1314,10 +1364,8 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   pf.ph(0);
   bias_bodies_parallel<NL, G>(w, lm, m, sub);
   pf.ph(1);
-  if (sub == 0) {
-    collide_serial<NL>(w, m);
-    if (SOLVER != KM_SOLVER_NEWTON) scalar_rows_serial<NL>(w, lm);
-  }
+  collide_parallel<NL, G>(w, m, sub);
+  if (SOLVER != KM_SOLVER_NEWTON && sub == 0) scalar_rows_serial<NL>(w, lm);
   GSYNC();
   pf.ph(2);
   composite_own<NL, G>(w, lm, sub);      // (comp aliases the bias scratch: its last reader is before the barrier above)
@@ -1453,7 +1501,13 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
     lm.parent[i] = m->link_parent[i]; lm.jtype[i] = m->jnt_type[i]; lm.forcelimited[i] = m->forcelimited[i];
     lm.anc[i] = dm->x.anc_mask[i]; lm.desc[i] = dm->x.desc_mask[i];
     for (int k = 0; k < 4; k++) lm.jump[k][i] = dm->x.jump[k][i];
-    if (i == 0) lm.fk_rounds = dm->x.fk_rounds;
+    if (i == 0) {
+      lm.fk_rounds = dm->x.fk_rounds;
+      get_kb(m, m->con_def_solref, m->con_def_solimp, lm.kb[0][0], lm.kb[0][1]);
+      get_kb(m, m->con_cube_solref, m->con_cube_solimp, lm.kb[1][0], lm.kb[1][1]);
+      lm.imp0[0] = impedance(m->con_def_solimp, 0.0);
+      lm.imp0[1] = impedance(m->con_cube_solimp, 0.0);
+    }
     lm.floss[i] = m->frictionloss[i]; lm.kp[i] = m->kp[i]; lm.mass[i] = m->mass[i]; lm.q_home[i] = m->q_home[i];
     for (int c = 0; c < 3; c++) { lm.pos[i][c] = m->link_pos[i][c]; lm.jaxis[i][c] = m->jnt_axis[i][c]; lm.com[i][c] = m->com[i][c]; lm.inertia[i][c] = m->inertia[i][c]; }
     for (int c = 0; c < 4; c++) lm.quat[i][c] = m->link_quat[i][c];
@@ -1527,7 +1581,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
-    if (sub == 0) collide_serial<NL>(w, m);
+    collide_parallel<NL, G>(w, m, sub);
     real v2 = gsum<G>(sub < NV ? w.qvel[sub] * w.qvel[sub] : 0.0);
     GSYNC();
     // get_reward, env_sim.py:148-179
