@@ -117,6 +117,8 @@ template <int NL> struct CReg {
 #define KM_NPH 16
 #ifdef KM_PROFILE
 __device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
+#define KM_PROF_BLOCKS 4096
+__device__ unsigned long long g_prof_blk[KM_PROF_BLOCKS][KM_NPH];   // last launch, per workgroup (who is the slowest wave?)
 struct Prof {
   unsigned long long t0, acc[KM_NPH];
   __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
@@ -126,13 +128,19 @@ struct Prof {
     acc[i] += t - t0; t0 = t;
     __builtin_amdgcn_sched_barrier(0);
   }
-  __device__ __forceinline__ void flush() { if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) atomicAdd(&g_prof[i], acc[i]); }
+  __device__ __forceinline__ void flush() {
+    if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) { atomicAdd(&g_prof[i], acc[i]); if (blockIdx.x < KM_PROF_BLOCKS) g_prof_blk[blockIdx.x][i] = acc[i]; }
+  }
 };
 #if KM_VAR_NL == 10 && KM_VAR_SOLVER == 1
 extern "C" int kmanip_dbg_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * KM_NPH) != hipSuccess) return -1;
   if (reset) { unsigned long long z[KM_NPH] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1; }
   return 0;
+}
+extern "C" int kmanip_dbg_prof_blocks(unsigned long long* out, int nblocks) {
+  if (nblocks > KM_PROF_BLOCKS) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_blk), sizeof(unsigned long long) * KM_NPH * nblocks) == hipSuccess ? 0 : -1;
 }
 #endif
 #else

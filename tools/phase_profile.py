@@ -32,6 +32,20 @@ print("solver", solver, "total ticks per block per step %.0f" % tot)
 for nm, x in zip(names, per):
     print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / tot))
 
+# ---- per-workgroup view of the LAST launch: the kernel ends when its slowest wave does
+nb = n // 4
+blk = (C.c_ulonglong * (16 * nb))()
+if hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) == 0:
+    B = np.array(list(blk), dtype=np.float64).reshape(nb, 16)
+    tot_b = B.sum(1)
+    order = np.argsort(tot_b)
+    print("last launch: wave totals  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
+        tot_b.mean(), np.median(tot_b), np.percentile(tot_b, 90), np.percentile(tot_b, 99), tot_b.max()))
+    print("  phase                      mean-wave   slowest-wave   mean of 10 slowest")
+    slow = order[-10:]
+    for i, nm in enumerate(names):
+        print("  %-26s %10.0f %12.0f %14.0f" % (nm, B[:, i].mean(), B[order[-1], i], B[slow, i].mean()))
+
 # ---- IK kernel phases
 names_ik = ["initial eval+grad", "scaling + normal matrix", "trust-region solve", "select_step", "trial eval (res+jac)", "accept/grad", "tail (divergence wait)", "-"]
 bi = (C.c_ulonglong * 8)()
