@@ -116,7 +116,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=64, help="untimed steps (default: one full 64-step episode, so timed steps see the steady-state mix)")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--env", default="KManipSoloArm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
