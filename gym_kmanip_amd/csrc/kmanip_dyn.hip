@@ -75,27 +75,35 @@ struct Ws {
   union {
     // kinematics: live from fk() to the end of the contact-Jacobian build ...
     struct { real xpos[NL][3], xquat[NL][4], xmat[NL][9], axis[NL][3], cpos[NL][3], cube_mat[9]; } k;
+#if KM_VAR_SOLVER == KM_SOLVER_PGS
     // ... then the same bytes hold the per-edge Gram rows Ge[c][e][l] = J_l . M^-1 (J_0 + sm J_k)^T for PGS
     struct { real Ge[NC][6][4]; } p;
+#endif
     // ... and, before any of that, the per-arm scratch of the fused decode + IK (before_step)
     CoopLds<7> ik[NL > 10 ? 2 : 1];
   };
   real Minv[NL][NL];       // joint-space inertia, overwritten by its inverse
-  real Mm[NL][NL];         // copy of the joint-space inertia itself (Newton: Gauss term and Hessian)
   union {
-    struct { union { real Lw[NL][NL]; real comp[NL][10]; }; real FN[NL][6]; } f;   // Cholesky workspace | composite inertias; bias wrenches
+    struct { union { real bsc[NL][9]; real comp[NL][10]; }; real FN[NL][6]; } f;   // bias-pass scratch | composite inertias; bias wrenches
+#if KM_VAR_SOLVER == KM_SOLVER_PGS
     real stage[4][NV];                               // staging of basis rows for B = M^-1 J^T
+#endif
     ConRec rec[NC];                                  // solver records (built last)
   };
-  real bias[NV], as[NV], tmp[NV], tmp2[NV], tmp3[NV];
+  real bias[NV], tmp[NV];
+#if KM_VAR_SOLVER == KM_SOLVER_PGS
+  real as[NV], tmp2[NV], tmp3[NV];
+#endif
   real Mtrace;
   int ns, bad, touch_fc, touch_ct;
   uint32_t contact_mask;   // KM_CON_* bits (which candidate pairs touch)
   uint32_t cact;           // active contact slots
   // single-dof constraint rows on ARM dofs (friction loss, then limits); the cube's friction-loss rows are
   // lane-local registers
+#if KM_VAR_SOLVER == KM_SOLVER_PGS
   int s_dof[NS], s_type[NS], s_quad[NS];
   real s_sign[NS], s_pos[NS], s_f[NS], s_R[NS], s_aref[NS], s_den[NS], s_inv[NS], s_floss[NS];
+#endif
   // contact geometry per slot
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
 };
@@ -361,10 +369,9 @@ __device__ __forceinline__ void mass_symmetrize(Ws<NL>& w, int sub) {
 //   a_i     = -g + sum_j d_j,      d_j  = alpha_p x r_j + omega_p x (omega_p x r_j) (+ 2 cz_j for a slide)
 template <int NL, int G>
 __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub) {
-  real* wvb = &w.f.Lw[0][0];            // [NL][3] each
+  real* wvb = &w.f.bsc[0][0];           // [NL][3] each
   real* czb = wvb + 3 * NL;
   real* dbb = czb + 3 * NL;
-  static_assert(9 * NL <= NL * NL, "bias scratch must fit the Cholesky workspace it aliases");
   const bool on = sub < NL;
   const bool slide = on && lm.jtype[sub] == KM_JNT_SLIDE;
   const uint32_t up = on ? (lm.anc[sub] & ~(1u << sub)) : 0u;       // proper ancestors
@@ -463,10 +470,6 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
   GSYNC();
 #pragma unroll
   for (int j = 0; j < NL; j++) cr.mrow[j] = a[j];
-  if (sub < NL) {
-#pragma unroll
-    for (int j = 0; j < NL; j++) w.Mm[sub][j] = a[j];
-  }
   int bad = 0;
   static_for<0, NL>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
@@ -1373,7 +1376,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   bias_bodies_parallel<NL, G>(w, lm, m, sub);
   pf.ph(1);
   collide_parallel<NL, G>(w, m, sub);
-  if (SOLVER != KM_SOLVER_NEWTON && sub == 0) scalar_rows_serial<NL>(w, lm);
+  if constexpr (SOLVER != KM_SOLVER_NEWTON) { if (sub == 0) scalar_rows_serial<NL>(w, lm); }
   GSYNC();
   pf.ph(2);
   composite_own<NL, G>(w, lm, sub);      // (comp aliases the bias scratch: its last reader is before the barrier above)
@@ -1386,17 +1389,19 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   pf.ph(3);
   invert_mass<NL, G>(w, sub, cr);
   pf.ph(4);
-  if (SOLVER == KM_SOLVER_NEWTON) build_constraints_newton<NL, G>(w, lm, m, sub, cr, invm);
+  if constexpr (SOLVER == KM_SOLVER_NEWTON) build_constraints_newton<NL, G>(w, lm, m, sub, cr, invm);
   else build_constraints<NL, G>(w, lm, m, sub, cr, invm);
   pf.ph(5);
 }
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ real solve(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
                                       CReg<NL>& cr, real invm, Prof& pf) {
-  if (SOLVER == KM_SOLVER_NEWTON) return solve_newton<NL, G>(w, lm, m, sub, actuation, cr, invm, pf);
-  real a = solve_accel<NL, G>(w, lm, m, sub, actuation, cr, invm);
-  pf.ph(6);
-  return a;
+  if constexpr (SOLVER == KM_SOLVER_NEWTON) return solve_newton<NL, G>(w, lm, m, sub, actuation, cr, invm, pf);
+  else {
+    real a = solve_accel<NL, G>(w, lm, m, sub, actuation, cr, invm);
+    pf.ph(6);
+    return a;
+  }
 }
 
 // mj_Euler: qvel += dt*qacc, then positions with the NEW velocity (semi-implicit); free-joint quaternion
