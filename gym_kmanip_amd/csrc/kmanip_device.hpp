@@ -33,6 +33,11 @@ struct KDeviceModel {
 
 typedef double real;
 
+// The small vector / quaternion helpers below are shared by the IK and the physics code.  They are compiled with FMA
+// contraction OFF (see kmanip_ik_coop.hpp: the IK must take the same discrete decisions as the oracle); the physics
+// translation unit switches contraction back on for its own code after including the headers.
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(real* r, const real* a, const real* b) {
   real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
@@ -134,14 +139,15 @@ template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
 template <int G, int K> __device__ __forceinline__ real gbcast(real v) {
   static_assert(G == 8 || G == 16 || G == 32, "group = half a DPP row, one row or two rows");
   if constexpr (G == 32) {
-    const real b = dpp_f64<0x150 + (K & 15)>(v);
+    const real b = __builtin_amdgcn_update_dpp(v, v, 0x150 + (K & 15), 0xF, 0xF, false);
     const unsigned lo = (unsigned)__double2loint(b), hi = (unsigned)__double2hiint(b);
     const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
     const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     constexpr int w = (K >> 4) & 1;
     return __hiloint2double((int)rh[w], (int)rl[w]);
   } else {
-    return dpp_f64<0x150 + K>(v);      // G == 8 callers pass K already offset into the row
+    // one v_mov_b64_dpp: gfx90a+ DPP on 64-bit operands exists for exactly this control (row_newbcast)
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false);      // G == 8 callers pass K already offset into the row
   }
 }
 // compile-time counted loop: f(std::integral_constant<int, K>) for K in [K0, N)

@@ -17,6 +17,11 @@
 // kernel into 0.5-1.5 KB of scratch per lane.
 #pragma once
 #include "kmanip_device.hpp"
+// FMA contraction stays OFF for the decode + IK code, wherever it is compiled: TRF takes discrete decisions (step
+// acceptance, termination tests, the "last evaluated point" the reference teleports qpos to) and the parity tests
+// demand the same decisions as the oracle, whose C is compiled without fused multiply-adds.  The physics code
+// converges to a unique minimiser per sub-step and is compiled with contraction on.
+#pragma clang fp contract(off)
 
 #define GI 8            // lanes per problem
 #define PPW (64 / GI)   // problems per wave / workgroup
@@ -594,3 +599,7 @@ __device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds
       io.set_ctrl(q, f32r_c(x0 + (double)(a[cq + c] * (float)m->q_pos_delta)));
   }
 }
+
+#ifdef KM_VAR_NL
+#pragma clang fp contract(fast)     // back to the physics translation unit's setting (see the note at the top)
+#endif

@@ -6,7 +6,7 @@ calls (reference gym_kmanip/ik_mujoco.py:129-135) and scipy.spatial.transform.Ro
 euler/quaternion decode of env_sim.py:66-69) run here.  MuJoCo is not installed, so its helper
 calls (mj_kinematics, mj_jacSite, mju_mat2Quat, mju_subQuat, mjd_subQuat) are restated in NumPy
 from the public MuJoCo source/documentation.  It pins the C oracle's IK (tests/test_oracle_ik.py)
-and produces tests/golden/ik_*.npz through tools/make_golden.py.
+and produces tests/golden/ik_*.npz through tests/tools/make_golden.py.
 
 Functions follow the reference one-to-one:
   ik_res  <- ik_mujoco.py:20-53      ik_jac <- ik_mujoco.py:56-97      ik <- ik_mujoco.py:100-155

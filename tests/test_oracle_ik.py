@@ -1,5 +1,5 @@
 """Oracle pinning: the C restatement of ik_mujoco.py + SciPy TRF against (a) fixtures produced by the
-real scipy.optimize.least_squares (tests/golden/ik_scipy_*.npz, tools/make_golden.py) and (b) a live
+real scipy.optimize.least_squares (tests/golden/ik_scipy_*.npz, tests/tools/make_golden.py) and (b) a live
 SciPy run on fresh seeds.  CPU only."""
 import os
 

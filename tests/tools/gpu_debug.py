@@ -1,7 +1,7 @@
 """Ad-hoc GPU-vs-oracle comparison (debug aid; the real parity tests live in tests/test_gpu_*.py)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 from gym_kmanip_amd.model import compile_model
 from gym_kmanip_amd import env_hip

@@ -9,14 +9,14 @@ Sources of truth, per file:
   traj_<env>.npz       C oracle 64-step trajectories with a seeded action stream -> pins the HIP
                        step (oracle-vs-oracle regression on CPU).
   philox_kat.npz       published Random123 philox4x32-10 known-answer vectors.
-Run in the build container: python tools/make_golden.py
+Run in the build container: python tests/tools/make_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 
 from gym_kmanip_amd.model import compile_model  # noqa: E402
