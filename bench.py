@@ -211,9 +211,9 @@ def main():
                          "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1)},
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }
-        if not args.no_pgs_variant and args.solver == "newton":
+        if not args.no_pgs_variant and args.solver == "newton" and world == 1:
             out["pgs_variant"] = measure_variant(args.env, "pgs", n, local_rank, rank)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(cm, n)
             out["cpu_baseline"]["solver"] = args.solver
         print(json.dumps(out), flush=True)

@@ -1689,8 +1689,8 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
 
 // envs per workgroup: as many waves as the chip has SIMD slots for, but no more lanes idle than needed.
 static int pick_epb(int num_envs, int max_epb) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("KMANIP_EPB"); forced = e ? atoi(e) : 0; }
+  const char* e = getenv("KMANIP_EPB");              // diagnostic override (tests exercise every launch shape)
+  const int forced = e ? atoi(e) : 0;
   if (forced > 0) return forced < max_epb ? forced : max_epb;
   int epb = max_epb;
   while (epb > 1 && (num_envs + epb - 1) / epb < KM_TARGET_WAVES) epb >>= 1;

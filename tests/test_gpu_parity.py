@@ -261,3 +261,59 @@ def test_render_depth_config5_size():
     a = e.render_depth("grip_r", 64, 64); b = e.render_depth("grip_r", 64, 64)
     assert a.shape == (2048, 64, 64) and torch.equal(a, b) and torch.isfinite(a).all()
     e.k_close()
+
+
+@pytest.mark.parametrize("env", ["KManipSoloArm", "KManipTorso"])
+def test_fused_and_split_launches_agree(env, monkeypatch):
+    """The product path runs before_step inside k_step; KMANIP_IK_UNFUSED=1 (and the one-lane KMANIP_IK_SERIAL=1
+    kernel) keep it as separate launches.  Same device code on the same inputs => bit-identical state/obs/reward."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    n = 96
+    cm = compile_model(env)
+    envs = {}
+    for name, var in (("fused", None), ("split", "KMANIP_IK_UNFUSED"), ("serial", "KMANIP_IK_SERIAL")):
+        monkeypatch.delenv("KMANIP_IK_UNFUSED", raising=False); monkeypatch.delenv("KMANIP_IK_SERIAL", raising=False)
+        if var:
+            monkeypatch.setenv(var, "1")
+        envs[name] = env_hip.KManipEnvHip(cm, num_envs=n, seed=9)      # the switch is read at kmanip_create
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4)
+    for e in envs.values():
+        e.k_reset()
+    for k in range(70):                                                    # crosses the 64-step auto-reset
+        act = torch.rand((n, cm.act_dim), generator=gen, device="cuda") * 2 - 1
+        for e in envs.values():
+            e.step_flat(act)
+        f, s = envs["fused"], envs["split"]
+        assert torch.equal(f.obs, s.obs) and torch.equal(f.reward, s.reward) and torch.equal(f.done, s.done), k
+    for x, y in zip(envs["fused"].get_state(), envs["split"].get_state()):
+        assert np.array_equal(x, y)
+    df, ds = envs["fused"].get_diag(), envs["split"].get_diag()
+    for x, y in zip(df, ds):
+        assert np.array_equal(x, y)
+    # the serial kernel is a different implementation of the same TRF (one lane per problem): tolerance, not bits
+    sf, ss = envs["fused"].get_state(), envs["serial"].get_state()
+    assert np.abs(sf[0] - ss[0]).max() < TOL_Q and np.abs(sf[1] - ss[1]).max() < TOL_V
+    for e in envs.values():
+        e.k_close()
+
+
+@pytest.mark.parametrize("n,epb", [(1, None), (5, None), (37, "1"), (37, "2"), (300, None)])
+def test_small_batches_and_launch_shapes(n, epb, monkeypatch):
+    """Ragged / tiny batches and every envs-per-workgroup launch shape (KMANIP_EPB) against the oracle."""
+    torch = _torch()
+    if epb:
+        monkeypatch.setenv("KMANIP_EPB", epb)
+    cm, dev, orc = _mk("KManipSoloArm", n, seed=21, off=7)
+    dev.k_reset(); orc.reset()
+    rng = np.random.default_rng(n)
+    for k in range(20):
+        act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda()); obs_o, rew_o, done_o = orc.step(act)
+        _cmp_state(dev, orc, k)
+        assert np.abs(dev.obs.cpu().numpy() - obs_o).max() < TOL_Q
+        assert np.abs(dev.reward.cpu().numpy() - rew_o).max() < TOL_R
+        assert np.array_equal(dev.done.cpu().numpy(), done_o)
+    mg, nf, st = dev.get_diag(); mo, nfo, sto = orc.get_diag()
+    assert np.array_equal(mg, mo) and np.array_equal(nf[:, 0], nfo[:, 0]) and np.array_equal(st[:, 0], sto[:, 0])
+    dev.k_close()
