@@ -33,10 +33,6 @@ struct KDeviceModel {
 
 typedef double real;
 
-// The small vector / quaternion helpers below are shared by the IK and the physics code.  They are compiled with FMA
-// contraction OFF (see kmanip_ik_coop.hpp: the IK must take the same discrete decisions as the oracle); the physics
-// translation unit switches contraction back on for its own code after including the headers.
-#pragma clang fp contract(off)
 
 __device__ __forceinline__ real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(real* r, const real* a, const real* b) {

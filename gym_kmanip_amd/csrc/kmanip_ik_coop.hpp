@@ -17,11 +17,10 @@
 // kernel into 0.5-1.5 KB of scratch per lane.
 #pragma once
 #include "kmanip_device.hpp"
-// FMA contraction stays OFF for the decode + IK code, wherever it is compiled: TRF takes discrete decisions (step
-// acceptance, termination tests, the "last evaluated point" the reference teleports qpos to) and the parity tests
-// demand the same decisions as the oracle, whose C is compiled without fused multiply-adds.  The physics code
-// converges to a unique minimiser per sub-step and is compiled with contraction on.
-#pragma clang fp contract(off)
+// FMA contraction: ON here, like the physics products.  TRF takes discrete decisions too (step acceptance, termination,
+// the "last evaluated point" the reference teleports qpos to), but unlike the Newton solver's termination test they
+// proved insensitive to contraction on every parity case (tests/test_gpu_parity.py: same nfev / status as the oracle);
+// the Newton evaluation / line-search code is the region compiled without FMAs (kmanip_dyn.hip).
 
 #define GI 8            // lanes per problem
 #define PPW (64 / GI)   // problems per wave / workgroup
@@ -599,7 +598,3 @@ __device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds
       io.set_ctrl(q, f32r_c(x0 + (double)(a[cq + c] * (float)m->q_pos_delta)));
   }
 }
-
-#ifdef KM_VAR_NL
-#pragma clang fp contract(fast)     // back to the physics translation unit's setting (see the note at the top)
-#endif
