@@ -114,8 +114,7 @@ class KManipEnvHip:
         self.step_flat(act)
         terminated = torch.zeros((self.num_envs,), dtype=torch.bool, device=self.device)
         discount = torch.ones((self.num_envs,), dtype=torch.float64, device=self.device)
-        step_idx = self.get_state()[4]
-        sim_time = step_idx.astype(np.float64) * CONTROL_TIMESTEP
+        sim_time = self.step_counters().astype(np.float64) * CONTROL_TIMESTEP
         return terminated, self.reward, discount, self.obs_dict(), sim_time
 
     def render_depth(self, cam="grip_r", height: int = 64, width: int = 64, out=None):
@@ -152,6 +151,13 @@ class KManipEnvHip:
         p = lambda a, t=C.c_double: a.ctypes.data_as(C.POINTER(t))
         self._check(self.L.kmanip_get_state(self.h, p(qpos), p(qvel), p(ctrl), p(warm), p(step, C.c_int32)), "kmanip_get_state")
         return qpos, qvel, ctrl, warm, step
+
+    def step_counters(self):
+        """Per-env step index inside the current episode (only the int32 counters cross PCIe)."""
+        step = np.zeros(self.num_envs, dtype=np.int32)
+        self._check(self.L.kmanip_get_state(self.h, None, None, None, None, step.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "kmanip_get_state")
+        return step
 
     def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None, step=None):
         def p(a, dt, t):
