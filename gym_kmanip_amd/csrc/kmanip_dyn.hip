@@ -162,7 +162,12 @@ struct Prof {
 
 // sum over the G lanes of a group, result identical (bitwise) in every lane.  16-lane rows use four DPP
 // steps (row_mirror, row_half_mirror, two quad_perms) instead of ds_bpermute; G = 32 adds one swizzle.
+// The additions below must NOT be contracted with a multiply in the caller's argument (gsum(x * y)): lane i would add
+// the exact product to its partner's ROUNDED one and the lanes of a group would no longer hold the bitwise-identical
+// sum -- which group-uniform control flow (line-search breaks, termination tests) relies on.  Contraction needs the
+// `contract` flag on both operations, so switching it off for this body is enough.
 template <int G> __device__ __forceinline__ real gsum(real v) {
+#pragma clang fp contract(off)
   static_assert(G == 16 || G == 32, "lane group must be one or two DPP rows");
   v += dpp_f64<0x140>(v);   // row_mirror:      i <-> 15 - i
   v += dpp_f64<0x141>(v);   // row_half_mirror: i <-> 7 - i within each half row
@@ -1196,13 +1201,6 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const C
   });
 }
 
-// ---- From here to the end of solve_newton FMA contraction is OFF.  The Newton iteration takes discrete decisions on
-// noisy quantities (cost differences against the tolerance, line-search bracket updates, active-set flags); MuJoCo's
-// termination rule "improvement < tolerance" can stop an iteration early at a kink of the piecewise-quadratic cost, so
-// a different rounding of the cost can change the result at the 1e-4 level.  The oracle's C is compiled without FMAs,
-// and the parity tests hold the GPU to the oracle's decisions.  (Measured: with this region contracted, qpos departs
-// from the oracle by 4e-4 after one control step; without, 5e-15.)
-#pragma clang fp contract(off)
 // Newton state at the current point: a, Mr = M (a - a_s) (lane components) and, per active contact, the basis
 // projections u_k = J_k a in the record's inv[] slots (group-uniform, LDS).  PROJECT = recompute them from a
 // (start points); otherwise they were advanced incrementally (u += alpha * J p), as MuJoCo does.
@@ -1382,8 +1380,6 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   }
   return a;
 }
-
-#pragma clang fp contract(fast)
 
 // everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
 template <int NL, int G, int SOLVER>

@@ -17,16 +17,16 @@
 // kernel into 0.5-1.5 KB of scratch per lane.
 #pragma once
 #include "kmanip_device.hpp"
-// FMA contraction: ON here, like the physics products.  TRF takes discrete decisions too (step acceptance, termination,
-// the "last evaluated point" the reference teleports qpos to), but unlike the Newton solver's termination test they
-// proved insensitive to contraction on every parity case (tests/test_gpu_parity.py: same nfev / status as the oracle);
-// the Newton evaluation / line-search code is the region compiled without FMAs (kmanip_dyn.hip).
+// FMA contraction is ON for this code like for the physics (-ffp-contract=fast-honor-pragmas); the one place where it
+// must not act is inside the lane reductions (gsum8 below, gsum in kmanip_dyn.hip), whose results steer group-uniform
+// control flow and therefore have to be bitwise identical on every lane of a problem.
 
 #define GI 8            // lanes per problem
 #define PPW (64 / GI)   // problems per wave / workgroup
 
 // ---- 8-lane group collectives (DPP half-row patterns); results identical in all 8 lanes
 __device__ __forceinline__ real gsum8(real v) {
+#pragma clang fp contract(off)     // keep the sum bitwise identical on all 8 lanes: no FMA with the caller's product (see gsum)
   v += dpp_f64<0x141>(v);   // row_half_mirror: i <-> 7 - i
   v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
