@@ -1132,6 +1132,8 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
         rc.D = 1.0 / rc.R;
         rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2];
 #pragma unroll
+        for (int e = 0; e < 6; e++) rc.f[e] = 0;       // edge forces (the unused edges of a condim-3 pair stay 0)
+#pragma unroll
         for (int e = 0; e < 6; e++) {
           const int k = e / 2 + 1;
           const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
@@ -1257,6 +1259,53 @@ __device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
   return gsum<G>(cost);
 }
 
+// The same evaluation after a line-search step, without touching the projections: the contact edges this lane owns
+// in the line search (x = lx + alpha ly, registers) give their forces directly; the forces are exchanged through the
+// records (f[] slots), after which every lane needs only 6 forces + 3 friction coefficients per contact for its
+// gradient component and the active-edge mask.
+template <int NL, int G, int NEQ>
+__device__ __forceinline__ real newton_eval_step(Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
+                                                 const real (&lx)[NEQ], const real (&ly)[NEQ], const real (&lR)[NEQ],
+                                                 const real (&lD)[NEQ], real alpha, real& grad, int& qf, int& ql,
+                                                 uint32_t (&qm)[Dim<NL>::NC]) {
+  constexpr int NC = Dim<NL>::NC;
+  const uint32_t act = w.cact;
+  real cost = 0.5 * (a - a_s) * Mr;        // per-lane share; summed at the end
+  grad = Mr;
+  qf = 0; ql = 0;
+  if (cr.fl > 0) { real f; cost += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
+  if (cr.sg != 0) { real f; cost += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
+#pragma unroll
+  for (int q = 0; q < NEQ; q++) {
+    if (lR[q] != 0) {
+      const int t = sub + G * q, c = t / 6, e = t - 6 * c;
+      const real x = lx[q] + alpha * ly[q];
+      real f; int quad;
+      cost += row_eval(1, x, lR[q], lD[q], 0.0, f, quad);
+      w.rec[c].f[e] = f;
+    }
+  }
+  GSYNC();
+  static_for<0, NC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    qm[c] = 0;
+    if ((act >> c) & 1u) {
+      const ConRec& rc = w.rec[c];
+      real f[6];
+#pragma unroll
+      for (int e = 0; e < 6; e++) f[e] = rc.f[e];
+      uint32_t q = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
+      qm[c] = q;
+      const real F0 = ((f[0] + f[1]) + (f[2] + f[3])) + (f[4] + f[5]);
+      const real F1 = rc.mu[0] * (f[0] - f[1]), F2 = rc.mu[1] * (f[2] - f[3]), F3 = rc.mu[2] * (f[4] - f[5]);
+      grad -= cr.jb[c][0] * F0 + cr.jb[c][1] * F1 + cr.jb[c][2] * F2 + cr.jb[c][3] * F3;
+    }
+  });
+  return gsum<G>(cost);
+}
+
 template <int NL, int G>
 __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
                                              CReg<NL>& cr, real invm, Prof& pf) {
@@ -1371,8 +1420,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
         if ((act >> c) & 1u) w.rec[c].inv[sub] += alpha * w.rec[c].den[sub];
       });
     }
-    GSYNC();
-    const real cost_new = newton_eval<NL, G, false>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm);
+    const real cost_new = newton_eval_step<NL, G, NEQ>(w, sub, cr, a, a_s, Mr, lx, ly, lR, lD, alpha, grad, qf, ql, qm);
     const real improvement = scale * (cost - cost_new), gradient = scale * sqrt(gsum<G>(grad * grad));
     cost = cost_new;
     pf.ph(12);
