@@ -216,6 +216,17 @@ int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_
   return 0;
 }
 
+int kmanip_scripted_action(KHandle h, float* act_dev, void* stream) {
+  if (!h || !act_dev) { if (h) h->err = "kmanip_scripted_action: null buffer"; return -1; }
+  if (!h->desc.arm_present[0] || h->desc.act_col[KM_ACT_EER_POS] < 0) {
+    h->err = "kmanip_scripted_action: this env id has no eer_pos action (the scripted policy drives the right EE delta)"; return -1;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  kmanip_launch_scripted_action(h->dmodel, h->st, act_dev, (hipStream_t)stream);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 int kmanip_enable_timing(KHandle h, int enable) {
   if (!h) return -1;
   HIPCHK(h, hipSetDevice(h->device));

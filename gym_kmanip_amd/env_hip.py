@@ -128,6 +128,16 @@ class KManipEnvHip:
                     "kmanip_render_depth")
         return out
 
+    def scripted_action(self, act=None, generator=None):
+        """The reference's synthetic-data policy (examples/2_synthetic_data.py:28-41) for every env, on device:
+        action_space.sample() with eer_pos replaced by the unit vector from the right EE site to the cube.
+        `act` (float32 [num_envs, act_dim] on the device) is filled with U(-1, 1) when None; returns it."""
+        torch = _torch()
+        if act is None:
+            act = torch.rand((self.num_envs, self.cm.act_dim), device=self.device, generator=generator) * 2 - 1
+        self._check(self.L.kmanip_scripted_action(self.h, C.c_void_p(act.data_ptr()), self._stream()), "kmanip_scripted_action")
+        return act
+
     def k_render(self, cam, height: int = 64, width: int = 64):
         """KManipEnvSim.k_render (env_sim.py:187-188) for the gripper cameras: depth of the surrogate scene."""
         return self.render_depth(cam, height, width)

@@ -20,7 +20,7 @@ _lib = None
 EXPORTS = [
     "kmanip_model_desc_size", "kmanip_create", "kmanip_reset", "kmanip_step", "kmanip_get_state",
     "kmanip_set_state", "kmanip_get_diag", "kmanip_timing_summary", "kmanip_enable_timing", "kmanip_ik",
-    "kmanip_render_depth", "kmanip_num_envs", "kmanip_last_error", "kmanip_version", "kmanip_destroy",
+    "kmanip_render_depth", "kmanip_scripted_action", "kmanip_num_envs", "kmanip_last_error", "kmanip_version", "kmanip_destroy",
 ]
 
 
@@ -57,6 +57,7 @@ def load():
     lib.kmanip_enable_timing.argtypes = [vp, C.c_int]
     lib.kmanip_ik.argtypes = [vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, i32p, i32p]
     lib.kmanip_render_depth.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.kmanip_scripted_action.argtypes = [vp, vp, vp]
     lib.kmanip_num_envs.argtypes = [vp]
     lib.kmanip_last_error.argtypes = [vp]
     lib.kmanip_last_error.restype = C.c_char_p

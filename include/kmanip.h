@@ -210,6 +210,14 @@ int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos,
  * depth_dev: float[num_envs, height, width] device memory owned by the caller. */
 int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream);
 
+/* The scripted data-generation policy of reference examples/2_synthetic_data.py:28-41, for every env, on device:
+ * act_dev float[num_envs, act_dim] arrives holding action_space.sample() (the caller draws it) and leaves with its
+ * eer_pos columns overwritten by the unit vector from the right end-effector site to the cube centre
+ * (cube_pos - site("eer_site_pos").xpos, normalised), evaluated at the env's current state.  The reference
+ * stores that vector as float64 in the action dict; the flat action buffer is float32 (ACT_DTYPE).
+ * Returns an error for env ids without an eer_pos action (the *QPos ids). */
+int kmanip_scripted_action(KHandle h, float* act_dev, void* stream);
+
 int kmanip_num_envs(KHandle h);
 const char* kmanip_last_error(KHandle h);   /* h may be NULL: error of the last failed create */
 const char* kmanip_version(void);

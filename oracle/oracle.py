@@ -182,6 +182,11 @@ class Oracle:
         self.L.ko_render_depth(C.byref(self.desc), _p(_f64(qpos)), cam, h, w, _p(out, C.c_float))
         return out
 
+    def scripted_eer_pos(self, qpos):
+        o = np.zeros(3)
+        self.L.ko_scripted_eer_pos(C.byref(self.desc), _p(_f64(qpos)), _p(o))
+        return o
+
     def philox(self, ctr, key):
         c = np.ascontiguousarray(ctr, dtype=np.uint32); k = np.ascontiguousarray(key, dtype=np.uint32)
         o = np.zeros(4, dtype=np.uint32)

@@ -317,3 +317,38 @@ def test_small_batches_and_launch_shapes(n, epb, monkeypatch):
     mg, nf, st = dev.get_diag(); mo, nfo, sto = orc.get_diag()
     assert np.array_equal(mg, mo) and np.array_equal(nf[:, 0], nfo[:, 0]) and np.array_equal(st[:, 0], sto[:, 0])
     dev.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_scripted_policy_parity(env):
+    """the reference's synthetic-data policy (examples/2_synthetic_data.py:28-41) on device vs the
+    oracle: eer_pos columns = float32(unit vector site -> cube) at the current state, every other column untouched."""
+    torch = _torch()
+    cm, dev, orc = _mk(env, 48, seed=13)
+    dev.k_reset(); orc.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    sl = cm.act_slices["eer_pos"]
+    for k in range(8):
+        raw = torch.rand((48, cm.act_dim), generator=gen, device="cuda") * 2 - 1
+        act = dev.scripted_action(raw.clone())
+        a = act.cpu().numpy(); r = raw.cpu().numpy()
+        keep = np.ones(cm.act_dim, dtype=bool); keep[sl] = False
+        assert np.array_equal(a[:, keep], r[:, keep])                       # the sampled columns pass through
+        qpos = orc.get_state()[0]
+        ref = np.stack([orc.scripted_eer_pos(qpos[e]) for e in range(48)])
+        assert np.abs(a[:, sl] - ref.astype(np.float32)).max() <= 1.2e-7    # one float32 ulp of a unit vector
+        assert np.abs(np.linalg.norm(a[:, sl].astype(np.float64), axis=1) - 1).max() < 1e-6
+        dev.step_flat(act); orc.step(a)
+        _cmp_state(dev, orc, k)
+    dev.k_close()
+
+
+def test_scripted_policy_rejected_without_ee_action():
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.lib import KManipError
+    torch = _torch()
+    e = env_hip.make("KManipSoloArmQPos", num_envs=4)
+    e.k_reset()
+    with pytest.raises(KManipError):
+        e.scripted_action(torch.zeros((4, e.cm.act_dim), dtype=torch.float32, device="cuda"))
+    e.k_close()

@@ -205,3 +205,17 @@ def test_oracle_depth_render_geometry():
     centre = img[32, 32]
     assert abs(centre - (np.linalg.norm(cam - tgt) - 0.004)) < 1e-4
     assert img.min() >= d.cam_znear and img.max() <= d.cam_zfar
+
+
+def test_oracle_scripted_policy_points_at_cube():
+    """examples/2_synthetic_data.py:31-37 restated: unit vector from the right EE site to the cube centre."""
+    cm = compile_model("KManipSoloArm")
+    orc = Oracle(cm, 3, seed=2)
+    orc.reset()
+    qpos = orc.get_state()[0]
+    for e in range(3):
+        d = orc.scripted_eer_pos(qpos[e])
+        _, _, sp, _ = orc.fk(qpos[e])
+        want = qpos[e][cm.nlink:cm.nlink + 3] - sp[0]
+        assert abs(np.linalg.norm(d) - 1) < 1e-14
+        assert np.abs(d - want / np.linalg.norm(want)).max() < 1e-14
