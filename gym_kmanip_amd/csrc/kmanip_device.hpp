@@ -146,6 +146,17 @@ template <int G, int K> __device__ __forceinline__ real gbcast(real v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false);      // G == 8 callers pass K already offset into the row
   }
 }
+// acc += bcast_K(x) * t in ONE instruction: v_fmac_f64 with the DPP row_newbcast modifier on its first source (the
+// 64-bit DPP encoding gfx90a+ provides for exactly this control).  The compiler does not fold its own v_mov_b64_dpp
+// into the FMA, and it does not track hazards inside inline asm, so the two wait states a DPP read needs after a VALU
+// write of its source register (e.g. an AGPR reload just before) are spent explicitly.  One 16-lane row only.
+template <int K> __device__ __forceinline__ void fmac_bcast16(real& acc, real x, real t) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
+}
+// acc -= bcast_K(x) * t
+template <int K> __device__ __forceinline__ void fnmac_bcast16(real& acc, real x, real t) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
+}
 // compile-time counted loop: f(std::integral_constant<int, K>) for K in [K0, N)
 template <int K0, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (K0 < N) { f(std::integral_constant<int, K0>{}); static_for<K0 + 1, N>(f); }

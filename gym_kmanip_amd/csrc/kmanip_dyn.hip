@@ -486,8 +486,14 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
     static_for<0, NL>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       if constexpr (j != k) {
-        const real rkj = gbcast<G, k>(a[j]) * d;
-        a[j] = me ? rkj : a[j] - aik * rkj;
+        if constexpr (G == 16) {
+          real upd = a[j];
+          fnmac_bcast16<k>(upd, a[j], aik * d);          // a_ij - (a_ik / p) a_kj, row k arriving by DPP
+          a[j] = me ? a[j] * d : upd;
+        } else {
+          const real rkj = gbcast<G, k>(a[j]) * d;
+          a[j] = me ? rkj : a[j] - aik * rkj;
+        }
       }
     });
     a[k] = me ? d : -aik * d;
@@ -984,7 +990,8 @@ __device__ __forceinline__ void chol_rows(real (&h)[N], real& invd, int sub, int
     if (sub == k) invd = inv;
     static_for<k + 1, N>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      h[j] -= lik * gbcast<G, j>(lik);
+      if constexpr (G == 16) fnmac_bcast16<j>(h[j], lik, lik);
+      else h[j] -= lik * gbcast<G, j>(lik);
     });
   });
 }
@@ -994,8 +1001,15 @@ template <int G, int N>
 __device__ __forceinline__ real chol_solve_rows(const real (&h)[N], real invd, int sub, real b) {
   static_for<0, N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const real zk = gbcast<G, k>(b * invd);
-    b = sub > k ? b - h[k] * zk : (sub == k ? zk : b);
+    if constexpr (G == 16) {
+      const real t = b * invd;                       // lane k's t is z_k
+      real upd = b;
+      fnmac_bcast16<k>(upd, t, h[k]);
+      b = sub > k ? upd : (sub == k ? t : b);
+    } else {
+      const real zk = gbcast<G, k>(b * invd);
+      b = sub > k ? b - h[k] * zk : (sub == k ? zk : b);
+    }
   });
   real x = 0;
   static_for<0, N>([&](auto kc) {
@@ -1152,7 +1166,8 @@ __device__ __forceinline__ real mass_mul(const CReg<NL>& cr, int sub, real mdiag
   real s = 0;
   static_for<0, NL>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    s += cr.mrow[j] * gbcast<G, j>(x);
+    if constexpr (G == 16) fmac_bcast16<j>(s, x, cr.mrow[j]);
+    else s += cr.mrow[j] * gbcast<G, j>(x);
   });
   return sub < NL ? s : mdiag * x;
 }
@@ -1196,8 +1211,13 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const C
       constexpr int j0 = slot_kind<NL>(c) == 0 ? NL : 0;        // table-cube slots touch only the cube block
       static_for<j0, NV>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        h[j] += t[0] * gbcast<G, j>(cr.jb[c][0]) + t[1] * gbcast<G, j>(cr.jb[c][1]) + t[2] * gbcast<G, j>(cr.jb[c][2]) +
-                t[3] * gbcast<G, j>(cr.jb[c][3]);
+        if constexpr (G == 16) {
+          fmac_bcast16<j>(h[j], cr.jb[c][0], t[0]); fmac_bcast16<j>(h[j], cr.jb[c][1], t[1]);
+          fmac_bcast16<j>(h[j], cr.jb[c][2], t[2]); fmac_bcast16<j>(h[j], cr.jb[c][3], t[3]);
+        } else {
+          h[j] += t[0] * gbcast<G, j>(cr.jb[c][0]) + t[1] * gbcast<G, j>(cr.jb[c][1]) + t[2] * gbcast<G, j>(cr.jb[c][2]) +
+                  t[3] * gbcast<G, j>(cr.jb[c][3]);
+        }
       });
     }
   });
