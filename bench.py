@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=64, help="untimed steps (default: one full 64-step episode, so timed steps see the steady-state mix)")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-total", type=int, default=0,
+                    help="strong-scaling variant: split this many envs over the GPUs (contiguous shards) instead of --envs-per-gpu each")
     ap.add_argument("--env", default="KManipSoloArm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=0, help="also render a DxD gripper-cam depth image per env each step (BASELINE config 5)")
@@ -142,8 +144,14 @@ def main():
     from gym_kmanip_amd import env_hip
     from gym_kmanip_amd.model import compile_model
     cm = compile_model(args.env, auto_reset=True, solver_iterations=args.solver_iterations, solver=args.solver)
-    n = args.envs_per_gpu
-    env = env_hip.KManipEnvHip(cm, num_envs=n, device=local_rank, seed=0, env_id_offset=rank * n)
+    if args.envs_total:
+        assert args.envs_total % world == 0, "--envs-total must be a multiple of the GPU count (equal shards for the gather)"
+        from gym_kmanip_amd.dist import shard_range
+        lo, hi = shard_range(args.envs_total, world, rank)
+        n, off = hi - lo, lo
+    else:
+        n, off = args.envs_per_gpu, rank * args.envs_per_gpu
+    env = env_hip.KManipEnvHip(cm, num_envs=n, device=local_rank, seed=0, env_id_offset=off)
     gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
     nbank = 16
     acts = [(torch.rand((n, cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous() for _ in range(nbank)]
@@ -188,7 +196,8 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        total_env_steps = world * n * args.steps
+        total_envs = args.envs_total if args.envs_total else world * n
+        total_env_steps = total_envs * args.steps
         bytes_per_launch = algorithmic_bytes_per_env_step(cm) * n
         dyn_avg_s = dyn_ms / max(nt, 1) * 1e-3
         achieved = bytes_per_launch / dyn_avg_s / 1e9
@@ -197,9 +206,9 @@ def main():
             "metric": "env steps/sec (whole node), KManipSoloArm @4096 envs, 1/2/4/8 MI355X",
             "value": total_env_steps / dt, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.envs_total else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %d envs per GPU (%d total), no cameras, random U(-1,1) actions, 64-step episodes with auto-reset"
-                                   % (args.env, n, world * n),
+                                   % (args.env, n, total_envs),
                        "envs_per_gpu": n, "depth_image": ("%dx%d float32 grip_r" % (args.depth, args.depth)) if args.depth else None,
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
