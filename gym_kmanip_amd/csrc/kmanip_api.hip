@@ -90,7 +90,7 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
       x->jump[k][i] = a;
     }
   }
-  if (depth > 9) { err = "kinematic tree deeper than 9 links (KM_ANC_MAX + 1 in kmanip_dyn.hip)"; return -1; }
+  if (depth > 16) { err = "kinematic tree deeper than 16 links"; return -1; }
   x->fk_rounds = 0;
   while ((1 << x->fk_rounds) < depth) x->fk_rounds++;
   for (int a = 0; a < KM_MAX_ARMS; a++) {

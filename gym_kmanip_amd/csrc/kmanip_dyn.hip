@@ -27,7 +27,6 @@
 //   PGS              : per-contact block form on the 4x4 Gram matrix (algebraically the same row order)
 #include "kmanip_ik_coop.hpp"
 #include <stdlib.h>
-#define KM_ANC_MAX 8          // kmanip_create rejects deeper trees
 #define KM_TARGET_WAVES 1024   // 256 CUs x 4 SIMDs: below this many workgroups, fewer envs per wave fills more SIMDs
 
 template <int NL> struct Dim {
@@ -49,7 +48,6 @@ struct LModel {
   int parent[NL], jtype[NL], forcelimited[NL];
   uint32_t anc[NL], desc[NL];
   int jump[4][NL], fk_rounds;
-  int anc_list[NL][KM_ANC_MAX];   // proper ancestors of link i, root first, -1 padded (the tree is at most KM_ANC_MAX + 1 deep)
   real pos[NL][3], quat[NL][4], jaxis[NL][3], range[NL][2], floss[NL], kp[NL], ctrlrange[NL][2], forcerange[NL][2];
   real mass[NL], com[NL][3], inertia[NL][3], q_home[NL];
   real R[NL][9];        // constant rotation of each link in its parent (from link_quat)
@@ -346,22 +344,17 @@ __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int
       N[0] += t[0]; N[1] += t[1]; N[2] += t[2];
     }
     for (int i = 0; i < NL; i++) w.Minv[i][j] = 0;            // non-ancestors (filled symmetric below)
-#pragma unroll
-    for (int d = 0; d <= KM_ANC_MAX; d++) {                 // link j itself, then its ancestors (fixed trip count: no pointer chase)
-      const int i = d == 0 ? j : lm.anc_list[j][d - 1];
-      if (i >= 0) {
-        real val;
-        const real ai[3] = {w.k.axis[i][0], w.k.axis[i][1], w.k.axis[i][2]};
-        if (lm.jtype[i] == KM_JNT_SLIDE) val = dot3(ai, F);
-        else {
-          const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
-          real ti[3];
-          cross3(ti, oi, F);
-          real mo[3] = {N[0] - ti[0], N[1] - ti[1], N[2] - ti[2]};
-          val = dot3(ai, mo);
-        }
-        w.Minv[i][j] = val;
+    for (int i = j; i >= 0; i = lm.parent[i]) {
+      real val;
+      const real ai[3] = {w.k.axis[i][0], w.k.axis[i][1], w.k.axis[i][2]};
+      if (lm.jtype[i] == KM_JNT_SLIDE) val = dot3(ai, F);
+      else {
+        const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
+        cross3(t, oi, F);
+        real mo[3] = {N[0] - t[0], N[1] - t[1], N[2] - t[2]};
+        val = dot3(ai, mo);
       }
+      w.Minv[i][j] = val;
     }
   }
 }
@@ -386,6 +379,7 @@ __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>
   real* dbb = czb + 3 * NL;
   const bool on = sub < NL;
   const bool slide = on && lm.jtype[sub] == KM_JNT_SLIDE;
+  const uint32_t up = on ? (lm.anc[sub] & ~(1u << sub)) : 0u;       // proper ancestors
   real ax[3] = {0, 0, 0};
   if (on) {
     const real qv = w.qvel[sub];
@@ -395,22 +389,14 @@ __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>
   GSYNC();
   real wp[3] = {0, 0, 0}, cz[3] = {0, 0, 0};
   if (on) {
-#pragma unroll
-    for (int d = 0; d < KM_ANC_MAX; d++) {      // fixed trip count: all the LDS reads are in flight before the first add waits
-      const int j = lm.anc_list[sub][d];
-      if (j >= 0) { wp[0] += wvb[3 * j]; wp[1] += wvb[3 * j + 1]; wp[2] += wvb[3 * j + 2]; }
-    }
+    for (uint32_t mk = up; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; wp[0] += wvb[3 * j]; wp[1] += wvb[3 * j + 1]; wp[2] += wvb[3 * j + 2]; }
     cross3(cz, wp, ax);
     czb[3 * sub] = slide ? 0.0 : cz[0]; czb[3 * sub + 1] = slide ? 0.0 : cz[1]; czb[3 * sub + 2] = slide ? 0.0 : cz[2];
   }
   GSYNC();
   real alp[3] = {0, 0, 0};
   if (on) {
-#pragma unroll
-    for (int d = 0; d < KM_ANC_MAX; d++) {
-      const int j = lm.anc_list[sub][d];
-      if (j >= 0) { alp[0] += czb[3 * j]; alp[1] += czb[3 * j + 1]; alp[2] += czb[3 * j + 2]; }
-    }
+    for (uint32_t mk = up; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; alp[0] += czb[3 * j]; alp[1] += czb[3 * j + 1]; alp[2] += czb[3 * j + 2]; }
     const int p = lm.parent[sub];
     real op[3] = {0, 0, 0};
     if (p >= 0) { op[0] = w.k.xpos[p][0]; op[1] = w.k.xpos[p][1]; op[2] = w.k.xpos[p][2]; }
@@ -423,12 +409,7 @@ __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>
   GSYNC();
   if (on) {
     real ai[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]};
-#pragma unroll
-    for (int d = 0; d < KM_ANC_MAX; d++) {
-      const int j = lm.anc_list[sub][d];
-      if (j >= 0) { ai[0] += dbb[3 * j]; ai[1] += dbb[3 * j + 1]; ai[2] += dbb[3 * j + 2]; }
-    }
-    ai[0] += dbb[3 * sub]; ai[1] += dbb[3 * sub + 1]; ai[2] += dbb[3 * sub + 2];
+    for (uint32_t mk = lm.anc[sub]; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; ai[0] += dbb[3 * j]; ai[1] += dbb[3 * j + 1]; ai[2] += dbb[3 * j + 2]; }
     real wi[3] = {wp[0], wp[1], wp[2]}, ali[3] = {alp[0], alp[1], alp[2]};
     if (!slide) {
 #pragma unroll
@@ -1623,11 +1604,6 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
     lm.parent[i] = m->link_parent[i]; lm.jtype[i] = m->jnt_type[i]; lm.forcelimited[i] = m->forcelimited[i];
     lm.anc[i] = dm->x.anc_mask[i]; lm.desc[i] = dm->x.desc_mask[i];
     for (int k = 0; k < 4; k++) lm.jump[k][i] = dm->x.jump[k][i];
-    {
-      int tmp[KM_ANC_MAX], n = 0;
-      for (int a = m->link_parent[i]; a >= 0 && n < KM_ANC_MAX; a = m->link_parent[a]) tmp[n++] = a;
-      for (int d = 0; d < KM_ANC_MAX; d++) lm.anc_list[i][d] = d < n ? tmp[n - 1 - d] : -1;
-    }
     if (i == 0) {
       lm.fk_rounds = dm->x.fk_rounds;
       get_kb(m, m->con_def_solref, m->con_def_solimp, lm.kb[0][0], lm.kb[0][1]);
