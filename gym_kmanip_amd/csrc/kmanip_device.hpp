@@ -157,6 +157,34 @@ template <int K> __device__ __forceinline__ void fmac_bcast16(real& acc, real x,
 template <int K> __device__ __forceinline__ void fnmac_bcast16(real& acc, real x, real t) {
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
 }
+// The same for one- or two-row groups.  A broadcast source is prepared once (BSrc): for G = 16 the value itself; for
+// G = 32 two copies made by one v_permlane16_swap per 32-bit half -- `e` carries the even row's values in both rows
+// of the pair, `o` the odd row's -- so that lane K of the 32-lane group is row_newbcast:(K & 15) of the right copy and
+// the broadcast still folds into the FMA.
+template <int G> struct BSrc;
+template <> struct BSrc<16> { real v; };
+template <> struct BSrc<32> { real e, o; };
+template <int G> __device__ __forceinline__ BSrc<G> bsrc(real x) {
+  if constexpr (G == 32) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    BSrc<32> r;
+    r.e = __hiloint2double((int)rh[0], (int)rl[0]);
+    r.o = __hiloint2double((int)rh[1], (int)rl[1]);
+    return r;
+  } else {
+    BSrc<16> r; r.v = x; return r;
+  }
+}
+template <int G, int K> __device__ __forceinline__ void fmac_b(real& acc, const BSrc<G>& s, real t) {
+  if constexpr (G == 32) { if constexpr (K < 16) fmac_bcast16<K>(acc, s.e, t); else fmac_bcast16<K - 16>(acc, s.o, t); }
+  else fmac_bcast16<K>(acc, s.v, t);
+}
+template <int G, int K> __device__ __forceinline__ void fnmac_b(real& acc, const BSrc<G>& s, real t) {
+  if constexpr (G == 32) { if constexpr (K < 16) fnmac_bcast16<K>(acc, s.e, t); else fnmac_bcast16<K - 16>(acc, s.o, t); }
+  else fnmac_bcast16<K>(acc, s.v, t);
+}
 // compile-time counted loop: f(std::integral_constant<int, K>) for K in [K0, N)
 template <int K0, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (K0 < N) { f(std::integral_constant<int, K0>{}); static_for<K0 + 1, N>(f); }

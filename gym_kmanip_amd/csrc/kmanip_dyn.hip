@@ -486,14 +486,9 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
     static_for<0, NL>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       if constexpr (j != k) {
-        if constexpr (G == 16) {
-          real upd = a[j];
-          fnmac_bcast16<k>(upd, a[j], aik * d);          // a_ij - (a_ik / p) a_kj, row k arriving by DPP
-          a[j] = me ? a[j] * d : upd;
-        } else {
-          const real rkj = gbcast<G, k>(a[j]) * d;
-          a[j] = me ? rkj : a[j] - aik * rkj;
-        }
+        real upd = a[j];
+        fnmac_b<G, k>(upd, bsrc<G>(a[j]), aik * d);      // a_ij - (a_ik / p) a_kj, row k arriving by DPP
+        a[j] = me ? a[j] * d : upd;
       }
     });
     a[k] = me ? d : -aik * d;
@@ -988,10 +983,10 @@ __device__ __forceinline__ void chol_rows(real (&h)[N], real& invd, int sub, int
     const real lik = h[k] * inv;
     h[k] = lik;
     if (sub == k) invd = inv;
+    const BSrc<G> lsrc = bsrc<G>(lik);
     static_for<k + 1, N>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if constexpr (G == 16) fnmac_bcast16<j>(h[j], lik, lik);
-      else h[j] -= lik * gbcast<G, j>(lik);
+      fnmac_b<G, j>(h[j], lsrc, lik);
     });
   });
 }
@@ -1001,15 +996,10 @@ template <int G, int N>
 __device__ __forceinline__ real chol_solve_rows(const real (&h)[N], real invd, int sub, real b) {
   static_for<0, N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    if constexpr (G == 16) {
-      const real t = b * invd;                       // lane k's t is z_k
-      real upd = b;
-      fnmac_bcast16<k>(upd, t, h[k]);
-      b = sub > k ? upd : (sub == k ? t : b);
-    } else {
-      const real zk = gbcast<G, k>(b * invd);
-      b = sub > k ? b - h[k] * zk : (sub == k ? zk : b);
-    }
+    const real t = b * invd;                         // lane k's t is z_k
+    real upd = b;
+    fnmac_b<G, k>(upd, bsrc<G>(t), h[k]);
+    b = sub > k ? upd : (sub == k ? t : b);
   });
   real x = 0;
   static_for<0, N>([&](auto kc) {
@@ -1164,10 +1154,10 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
 template <int NL, int G>
 __device__ __forceinline__ real mass_mul(const CReg<NL>& cr, int sub, real mdiag, real x) {
   real s = 0;
+  const BSrc<G> xs = bsrc<G>(x);
   static_for<0, NL>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    if constexpr (G == 16) fmac_bcast16<j>(s, x, cr.mrow[j]);
-    else s += cr.mrow[j] * gbcast<G, j>(x);
+    fmac_b<G, j>(s, xs, cr.mrow[j]);
   });
   return sub < NL ? s : mdiag * x;
 }
@@ -1209,15 +1199,10 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const C
       }
       // H[sub][j] += sum_k t_k(sub) * J_k[j]: lane j's basis entries arrive by row broadcast
       constexpr int j0 = slot_kind<NL>(c) == 0 ? NL : 0;        // table-cube slots touch only the cube block
+      const BSrc<G> j0s = bsrc<G>(cr.jb[c][0]), j1s = bsrc<G>(cr.jb[c][1]), j2s = bsrc<G>(cr.jb[c][2]), j3s = bsrc<G>(cr.jb[c][3]);
       static_for<j0, NV>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (G == 16) {
-          fmac_bcast16<j>(h[j], cr.jb[c][0], t[0]); fmac_bcast16<j>(h[j], cr.jb[c][1], t[1]);
-          fmac_bcast16<j>(h[j], cr.jb[c][2], t[2]); fmac_bcast16<j>(h[j], cr.jb[c][3], t[3]);
-        } else {
-          h[j] += t[0] * gbcast<G, j>(cr.jb[c][0]) + t[1] * gbcast<G, j>(cr.jb[c][1]) + t[2] * gbcast<G, j>(cr.jb[c][2]) +
-                  t[3] * gbcast<G, j>(cr.jb[c][3]);
-        }
+        fmac_b<G, j>(h[j], j0s, t[0]); fmac_b<G, j>(h[j], j1s, t[1]); fmac_b<G, j>(h[j], j2s, t[2]); fmac_b<G, j>(h[j], j3s, t[3]);
       });
     }
   });
