@@ -15,7 +15,7 @@
 // about 8 KB per env, sized so that 16 envs fit one CU (4 workgroups x 4 envs) and all 4096 envs of the
 // headline config are resident in a single round.  HBM is touched once on entry and once on exit with
 // struct-of-arrays coalesced columns.  Per-env reductions (basis projections J.a, norms, costs) are DPP
-// row reductions (row_mirror / row_half_mirror / quad_perm), not ds_bpermute.  A lane group never needs
+// row reductions (row_mirror / row_half_mirror / quad_perm; v_permlane16_swap across the two rows of a 32-lane group), not ds_bpermute.  A lane group never needs
 // s_barrier: all its lanes sit in one wave.
 //
 // Formulations deliberately differ from the oracle's (so parity is a cross-check, not a re-run):
@@ -174,10 +174,8 @@ template <int G> __device__ __forceinline__ real gsum(real v) {
   v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
   if (G == 32) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);   // bit mode: xor lane id with 16
-    hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
-    v += __hiloint2double(hi, lo);
+    const BSrc<32> r = bsrc<32>(v);                  // even-row sum and odd-row sum, each in both rows (v_permlane16_swap)
+    v = r.e + r.o;                                   // same operands in the same order on every lane
   }
   return v;
 }
