@@ -48,6 +48,27 @@ def measured_traffic(kernel_prefix="void k_step"):
     return None, None
 
 
+def measure_chunked(env, cm, n, K, gen):
+    """Secondary measurement: the same workload through kmanip_step_chunk (K pre-supplied actions per env and launch,
+    as an action-chunking policy or a scripted stream provides).  Not the headline: the metric is per-step stepping."""
+    import torch
+    acts = (torch.rand((K, n, cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous()
+    obs = torch.empty((K, n, cm.obs_dim), dtype=torch.float64, device="cuda")
+    rew = torch.empty((K, n), dtype=torch.float64, device="cuda"); done = torch.empty((K, n), dtype=torch.uint8, device="cuda")
+    for _ in range(4):
+        env.step_chunk(acts, obs, rew, done)
+    torch.cuda.synchronize()
+    launches = 16
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        env.step_chunk(acts, obs, rew, done)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"api": "kmanip_step_chunk", "steps_per_launch": K, "value": n * K * launches / dt, "unit": "env steps/s",
+            "ms_per_env_step_batch": dt / (K * launches) * 1e3,
+            "note": "no launch boundary per step: waves do not wait for the batch's slowest env at every step"}
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     try:
@@ -128,6 +149,7 @@ def main():
     ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
                     help="newton = MuJoCo default, what the reference runs; pgs = the north star's named solver (100 sweeps)")
     ap.add_argument("--no-pgs-variant", action="store_true", help="skip the extra short PGS measurement")
+    ap.add_argument("--chunk", type=int, default=16, help="also time kmanip_step_chunk with this many control steps per launch (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,6 +244,8 @@ def main():
         }
         if not args.no_pgs_variant and args.solver == "newton" and world == 1:
             out["pgs_variant"] = measure_variant(args.env, "pgs", n, local_rank, rank)
+        if args.chunk > 1 and world == 1 and not args.depth:
+            out["chunked_variant"] = measure_chunked(env, cm, n, args.chunk, gen)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(cm, n)
             out["cpu_baseline"]["solver"] = args.solver

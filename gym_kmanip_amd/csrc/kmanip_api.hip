@@ -188,7 +188,7 @@ int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stre
   return 0;
 }
 
-int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, void* stream) {
+static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h || !act_dev || !obs_dev || !reward_dev || !done_dev) { if (h) h->err = "kmanip_step: null buffer"; return -1; }
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -198,13 +198,23 @@ int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward
   // product path: ONE launch, before_step (decode + IK) fused into k_step so that no device-wide barrier sits between
   // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1 / KMANIP_IK_SERIAL=1)
   const bool split = h->ik_serial || h->ik_unfused;
+  if (split && nchunk != 1) { h->err = "kmanip_step_chunk needs the fused path (unset KMANIP_IK_UNFUSED / KMANIP_IK_SERIAL)"; return -1; }
   if (h->ik_serial) kmanip_launch_ik(h->dmodel, h->desc, h->st, act_dev, s);
   else if (h->ik_unfused) kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
-  kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, s);
+  kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);
   if (tm) { HIPCHK(h, hipEventRecord(ev[2], s)); h->timed_steps++; }
   HIPCHK(h, hipGetLastError());
   return 0;
+}
+
+int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, void* stream) {
+  return step_impl(h, 1, act_dev, obs_dev, reward_dev, done_dev, stream);
+}
+
+int kmanip_step_chunk(KHandle h, int nsteps, const float* act_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, void* stream) {
+  if (nsteps <= 0) { if (h) h->err = "kmanip_step_chunk: nsteps must be positive"; return -1; }
+  return step_impl(h, nsteps, act_dev, obs_dev, reward_dev, done_dev, stream);
 }
 
 int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream) {

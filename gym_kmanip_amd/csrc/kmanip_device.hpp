@@ -235,8 +235,9 @@ void kmanip_launch_ik_standalone(const KDeviceModel* dm, const KModelDesc& hd, i
                                  const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
                                  int32_t* status, hipStream_t stream);
 // act != NULL: the decode + IK of before_step run inside k_step (product path); NULL: they already ran
+// nchunk > 1 (act != NULL only): that many control steps per launch, act / obs / reward / done laid out [nchunk][num_envs][..]
 void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act, double* obs,
-                        double* reward, uint8_t* done, hipStream_t stream);
+                        double* reward, uint8_t* done, int nchunk, hipStream_t stream);
 void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const uint8_t* mask,
                          int use_done_bits, double* obs, hipStream_t stream);
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,

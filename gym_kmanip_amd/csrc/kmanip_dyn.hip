@@ -1606,9 +1606,10 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
 // ---------------------------------------------------------------------------------------------
 // EPB = envs per single-wave workgroup (<= 64 / G).  Fewer envs per wave = more waves per SIMD: the kernel is
 // bound by LDS/dependent-issue latency, so waves of different envs hide each other's waits.
-template <int NL, int G, int SOLVER, int EPB>
+template <int NL, int G, int SOLVER, int EPB, bool CHUNK>
 __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm, KDeviceState st, const float* __restrict__ act,
-                                             double* __restrict__ obs, double* __restrict__ reward, uint8_t* __restrict__ done) {
+                                             double* __restrict__ obs, double* __restrict__ reward, uint8_t* __restrict__ done,
+                                             int nchunk) {
   constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
   __shared__ Ws<NL> ws[EPB];
   __shared__ LModel<NL> lm;
@@ -1623,16 +1624,30 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   Prof pf;
   pf.start();
-  load_state<NL, G>(w, st, env, sub, act != nullptr);
+  const bool fused = act != nullptr;
+  load_state<NL, G>(w, st, env, sub, fused);
+  int step_idx = st.step_idx[env], episode = st.episode[env];
+  const size_t NE = (size_t)st.num_envs;
   GSYNC();
   pf.ph(15);
-  if (act != nullptr) {
+  // nchunk control steps per launch (kmanip_step: 1).  With a chunk of pre-supplied actions every wave runs its envs
+  // through all of them without meeting the other waves at a launch boundary, so the batch advances at the MEAN wave
+  // speed instead of the slowest wave's; the state stays in LDS between the steps of a chunk.
+  const int nsteps = CHUNK ? nchunk : 1;      // (the single-step kernel keeps its register allocation: no outer loop)
+  for (int kc = 0; kc < nsteps; kc++) {
+  if (fused) {
+    if (kc > 0) {
+      // what load_state does for the first step: ctrl <- float32(ctrl) (env_sim.py:40), qpos_ik <- qpos
+      if (sub < NL) { w.ctrl[sub] = (real)(float)w.ctrl[sub]; w.qpos_ik[sub] = w.qpos[sub]; }
+      if (sub == 0) w.bad = 0;
+      GSYNC();
+    }
     // ---- KManipTask.before_step: 8 lanes per arm (lanes 0-7 of the group: right arm, 8-15: left arm), the rest idle.
     // Fused here so that an env whose IK needs many evaluations delays only its own wave, not the whole batch.
     const int arm = sub / GI;
     if (arm < KM_MAX_ARMS && (NL > 10 || arm == 0) && m->arm_present[arm]) {
       LdsIO<NL> io{w, st, env};
-      const float* arow = act + (size_t)env * m->act_dim;
+      const float* arow = act + ((size_t)kc * NE + env) * m->act_dim;
       CoopLds<7>* L = &w.ik[NL > 10 ? arm : 0];
       if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, L, arm, sub % GI, arow, io);
       else coop_before_step<6>(dm, reinterpret_cast<CoopLds<6>*>(L), arm, sub % GI, arow, io);
@@ -1663,7 +1678,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   }
   uint8_t dn = 0;
   real rew = 0;
-  double* obs_row = obs + (size_t)env * m->obs_dim;
+  double* obs_row = obs + ((size_t)kc * NE + env) * m->obs_dim;
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
@@ -1691,8 +1706,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     for (int i = sub; i < m->obs_dim; i += G) obs_row[i] = 0;
     if (sub == 0) st.contact_mask[env] = 0;
   }
-  int step_idx = st.step_idx[env] + 1;
-  int episode = st.episode[env];
+  step_idx += 1;
   if (step_idx >= m->max_episode_steps) dn |= KM_DONE_TRUNCATED;
   if (dn && (m->auto_reset || bad)) {
     episode += 1; step_idx = 0;
@@ -1700,8 +1714,10 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
   }
-  if (sub == 0) { reward[env] = rew; done[env] = dn; st.step_idx[env] = step_idx; st.episode[env] = episode; }
+  if (sub == 0) { reward[(size_t)kc * NE + env] = rew; done[(size_t)kc * NE + env] = dn; }
   GSYNC();
+  }   // chunk
+  if (sub == 0) { st.step_idx[env] = step_idx; st.episode[env] = episode; }
   store_state<NL, G>(w, st, env, sub);
   pf.ph(14);
   pf.flush();
@@ -1744,19 +1760,21 @@ static int pick_epb(int num_envs, int max_epb) {
   return epb;
 }
 template <int NL, int G, int SOLVER, int EPB>
-static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
-  hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, act, obs, reward, done);
+static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, int nchunk, hipStream_t stream) {
+  if (nchunk > 1) {
+    if constexpr (EPB == 64 / G) hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB, true>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, act, obs, reward, done, nchunk);
+  } else hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB, false>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, act, obs, reward, done, 1);
 }
 template <int NL, int G, int SOLVER, int EPB>
 static void launch_reset_e(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
   hipLaunchKernelGGL((k_reset<NL, G, SOLVER, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, mask, obs);
 }
 template <int NL, int G, int SOLVER>
-static void launch_step_t(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, hipStream_t stream) {
-  const int epb = pick_epb(st.num_envs, 64 / G);
-  if constexpr (64 / G >= 4) if (epb == 4) return launch_step_e<NL, G, SOLVER, 4>(dm, st, act, obs, reward, done, stream);
-  if (epb == 2) return launch_step_e<NL, G, SOLVER, 2>(dm, st, act, obs, reward, done, stream);
-  launch_step_e<NL, G, SOLVER, 1>(dm, st, act, obs, reward, done, stream);
+static void launch_step_t(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, int nchunk, hipStream_t stream) {
+  const int epb = nchunk > 1 ? 64 / G : pick_epb(st.num_envs, 64 / G);      // (the chunked kernel exists for the full shape only)
+  if constexpr (64 / G >= 4) if (epb == 4) return launch_step_e<NL, G, SOLVER, 4>(dm, st, act, obs, reward, done, nchunk, stream);
+  if (epb == 2) return launch_step_e<NL, G, SOLVER, 2>(dm, st, act, obs, reward, done, nchunk, stream);
+  launch_step_e<NL, G, SOLVER, 1>(dm, st, act, obs, reward, done, nchunk, stream);
 }
 template <int NL, int G, int SOLVER>
 static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
@@ -1772,8 +1790,8 @@ static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const
 #define KM_CAT4_(a, b, c, d) a##b##_##c##_##d
 #define KM_CAT4(a, b, c, d) KM_CAT4_(a, b, c, d)
 void KM_CAT4(kmanip_launch_step_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st, const float* act,
-                                                                    double* obs, double* reward, uint8_t* done, hipStream_t stream) {
-  launch_step_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, act, obs, reward, done, stream);
+                                                                    double* obs, double* reward, uint8_t* done, int nchunk, hipStream_t stream) {
+  launch_step_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, act, obs, reward, done, nchunk, stream);
 }
 void KM_CAT4(kmanip_launch_reset_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st,
                                                                      const uint8_t* mask, double* obs, hipStream_t stream) {

@@ -106,6 +106,25 @@ class KManipEnvHip:
                                        self._stream()), "kmanip_step")
         return self.obs, self.reward, self.done
 
+    def step_chunk(self, acts, obs=None, reward=None, done=None):
+        """K control steps in one launch (kmanip_step_chunk): acts float32 [K, num_envs, act_dim] on the device ->
+        (obs [K, N, obs_dim] f64, reward [K, N] f64, done [K, N] u8).  Same results as K step_flat calls; self.obs /
+        self.reward / self.done are left holding the last step."""
+        torch = _torch()
+        K = int(acts.shape[0])
+        n = self.num_envs
+        if obs is None:
+            obs = torch.empty((K, n, self.cm.obs_dim), dtype=torch.float64, device=self.device)
+        if reward is None:
+            reward = torch.empty((K, n), dtype=torch.float64, device=self.device)
+        if done is None:
+            done = torch.empty((K, n), dtype=torch.uint8, device=self.device)
+        self._check(self.L.kmanip_step_chunk(self.h, K, C.c_void_p(acts.data_ptr()), C.c_void_p(obs.data_ptr()),
+                                             C.c_void_p(reward.data_ptr()), C.c_void_p(done.data_ptr()), self._stream()),
+                    "kmanip_step_chunk")
+        self.obs.copy_(obs[-1]); self.reward.copy_(reward[-1]); self.done.copy_(done[-1])
+        return obs, reward, done
+
     def k_step(self, action):
         """KManipEnvSim.k_step (env_sim.py:196-200).  `terminated` is always False in the reference
         (get_termination -> None); the TimeLimit truncation and the divergence flag are in `self.done`."""

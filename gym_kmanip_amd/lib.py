@@ -18,7 +18,7 @@ _lib = None
 
 # every symbol include/kmanip.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "kmanip_model_desc_size", "kmanip_create", "kmanip_reset", "kmanip_step", "kmanip_get_state",
+    "kmanip_model_desc_size", "kmanip_create", "kmanip_reset", "kmanip_step", "kmanip_step_chunk", "kmanip_get_state",
     "kmanip_set_state", "kmanip_get_diag", "kmanip_timing_summary", "kmanip_enable_timing", "kmanip_ik",
     "kmanip_render_depth", "kmanip_scripted_action", "kmanip_num_envs", "kmanip_last_error", "kmanip_version", "kmanip_destroy",
 ]
@@ -50,6 +50,7 @@ def load():
     lib.kmanip_create.argtypes = [C.POINTER(KModelDesc), C.c_int, C.c_int, C.c_uint64, C.c_int64, C.POINTER(vp)]
     lib.kmanip_reset.argtypes = [vp, vp, vp, vp]
     lib.kmanip_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.kmanip_step_chunk.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.kmanip_get_state.argtypes = [vp, f64p, f64p, f64p, f64p, i32p]
     lib.kmanip_set_state.argtypes = [vp, f64p, f64p, f64p, f64p, i32p]
     lib.kmanip_get_diag.argtypes = [vp, C.POINTER(C.c_uint32), i32p, i32p]

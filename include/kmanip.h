@@ -197,6 +197,14 @@ int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t
 int kmanip_enable_timing(KHandle h, int enable);
 int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, int32_t* nsteps);
 
+/* nsteps control steps in ONE launch, for callers that already hold the next nsteps actions of every env (action-chunking
+ * policies such as ACT, scripted / replayed action streams): exactly the result of nsteps consecutive kmanip_step calls,
+ * with act_dev float[nsteps, num_envs, act_dim], obs_dev double[nsteps, num_envs, obs_dim], reward_dev double[nsteps,
+ * num_envs], done_dev uint8[nsteps, num_envs].  Without a launch boundary per step the waves do not wait for the
+ * batch's slowest env at every step, so throughput follows the mean wave rather than the slowest one. */
+int kmanip_step_chunk(KHandle h, int nsteps, const float* act_dev, double* obs_dev, double* reward_dev,
+                      uint8_t* done_dev, void* stream);
+
 /* Standalone batched IK (ik_mujoco.ik, reference ik_mujoco.py:100-155) for parity tests:
  * qpos HOST double[n, nq] (in: current; out: qpos after the IK's last evaluation),
  * goal_pos double[n,3], goal_quat double[n,4] (wxyz), arm 0/1; q_out double[n, arm_nq]

