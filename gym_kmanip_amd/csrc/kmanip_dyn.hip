@@ -1,7 +1,8 @@
-// kmanip_dyn.hip -- the physics half of one control step, all envs, one launch (gfx950, wave64).
+// kmanip_dyn.hip -- one control step (or a chunk of them) of every env in ONE launch (gfx950, wave64).
 //
-// Replaces, for every env, `physics.step(n_sub_steps)` as dm_control runs it for KManipEnvSim.k_step
-// (reference gym_kmanip/env_sim.py:196-200, control_timestep :210): legacy order
+// Replaces, for every env, KManipEnvSim.k_step (reference gym_kmanip/env_sim.py:196-200): KManipTask.before_step
+// (env_sim.py:38-108: action decode + IK, device code in kmanip_ik_coop.hpp, fused in here) and then
+// `physics.step(n_sub_steps)` as dm_control runs it (control_timestep :210), legacy order
 //   mj_step2 (on products of the PRE-IK state) ; (n-1) x mj_step ; mj_step1
 // followed by KManipTask.get_reward (env_sim.py:148-179) and get_observation (env_sim.py:110-146), the
 // TimeLimit done flag (__init__.py:28,247) and, when enabled, the auto-reset
@@ -9,20 +10,23 @@
 //
 // Execution model ("many envs per wavefront"): a workgroup is ONE wave of 64 lanes holding 64/G envs;
 // each env is owned by a group of G lanes (G = 16 for nv = 16, G = 32 for nv = 26), lane d of the group
-// owning dof d: its component of qacc and its COLUMN of every contact-basis Jacobian (J and M^-1 J^T)
-// live in that lane's registers for the whole constraint solve.  Per-env intermediates that need random
-// access (body frames, joint-space inertia and inverse, group-uniform constraint scalars) sit in LDS --
-// about 8 KB per env, sized so that 16 envs fit one CU (4 workgroups x 4 envs) and all 4096 envs of the
-// headline config are resident in a single round.  HBM is touched once on entry and once on exit with
-// struct-of-arrays coalesced columns.  Per-env reductions (basis projections J.a, norms, costs) are DPP
-// row reductions (row_mirror / row_half_mirror / quad_perm; v_permlane16_swap across the two rows of a 32-lane group), not ds_bpermute.  A lane group never needs
-// s_barrier: all its lanes sit in one wave.
+// owning dof d: its component of qacc, its COLUMN of every contact-basis Jacobian, its ROW of the joint-space
+// inertia, of the Newton Hessian and of its Cholesky factor, and its own single-dof constraint rows all live in
+// that lane's registers.  The cooperative linear algebra exchanges values with DPP row broadcasts folded into the
+// FMA (v_fmac_f64_dpp row_newbcast; v_permlane16_swap copies for the two-row groups) -- no LDS, no synchronisation.
+// Per-env data that needs lane-indexed random access (body frames, M^-1, contact geometry and records) sits in LDS:
+// 7 KB per env for Solo, 15 KB for Dual/Torso in the Newton variant.  The kernel needs 400-500 registers, i.e. one
+// wave per SIMD: 16 Solo envs per CU, all 4096 envs of the headline config resident in a single round.  HBM is
+// touched once on entry and once on exit with struct-of-arrays coalesced columns.  Per-env reductions are DPP row
+// reductions (row_mirror / row_half_mirror / quad_perm, v_permlane16_swap across the rows of a 32-lane group) whose
+// result is bitwise identical on every lane (they opt out of FMA contraction for that reason).  A lane group never
+// needs s_barrier: all its lanes sit in one wave.
 //
 // Formulations deliberately differ from the oracle's (so parity is a cross-check, not a re-run):
 //   mass matrix      : composite inertias about the world origin, one column per lane (oracle: link-frame CRBA)
 //   bias forces      : per-body bias wrenches projected with J^T   (oracle: RNE backward recursion)
 //   M^-1             : explicit inverse, Gauss-Jordan on register rows (oracle: Cholesky factor + solves)
-//   Newton           : Hessian rows / Cholesky / solves in registers, DPP row broadcasts (oracle: dense LDS-free C)
+//   Newton           : incremental state, Hessian rows / Cholesky / solves in registers (oracle: dense, recomputed per iteration)
 //   constraint rows  : single-dof rows + 4-vector contact bases, pyramid edges expanded on the fly
 //   PGS              : per-contact block form on the 4x4 Gram matrix (algebraically the same row order)
 #include "kmanip_ik_coop.hpp"
