@@ -39,7 +39,7 @@ def measured_traffic(kernel_prefix="void k_step"):
     try:
         d = json.load(open(files[-1]))
         for k, v in d.items():
-            if k.startswith(kernel_prefix + "<10, 16, 1"):        # SoloArm / Newton instantiation (any envs-per-workgroup)
+            if k.startswith(kernel_prefix + "<10, 16, 1") and "true>" not in k:   # SoloArm / Newton, single-step kernel
                 # FETCH_SIZE under-reports wide 16 B/lane streams by 2x on gfx950; these are 8 B/lane column reads
                 # (uncalibrated width): reported as counted, see DESIGN.md
                 return (v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024.0, os.path.basename(files[-1])

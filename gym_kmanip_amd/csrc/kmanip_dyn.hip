@@ -78,7 +78,7 @@ struct Ws {
   real qpos[NQ], qvel[NV], ctrl[NL], warm[NV], qpos_ik[NL];
   union {
     // kinematics: live from fk() to the end of the contact-Jacobian build ...
-    struct { real xpos[NL][3], xquat[NL][4], xmat[NL][9], axis[NL][3], cpos[NL][3], cube_mat[9]; } k;
+    struct { real xpos[NL][3], xmat[NL][9], axis[NL][3], cpos[NL][3], cube_mat[9]; } k;
 #if KM_VAR_SOLVER == KM_SOLVER_PGS
     // ... then the same bytes hold the per-edge Gram rows Ge[c][e][l] = J_l . M^-1 (J_0 + sm J_k)^T for PGS
     struct { real Ge[NC][6][4]; } p;
@@ -130,7 +130,7 @@ template <int NL> struct CReg {
 #ifdef KM_PROFILE
 __device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
 #define KM_PROF_BLOCKS 4096
-__device__ unsigned long long g_prof_blk[KM_PROF_BLOCKS][KM_NPH];   // last launch, per workgroup (who is the slowest wave?)
+__device__ unsigned long long g_prof_blk[KM_PROF_BLOCKS][4][KM_NPH];   // last launch, per workgroup and lane group (who is slow?)
 struct Prof {
   unsigned long long t0, acc[KM_NPH];
   __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
@@ -141,7 +141,8 @@ struct Prof {
     __builtin_amdgcn_sched_barrier(0);
   }
   __device__ __forceinline__ void flush() {
-    if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) { atomicAdd(&g_prof[i], acc[i]); if (blockIdx.x < KM_PROF_BLOCKS) g_prof_blk[blockIdx.x][i] = acc[i]; }
+    if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) atomicAdd(&g_prof[i], acc[i]);
+    if ((threadIdx.x & 15) == 0 && blockIdx.x < KM_PROF_BLOCKS) for (int i = 0; i < KM_NPH; i++) g_prof_blk[blockIdx.x][threadIdx.x >> 4][i] = acc[i];
   }
 };
 #if KM_VAR_NL == 10 && KM_VAR_SOLVER == 1
@@ -152,7 +153,7 @@ extern "C" int kmanip_dbg_prof(unsigned long long* out, int reset) {
 }
 extern "C" int kmanip_dbg_prof_blocks(unsigned long long* out, int nblocks) {
   if (nblocks > KM_PROF_BLOCKS) return -1;
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_blk), sizeof(unsigned long long) * KM_NPH * nblocks) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_blk), sizeof(unsigned long long) * KM_NPH * 4 * nblocks) == hipSuccess ? 0 : -1;
 }
 #endif
 #else

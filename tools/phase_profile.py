@@ -32,19 +32,26 @@ print("solver", solver, "total ticks per block per step %.0f" % tot)
 for nm, x in zip(names, per):
     print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / tot))
 
-# ---- per-workgroup view of the LAST launch: the kernel ends when its slowest wave does
+# ---- per-workgroup, per-lane-group view of the LAST launch: the kernel ends when its slowest wave does, and a wave is as
+# slow as its slowest env in every phase.  Slot 13 ("integrate") of a group also holds its wait for the sibling envs.
 nb = n // 4
-blk = (C.c_ulonglong * (16 * nb))()
+blk = (C.c_ulonglong * (16 * 4 * nb))()
 if hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) == 0:
-    B = np.array(list(blk), dtype=np.float64).reshape(nb, 16)
-    tot_b = B.sum(1)
+    B = np.array(list(blk), dtype=np.float64).reshape(nb, 4, 16)
+    tot_b = B[:, 0, :].sum(1)                       # wave lifetime as seen by lane group 0
     order = np.argsort(tot_b)
     print("last launch: wave totals  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
         tot_b.mean(), np.median(tot_b), np.percentile(tot_b, 90), np.percentile(tot_b, 99), tot_b.max()))
-    print("  phase                      mean-wave   slowest-wave   mean of 10 slowest")
+    newton = [7, 8, 9, 10, 11, 12]
+    work = B.copy(); work[:, :, 13] = 0; work[:, :, 14] = 0     # drop the wait / tail slots: a group's OWN work
+    own = work.sum(2)                                            # [nb, 4]
+    slow_g = own.argmax(1)
     slow = order[-10:]
+    print("  phase                      mean group   busiest group of the 10 slowest waves")
     for i, nm in enumerate(names):
-        print("  %-26s %10.0f %12.0f %14.0f" % (nm, B[:, i].mean(), B[order[-1], i], B[slow, i].mean()))
+        print("  %-26s %10.0f %14.0f" % (nm, B[:, :, i].mean(), np.mean([B[wv, slow_g[wv], i] for wv in slow])))
+    print("  own work of that group: %.0f of the wave's %.0f cycles; Newton phases %.0f" % (
+        np.mean([own[wv, slow_g[wv]] for wv in slow]), tot_b[slow].mean(), np.mean([B[wv, slow_g[wv], newton].sum() for wv in slow])))
 
 # ---- IK kernel phases
 names_ik = ["initial eval+grad", "scaling + normal matrix", "trust-region solve", "select_step", "trial eval (res+jac)", "accept/grad", "tail (divergence wait)", "-"]
