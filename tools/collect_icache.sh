@@ -5,7 +5,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/ic_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT -o ic -- python bench.py --steps 16 --warmup 68 --no-cpu-baseline --no-pgs-variant > /dev/null 2> $OUT/ic.err
+rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT -o ic -- python bench.py --steps 16 --warmup 68 --no-cpu-baseline --no-pgs-variant --chunk 0 > /dev/null 2> $OUT/ic.err
 python - <<PY
 import csv, collections, json, glob
 out = {}

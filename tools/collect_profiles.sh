@@ -8,8 +8,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ktrace -- python bench.py --no-cpu-baseline --no-pgs-variant > $OUT/bench_under_prof.json 2> $OUT/ktrace.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-pgs-variant > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-pgs-variant > /dev/null 2> $OUT/write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-pgs-variant --chunk 0 > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-pgs-variant --chunk 0 > /dev/null 2> $OUT/write.err
 python - <<PY
 import csv, collections, json
 out = {}

@@ -5,7 +5,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/sq_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 16 --warmup 4 --no-cpu-baseline --no-pgs-variant"
+ARGS="--steps 16 --warmup 4 --no-cpu-baseline --no-pgs-variant --chunk 0"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT -o p1 -- python bench.py $ARGS > /dev/null 2> $OUT/p1.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES --output-format csv -d $OUT -o p2 -- python bench.py $ARGS > /dev/null 2> $OUT/p2.err
 python - <<PY
