@@ -376,3 +376,29 @@ def test_step_chunk_equals_single_steps(env, n, K):
         assert np.array_equal(x, y)
     assert (a.done.cpu().numpy() | 1).all() or True
     a.k_close(); b.k_close()
+
+
+def test_side_stream_execution():
+    """Every entry point takes the caller's stream: stepping on a non-default torch stream gives the same results as on
+    the default stream, and the work is really enqueued there (the event recorded on the side stream completes it)."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    n = 256
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=23); b = env_hip.make("KManipSoloArm", num_envs=n, seed=23)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(8)
+    acts = [(torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1) for _ in range(10)]
+    a.k_reset()
+    for act in acts:
+        a.step_flat(act)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        b.k_reset()
+        for act in acts:
+            b.step_flat(act)
+        ev = torch.cuda.Event(); ev.record(side)
+    ev.synchronize()
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    a.k_close(); b.k_close()
