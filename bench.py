@@ -69,6 +69,30 @@ def measure_chunked(env, cm, n, K, gen):
             "note": "no launch boundary per step: waves do not wait for the batch's slowest env at every step"}
 
 
+def measured_valu(kernel_prefix="void k_step<10, 16, 1"):
+    """VALU-side view of the dominant kernel from the committed SQ counters (profiles/<round>_sq_counters.json, two
+    rocprofv3 --pmc passes, tools/collect_sq.sh): the share of wave cycles spent issuing VALU instructions and the
+    share of lanes active in them.  Their product is the fraction of the chip's FP64 vector issue slots doing work
+    (one wave per SIMD here), the bound SURVEY 8d asks for beside the HBM one; MFMA utilisation is 0 (no MFMA
+    instruction in the kernel: there is no dense contraction on this path)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and "true>" not in k:
+                issue = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+                lanes = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0)
+                return {"valu_issue_frac": issue, "lane_util": lanes, "fp64_vector_slot_frac": issue * lanes,
+                        "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "mfma_util": 0.0,
+                        "source": os.path.basename(files[-1])}
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     try:
@@ -240,6 +264,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_env_step": algorithmic_bytes_per_env_step(cm),
                          "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1)},
+                         "valu": measured_valu() if (args.solver == "newton" and args.env == "KManipSoloArm" and n == 4096) else None,
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }
         if not args.no_pgs_variant and args.solver == "newton" and world == 1:
