@@ -1637,7 +1637,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   pf.ph(15);
   // nchunk control steps per launch (kmanip_step: 1).  With a chunk of pre-supplied actions every wave runs its envs
   // through all of them without meeting the other waves at a launch boundary, so the batch advances at the MEAN wave
-  // speed instead of the slowest wave's (DESIGN.md 3.5); the state stays in LDS between the steps of a chunk.
+  // speed instead of the slowest wave's (DESIGN.md 3.4); the state stays in LDS between the steps of a chunk.
   const int nsteps = CHUNK ? nchunk : 1;      // (the single-step kernel keeps its register allocation: no outer loop)
   for (int kc = 0; kc < nsteps; kc++) {
   if (fused) {
