@@ -177,6 +177,13 @@ class Oracle:
         ne = nefc.value
         return dict(M=M, bias=bias, qacc_smooth=qs, qacc=qa, nefc=ne, J=J[:ne], aref=aref[:ne], R=R[:ne])
 
+    def constraint_rows(self, qpos, qvel):
+        ne_max = self.L.ko_nefc_max()
+        t = np.zeros(ne_max, dtype=np.int32); fl = np.zeros(ne_max)
+        n = self.L.ko_constraint_rows(C.byref(self.desc), _p(_f64(qpos)), _p(_f64(qvel)), _p(t, C.c_int32), _p(fl))
+        assert n >= 0
+        return t[:n], fl[:n]
+
     def render_depth(self, qpos, cam=0, h=64, w=64):
         out = np.zeros((h, w), dtype=np.float32)
         self.L.ko_render_depth(C.byref(self.desc), _p(_f64(qpos)), cam, h, w, _p(out, C.c_float))

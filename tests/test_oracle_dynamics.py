@@ -219,3 +219,62 @@ def test_oracle_scripted_policy_points_at_cube():
         want = qpos[e][cm.nlink:cm.nlink + 3] - sp[0]
         assert abs(np.linalg.norm(d) - 1) < 1e-14
         assert np.abs(d - want / np.linalg.norm(want)).max() < 1e-14
+
+
+@pytest.mark.parametrize("env", ["KManipSoloArm", "KManipDualArm"])
+def test_newton_solution_vs_scipy_minimize(env):
+    """External pin of the constraint solve: on constraint problems taken from a rollout (contacts, limits, friction
+    loss active) the oracle's qacc must be the minimiser of MuJoCo's primal cost
+        1/2 (a - a_s)^T M (a - a_s) + sum_i s_i(J_i a - aref_i)
+    as found by SciPy's own trust-region Newton (scipy.optimize.minimize, method='trust-exact') from a cold start."""
+    from scipy.optimize import minimize
+    cm = compile_model(env)
+    n = 6
+    orc = Oracle(cm, n, seed=3)
+    orc.reset()
+    rng = np.random.default_rng(5)
+    checked = 0
+    for step in range(24):
+        orc.step(rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32))
+        if step < 14 or step % 3:
+            continue
+        qpos, qvel, ctrl, _, _ = orc.get_state()
+        for e in range(n):
+            d = orc.dynamics(qpos[e], qvel[e], ctrl[e])
+            typ, fl = orc.constraint_rows(qpos[e], qvel[e])
+            ne = d["nefc"]
+            assert ne == len(typ) and ne > 0
+            M, a_s, J, aref, R = d["M"], d["qacc_smooth"], d["J"], d["aref"], d["R"]
+            D = 1.0 / R
+
+            def parts(a):
+                x = J @ a - aref
+                lin_lo = (typ == 0) & (x <= -R * fl); lin_hi = (typ == 0) & (x >= R * fl)
+                quad = ((typ == 0) & ~lin_lo & ~lin_hi) | ((typ == 1) & (x < 0))
+                return x, lin_lo, lin_hi, quad
+
+            def cost(a):
+                x, lo, hi, quad = parts(a)
+                r = a - a_s
+                c = 0.5 * r @ M @ r + 0.5 * np.sum(D[quad] * x[quad] ** 2)
+                c += np.sum(fl[lo] * (-0.5 * R[lo] * fl[lo] - x[lo])) + np.sum(fl[hi] * (-0.5 * R[hi] * fl[hi] + x[hi]))
+                return c
+
+            def grad(a):
+                x, lo, hi, quad = parts(a)
+                f = np.zeros(ne)
+                f[quad] = D[quad] * x[quad]; f[lo] = -fl[lo]; f[hi] = fl[hi]
+                return M @ (a - a_s) + J.T @ f
+
+            def hess(a):
+                _, _, _, quad = parts(a)
+                Jq = J[quad]
+                return M + Jq.T @ (D[quad][:, None] * Jq)
+
+            res = minimize(cost, a_s.copy(), jac=grad, hess=hess, method="trust-exact", options={"gtol": 1e-9, "maxiter": 500})
+            scale = 1.0 + np.abs(d["qacc"]).max()
+            assert np.linalg.norm(grad(d["qacc"])) <= 1e-6 * scale * np.linalg.norm(M, 2), (step, e)      # KKT at the oracle's point
+            assert cost(d["qacc"]) <= cost(res.x) + 1e-9 * (1 + abs(cost(res.x)))                         # no worse than SciPy's minimum
+            assert np.abs(res.x - d["qacc"]).max() <= 1e-5 * scale, (step, e, np.abs(res.x - d["qacc"]).max())
+            checked += 1
+    assert checked >= 12
