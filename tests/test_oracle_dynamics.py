@@ -278,3 +278,38 @@ def test_newton_solution_vs_scipy_minimize(env):
             assert np.abs(res.x - d["qacc"]).max() <= 1e-5 * scale, (step, e, np.abs(res.x - d["qacc"]).max())
             checked += 1
     assert checked >= 12
+
+
+def test_cube_free_fall_and_rest():
+    """Closed-form anchors for the contact-free and the resting phase of the cube (arm held at home by zero
+    joint-delta actions): in free fall the only forces on the cube are gravity and the saturated friction-loss row of
+    its free joint, so dv_z = (-g + floss / m) dt per sub-step; at the end of the episode it rests on the table with a
+    soft-contact penetration of a fraction of a millimetre and (numerically) zero velocity."""
+    cm = compile_model("KManipSoloArmQPos")
+    d = cm.desc
+    nl = cm.nlink
+    orc = Oracle(cm, 4, seed=11)
+    orc.reset()
+    act = np.zeros((4, cm.act_dim), dtype=np.float32)
+    a_fall = d.gravity[2] + d.cube_frictionloss / d.cube_mass            # -9.81 + 0.2
+    qpos0 = orc.get_state()[0].copy()
+    orc.step(act)
+    qpos1, qvel1 = orc.get_state()[:2]
+    falling = qpos1[:, nl + 2] - d.cube_half[2] > d.table_z + 1e-3       # still clear of the table after 10 sub-steps
+    assert falling.any()
+    # the first sub-step starts from rest inside the friction-loss dead zone (R * floss), all later ones are saturated:
+    # v after 10 sub-steps lies between 9 and 10 saturated sub-steps' worth
+    vz = qvel1[falling, nl + 2]
+    assert (vz < 9 * a_fall * d.timestep + 1e-9).all() and (vz > 10 * a_fall * d.timestep - 1e-9).all()
+    orc.step(act)
+    vz2 = orc.get_state()[1][:, nl + 2]
+    still = falling & (orc.get_state()[0][:, nl + 2] - d.cube_half[2] > d.table_z + 1e-3)
+    assert np.abs((vz2 - qvel1[:, nl + 2])[still] - 10 * a_fall * d.timestep).max() < 1e-9     # pure saturated fall
+    for _ in range(58):
+        orc.step(act)
+    qpos, qvel = orc.get_state()[:2]
+    pen = d.table_z + d.cube_half[2] - qpos[:, nl + 2]
+    assert (pen > 0).all() and (pen < 1e-3).all()                           # resting: sub-millimetre soft penetration
+    assert np.abs(qvel[:, nl:nl + 6]).max() < 1e-4
+    straight = np.abs(qpos[:, nl:nl + 2] - qpos0[:, nl:nl + 2]).max(axis=1) < 1e-6
+    assert straight.sum() >= 3                                             # it fell straight down (one spawn may brush the home-pose gripper)
