@@ -402,3 +402,34 @@ def test_side_stream_execution():
     for x, y in zip(a.get_state(), b.get_state()):
         assert np.array_equal(x, y)
     a.k_close(); b.k_close()
+
+
+def test_episode_logger_from_device_buffers(tmp_path):
+    """SURVEY 8f rank 3 on the GPU: a full scripted-policy episode logged from the handle's device buffers (no host
+    traffic on the step path), then read back: the files hold exactly the actions taken and the observations returned."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.episode_log import EpisodeLogger
+    from gym_kmanip_amd.model import MAX_EPISODE_STEPS
+    n = 32
+    e = env_hip.make("KManipSoloArm", num_envs=n, seed=31, auto_reset=False)
+    cm = e.cm
+    lg = EpisodeLogger(str(tmp_path), n, cm.nlink, cm.act_dim, device="cuda", env_ids=[0, 7, 31],
+                       info={"sim": True, "env_id": "KManipSoloArm"}, backend="npz")
+    e.k_reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    acts, qps, qvs = [], [], []
+    sq, sv = cm.obs_slices["q_pos"], cm.obs_slices["q_vel"]
+    for k in range(MAX_EPISODE_STEPS):
+        act = e.scripted_action(generator=gen)
+        e.step_flat(act)
+        lg.step(act, e.obs[:, sq], e.obs[:, sv])
+        acts.append(act.cpu().numpy()); qps.append(e.obs[:, sq].cpu().numpy()); qvs.append(e.obs[:, sv].cpu().numpy())
+    assert (e.done.cpu().numpy() & KM_DONE_TRUNCATED).all()
+    paths = lg.end_episode()
+    assert len(paths) == 3
+    z = np.load(paths[1])                                                   # env 7
+    assert np.array_equal(z["action"], np.stack(acts)[:, 7])
+    assert np.array_equal(z["observations/qpos"], np.stack(qps)[:, 7].astype(np.float32))
+    assert np.array_equal(z["observations/qvel"], np.stack(qvs)[:, 7].astype(np.float32))
+    e.k_close()
