@@ -67,3 +67,14 @@ def test_bad_model_rejected(L):
     h = C.c_void_p()
     assert L.kmanip_create(C.byref(d), 4, 0, C.c_uint64(0), C.c_int64(0), C.byref(h)) != 0
     assert b"nlink" in L.kmanip_last_error(None)
+
+
+def test_header_is_plain_c():
+    """The drop-in boundary is a C ABI: include/kmanip.h must compile as C99 (and as C++) on its own."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "kmanip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", hdr])
