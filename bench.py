@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- env steps/sec of the hot path (KManipSoloArm @ 4096 envs per GPU) on N MI355X.
+"""bench.py -- env steps/sec of the hot path (default: KManipSoloArm @ 4096 envs per GPU) on N MI355X.
 
 A "step" is one control step of every env on the rank = one pass of the hot path
 (decode + IK -> 10 physics sub-steps -> reward/obs/done, auto-reset every 64 steps) over one batch of
@@ -8,89 +8,159 @@ shard by global env index with no data-path collective except the per-step rewar
 north star names (RCCL, async, off the critical path).  Rank 0 prints ONE JSON line.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu 4096] [--env KManipSoloArm]
+
+`--gpus N` with N > 1 and no RANK in the environment: this process starts N fresh rank processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE touching the GPU, waits for them and exits with their worst
+code; under `python -m torch.distributed.run` the ranks are already there and it just runs as one of them.
+
+Steady state: the timed region always runs on DESYNCHRONISED envs -- before the W warm-up steps an untimed
+preparation staggers the per-env episode phase uniformly over 0..63 and pre-rolls one full episode, so that every
+launch sees the same mix of falling / landing / resting cubes and reset envs whatever K and W are (episodes are
+exactly 64 steps long, so envs that all start together would otherwise stay phase-locked for ever and a short window
+would time whichever phase it happens to fall on).  `phase_locked` in the JSON line is the same workload without
+the stagger over whole episodes.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+EPISODE = 64                      # MAX_EPISODE_STEPS, gym_kmanip/__init__.py:28
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 
 
-def algorithmic_bytes_per_env_step(cm):
-    """DESIGN.md section 'Roofline': float64 state read once + written once, action read, outputs written."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024, help="timed control steps (default ~1 s at 4096 envs)")
+    ap.add_argument("--warmup", type=int, default=16, help="untimed steps after the (also untimed) desynchronising preparation")
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-total", type=int, default=0,
+                    help="strong-scaling variant: split this many envs over the GPUs (contiguous shards) instead of --envs-per-gpu each")
+    ap.add_argument("--env", default="KManipSoloArm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="also render a DxD gripper-cam depth image per env each step (BASELINE config 5)")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-stagger", action="store_true", help="keep all envs phase-locked (episode phase = step index for every env)")
+    ap.add_argument("--solver-iterations", type=int, default=100, help="solver iteration cap (MuJoCo default 100); ablation only")
+    ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
+                    help="newton = MuJoCo default, what the reference runs; pgs = the north star's named solver (100 sweeps)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (phase-locked, PGS, chunked, seam)")
+    ap.add_argument("--chunk", type=int, default=16, help="also time kmanip_step_chunk with this many control steps per launch (0: skip)")
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# multi-GPU self-launch: the parent never initialises HIP and never execs
+def free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """Start args.gpus fresh rank processes of this script (one per GPU) and wait for them.  Rank 0 inherits stdout, so
+    its single JSON line is this command's output; the other ranks' stdout goes to stderr."""
+    world = args.gpus
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KMANIP_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("KMANIP_BENCH_TIMEOUT", "1500"))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if (rc != 0 or time.time() > deadline) and live:
+            # a rank died (or the run timed out): its peers would wait for it in the rendezvous -- stop exactly the
+            # processes started above, after a short grace for their own error messages
+            time.sleep(2.0)
+            for q in live:
+                if q.poll() is None:
+                    q.kill()
+            for q in live:
+                q.wait()
+            rc = rc or -9
+            break
+        time.sleep(0.05)
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank process failed (exit code %s)\n" % rc)
+    return 1 if rc else 0
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def algorithmic_bytes_per_env_step(cm, depth=0):
+    """float64 state read once + written once, action read, outputs written (+ the float32 depth image
+    of BASELINE config 5 when rendered in the step)."""
     state = (cm.nq + cm.nv + cm.nu + cm.nv) * 8          # qpos, qvel, ctrl, qacc_warmstart
-    return 2 * state + cm.act_dim * 4 + cm.obs_dim * 8 + 8 + 1
+    return 2 * state + cm.act_dim * 4 + cm.obs_dim * 8 + 8 + 1 + depth * depth * 4
 
 
-def measured_traffic(kernel_prefix="void k_step"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes, KB units; profiles/<round>_pmc_hbm.json).  bench.py cannot run rocprofv3 on
-    itself, so the number is the last committed measurement of this kernel, or None."""
+def _committed(name_glob):
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1]))
-        for k, v in d.items():
-            if k.startswith(kernel_prefix + "<10, 16, 1") and "true>" not in k:   # SoloArm / Newton, single-step kernel
-                # FETCH_SIZE under-reports wide 16 B/lane streams by 2x on gfx950; these are 8 B/lane column reads
-                # (uncalibrated width): reported as counted, see DESIGN.md
-                return (v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024.0, os.path.basename(files[-1])
-    except Exception:  # noqa: BLE001
-        pass
-    return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", name_glob)))
+    return files[-1] if files else None
 
 
-def measure_chunked(env, cm, n, K, gen):
-    """Secondary measurement: the same workload through kmanip_step_chunk (K pre-supplied actions per env and launch,
-    as an action-chunking policy or a scripted stream provides).  Not the headline: the metric is per-step stepping."""
-    import torch
-    acts = (torch.rand((K, n, cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous()
-    obs = torch.empty((K, n, cm.obs_dim), dtype=torch.float64, device="cuda")
-    rew = torch.empty((K, n), dtype=torch.float64, device="cuda"); done = torch.empty((K, n), dtype=torch.uint8, device="cuda")
-    for _ in range(4):
-        env.step_chunk(acts, obs, rew, done)
-    torch.cuda.synchronize()
-    launches = 16
-    t0 = time.perf_counter()
-    for _ in range(launches):
-        env.step_chunk(acts, obs, rew, done)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"api": "kmanip_step_chunk", "steps_per_launch": K, "value": n * K * launches / dt, "unit": "env steps/s",
-            "ms_per_env_step_batch": dt / (K * launches) * 1e3,
-            "note": "no launch boundary per step: waves do not wait for the batch's slowest env at every step"}
-
-
-def measured_valu(kernel_prefix="void k_step<10, 16, 1"):
-    """VALU-side view of the dominant kernel from the committed SQ counters (profiles/<round>_sq_counters.json, two
-    rocprofv3 --pmc passes, tools/collect_sq.sh): the share of wave cycles spent issuing VALU instructions and the
-    share of lanes active in them.  Their product is the fraction of the chip's FP64 vector issue slots doing work
-    (one wave per SIMD here), the bound SURVEY 8d asks for beside the HBM one; MFMA utilisation is 0 (no MFMA
-    instruction in the kernel: there is no dense contraction on this path)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-        for k, v in d.items():
-            if k.startswith(kernel_prefix) and "true>" not in k:
-                issue = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
-                lanes = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0)
-                return {"valu_issue_frac": issue, "lane_util": lanes, "fp64_vector_slot_frac": issue * lanes,
-                        "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "mfma_util": 0.0,
-                        "source": os.path.basename(files[-1])}
-    except Exception:  # noqa: BLE001
-        pass
-    return None
+def committed_counters(version, kernel_prefix):
+    """Counter-derived figures of the dominant kernel (HBM traffic, VALU issue / lane utilisation, hardware-counted FP64
+    FLOPs) from the LAST committed rocprofv3 --pmc summaries.  bench.py cannot run rocprofv3 on itself, so these are the
+    last committed measurement of this kernel -- and only if that measurement was taken on the same library version
+    (`_meta.version` in the file == kmanip_version()): a stale file is refused (None + `stale`)."""
+    out = {"traffic": None, "traffic_source": None, "valu": None, "flops": None}
+    f = _committed("*_pmc_hbm.json")
+    if f:
+        d = json.load(open(f))
+        if d.get("_meta", {}).get("version") != version:
+            out["traffic_source"] = "stale: %s was measured on %r" % (os.path.basename(f), d.get("_meta", {}).get("version"))
+        else:
+            for k, v in d.items():
+                if k.startswith(kernel_prefix) and "true>" not in k:
+                    # FETCH_SIZE under-reports wide 16 B/lane streams by 2x on gfx950; these are 8 B/lane column reads
+                    # (uncalibrated width): reported as counted, see DESIGN.md
+                    out["traffic"] = (v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024.0
+                    out["traffic_source"] = os.path.basename(f)
+    f = _committed("*_sq_counters.json")
+    if f:
+        d = json.load(open(f))
+        if d.get("_meta", {}).get("version") != version:
+            out["valu"] = {"stale": "%s was measured on %r" % (os.path.basename(f), d.get("_meta", {}).get("version"))}
+        else:
+            for k, v in d.items():
+                if k.startswith(kernel_prefix) and "true>" not in k:
+                    issue = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+                    lanes = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0)
+                    out["valu"] = {"valu_issue_frac": issue, "lane_util": lanes, "fp64_vector_slot_frac": issue * lanes,
+                                   "wait_frac": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], "mfma_util": 0.0,
+                                   "source": os.path.basename(f)}
+                    if "SQ_INSTS_VALU_FMA_F64" in v:
+                        # per-launch FP64 FLOPs as the hardware counted them: wave-level instruction counts x 64 lanes
+                        # (an upper bound: masked lanes are counted), FMA = 2 flops
+                        fl = 64.0 * (2 * v["SQ_INSTS_VALU_FMA_F64"] + v.get("SQ_INSTS_VALU_ADD_F64", 0) + v.get("SQ_INSTS_VALU_MUL_F64", 0)
+                                     + v.get("SQ_INSTS_VALU_TRANS_F64", 0))
+                        out["flops"] = {"fp64_flops_per_launch_issued": fl, "fp64_flops_per_launch_active_lanes": fl * lanes,
+                                        "source": os.path.basename(f)}
+    return out
 
 
 def usable_cores():
@@ -115,28 +185,11 @@ def usable_cores():
     return n
 
 
-def measure_variant(env_id, solver, n, local_rank, rank, steps=16, warmup=12):
-    """Short single-rank measurement of the other constraint solver on the same workload (reported, not `value`)."""
-    from gym_kmanip_amd import env_hip
-    from gym_kmanip_amd.model import compile_model
-    cm = compile_model(env_id, auto_reset=True, solver=solver)
-    env = env_hip.KManipEnvHip(cm, num_envs=n, device=local_rank, seed=0, env_id_offset=rank * n)
-    gen = torch.Generator(device="cuda"); gen.manual_seed(99)
-    acts = [(torch.rand((n, cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous() for _ in range(8)]
-    env.k_reset()
-    for k in range(warmup):
-        env.step_flat(acts[k % 8])
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for k in range(steps):
-        env.step_flat(acts[k % 8])
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    env.k_close()
-    return {"solver": solver, "value": n * steps / dt, "unit": "env steps/s", "steps": steps, "ms_per_step": dt / steps * 1e3}
-
-
 def cpu_baseline(cm, n_envs, budget_s=12.0):
-    """The oracle (a C port of the reference path; the reference itself cannot run here) timed on this
-    box's host cores with OpenMP over envs, on a bounded sample of the same workload."""
+    """The oracle (a C port of the reference path; the reference itself cannot run here: mujoco / dm_control / gymnasium
+    are absent from this image and from the GPU box, profiles/r02_probe_imports.txt) timed on this box's host cores
+    with OpenMP over envs, on a bounded sample of the same workload."""
+    import numpy as np
     from oracle.oracle import Oracle
     cores = usable_cores()
     n = min(n_envs, 1024)
@@ -154,42 +207,131 @@ def cpu_baseline(cm, n_envs, budget_s=12.0):
             break
     return {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d control steps (episode steps 10..%d, contacts active), OpenMP over envs, %d threads"
-                      % (n, steps, 10 + steps, cores)}
+                      % (n, steps, 10 + steps, cores),
+            "mujoco": "absent on the GPU box (import probe: profiles/r02_probe_imports.txt), so no MuJoCo-timed baseline"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=64, help="untimed steps (default: one full 64-step episode, so timed steps see the steady-state mix)")
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
-    ap.add_argument("--envs-total", type=int, default=0,
-                    help="strong-scaling variant: split this many envs over the GPUs (contiguous shards) instead of --envs-per-gpu each")
-    ap.add_argument("--env", default="KManipSoloArm")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--depth", type=int, default=0, help="also render a DxD gripper-cam depth image per env each step (BASELINE config 5)")
-    ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--solver-iterations", type=int, default=100, help="solver iteration cap (MuJoCo default 100); ablation only")
-    ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
-                    help="newton = MuJoCo default, what the reference runs; pgs = the north star's named solver (100 sweeps)")
-    ap.add_argument("--no-pgs-variant", action="store_true", help="skip the extra short PGS measurement")
-    ap.add_argument("--chunk", type=int, default=16, help="also time kmanip_step_chunk with this many control steps per launch (0: skip)")
-    args = ap.parse_args()
+class Workload:
+    """One rank's envs + action bank, prepared to the desynchronised steady state."""
 
+    def __init__(self, torch, env_id, n, device_index, rank, off, solver, solver_iterations, seed_gen, stagger=True, nbank=16):
+        from gym_kmanip_amd import env_hip
+        from gym_kmanip_amd.model import compile_model
+        import numpy as np
+        self.torch = torch
+        self.cm = compile_model(env_id, auto_reset=True, solver_iterations=solver_iterations, solver=solver)
+        self.n = n
+        self.env = env_hip.KManipEnvHip(self.cm, num_envs=n, device=device_index, seed=0, env_id_offset=off)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(seed_gen)
+        self.gen = gen
+        self.nbank = nbank
+        self.acts = [(torch.rand((n, self.cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous() for _ in range(nbank)]
+        self.k = 0
+        self.env.k_reset()
+        if stagger:
+            # episode phase of env e = (global env id) % 64: the auto-reset then fires for n/64 envs at every step
+            phase = ((off + np.arange(n)) % EPISODE).astype(np.int32)
+            self.env.set_state(step=phase)
+            self.run(EPISODE)             # one full episode: every env has been through its own reset since the stagger
+        torch.cuda.synchronize()
+
+    def step(self):
+        self.env.step_flat(self.acts[self.k % self.nbank]); self.k += 1
+
+    def run(self, steps):
+        for _ in range(steps):
+            self.step()
+
+    def timed(self, steps, warmup):
+        torch = self.torch
+        self.run(warmup)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        self.run(steps)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def close(self):
+        self.env.k_close()
+
+
+def measure_variant(torch, args, n, local_rank, rank, solver, stagger, steps, warmup):
+    w = Workload(torch, args.env, n, local_rank, rank, rank * n, solver, args.solver_iterations, 99, stagger=stagger)
+    dt = w.timed(steps, warmup)
+    w.close()
+    return {"solver": solver, "staggered": stagger, "value": n * steps / dt, "unit": "env steps/s", "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "timed_window_s": dt}
+
+
+def measure_chunked(torch, w, K):
+    """Secondary: the same workload through kmanip_step_chunk (K pre-supplied actions per env and launch, as an
+    action-chunking policy or a scripted stream provides).  Not the headline: the metric is per-step stepping."""
+    n, cm, env = w.n, w.cm, w.env
+    acts = (torch.rand((K, n, cm.act_dim), generator=w.gen, device="cuda") * 2 - 1).contiguous()
+    obs = torch.empty((K, n, cm.obs_dim), dtype=torch.float64, device="cuda")
+    rew = torch.empty((K, n), dtype=torch.float64, device="cuda"); done = torch.empty((K, n), dtype=torch.uint8, device="cuda")
+    for _ in range(4):
+        env.step_chunk(acts, obs, rew, done)
+    torch.cuda.synchronize()
+    launches = 16
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        env.step_chunk(acts, obs, rew, done)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"api": "kmanip_step_chunk", "steps_per_launch": K, "value": n * K * launches / dt, "unit": "env steps/s",
+            "ms_per_env_step_batch": dt / (K * launches) * 1e3,
+            "note": "no launch boundary per step: waves do not wait for the batch's slowest env at every step"}
+
+
+def measure_seam(torch, w, steps=256):
+    """The drop-in path: KManipEnvHip.k_step with a DICT of device tensors keyed like the reference action space
+    (env_base.py:241-259 -> env_sim.py:196-200), returning the 5-tuple -- vs step_flat on the same envs."""
+    n, cm, env = w.n, w.cm, w.env
+    bank = [{k: a[:, sl] for k, sl in cm.act_slices.items()} for a in w.acts]
+    for k in range(8):
+        env.k_step(bank[k % len(bank)])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(steps):
+        terminated, reward, discount, obs, sim_time = env.k_step(bank[k % len(bank)])
+    torch.cuda.synchronize(); dt_seam = time.perf_counter() - t0
+    for k in range(8):
+        env.step_flat(w.acts[k % len(w.acts)])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(steps):
+        env.step_flat(w.acts[k % len(w.acts)])
+    torch.cuda.synchronize(); dt_flat = time.perf_counter() - t0
+    return {"api": "KManipEnvHip.k_step(dict of device tensors) -> (terminated, reward, discount, obs dict, sim_time)",
+            "value": n * steps / dt_seam, "unit": "env steps/s", "steps": steps, "step_flat_value": n * steps / dt_flat,
+            "ratio_to_step_flat": dt_flat / dt_seam}
+
+
+def run_rank(args):
+    import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node %d, or let bench.py spawn the ranks)\n"
+                         % (world, args.gpus, args.gpus))
+        return 2
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py needs a HIP device (no CPU fallback)\n")
+        return 3
+    if local_rank >= torch.cuda.device_count() and os.environ.get("KMANIP_BENCH_ONE_GPU") != "1":
+        sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (local_rank, torch.cuda.device_count()))
+        return 3
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 and gloo in place of RCCL, which
+    # refuses two ranks on one device -- everything else of the multi-rank path is the same code
+    backend = os.environ.get("KMANIP_BENCH_BACKEND", "nccl")
+    if os.environ.get("KMANIP_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
-    from gym_kmanip_amd import env_hip
-    from gym_kmanip_amd.model import compile_model
-    cm = compile_model(args.env, auto_reset=True, solver_iterations=args.solver_iterations, solver=args.solver)
     if args.envs_total:
         assert args.envs_total % world == 0, "--envs-total must be a multiple of the GPU count (equal shards for the gather)"
         from gym_kmanip_amd.dist import shard_range
@@ -197,21 +339,22 @@ def main():
         n, off = hi - lo, lo
     else:
         n, off = args.envs_per_gpu, rank * args.envs_per_gpu
-    env = env_hip.KManipEnvHip(cm, num_envs=n, device=local_rank, seed=0, env_id_offset=off)
-    gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + rank)
-    nbank = 16
-    acts = [(torch.rand((n, cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous() for _ in range(nbank)]
-    env.k_reset()
+    w = Workload(torch, args.env, n, local_rank, rank, off, args.solver, args.solver_iterations, 1234 + rank,
+                 stagger=not args.no_stagger)
+    env, cm = w.env, w.cm
 
     gather = None
-    if dist is not None and not args.no_gather:
-        from gym_kmanip_amd.dist import RewardDoneGather
-        gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist)
+    ranks_seen = 1
+    if dist is not None:
+        t = torch.ones(1, device="cuda"); dist.all_reduce(t); ranks_seen = int(t.item())      # RCCL really spans all ranks
+        if not args.no_gather:
+            from gym_kmanip_amd.dist import RewardDoneGather
+            gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist)
 
     depth_buf = torch.empty((n, args.depth, args.depth), dtype=torch.float32, device="cuda") if args.depth else None
 
-    def one_step(k):
-        env.step_flat(acts[k % nbank])
+    def one_step():
+        w.step()
         if depth_buf is not None:
             env.render_depth("grip_r", args.depth, args.depth, out=depth_buf)
         if gather is not None:
@@ -223,13 +366,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        one_step(k)
+    for _ in range(args.warmup):
+        one_step()
     barrier()
     env.enable_timing(True)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k)
+    for _ in range(args.steps):
+        one_step()
     if gather is not None:
         gather.wait()
     barrier()
@@ -242,44 +385,84 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
+        version = env.L.kmanip_version().decode()
         total_envs = args.envs_total if args.envs_total else world * n
         total_env_steps = total_envs * args.steps
-        bytes_per_launch = algorithmic_bytes_per_env_step(cm) * n
+        bpe = algorithmic_bytes_per_env_step(cm, args.depth)
+        bytes_per_launch = algorithmic_bytes_per_env_step(cm) * n        # k_step alone (the depth image is k_render_depth's)
         dyn_avg_s = dyn_ms / max(nt, 1) * 1e-3
         achieved = bytes_per_launch / dyn_avg_s / 1e9
-        traffic, traffic_src = measured_traffic() if (args.solver == "newton" and args.env == "KManipSoloArm" and n == 4096) else (None, None)
+        nl = cm.nlink
+        kprefix = "void k_step<%d, %d, %d" % (10 if nl <= 10 else 20, 16 if nl <= 10 else 32, 1 if args.solver == "newton" else 0)
+        cc = committed_counters(version, kprefix) if (args.env == "KManipSoloArm" and n == 4096 and not args.no_stagger) else \
+            {"traffic": None, "traffic_source": "committed counters are for KManipSoloArm @ 4096 envs only", "valu": None, "flops": None}
+        headline = args.env == "KManipSoloArm" and n == 4096
+        metric = "env steps/sec (whole node), KManipSoloArm @4096 envs, 1/2/4/8 MI355X" if headline else \
+            "env steps/sec (whole node), %s @%d envs per GPU, %d MI355X" % (args.env, n, world)
+        valu = cc["valu"]
+        if cc["flops"] and valu is not None and "stale" not in valu:
+            fl = cc["flops"]["fp64_flops_per_launch_active_lanes"]
+            valu = dict(valu, fp64_flops_per_env_step=fl / n, achieved_tflops=fl / dyn_avg_s / 1e12,
+                        flop_frac=fl / dyn_avg_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS, peak_tflops=FP64_VECTOR_PEAK_TFLOPS,
+                        flops_source=cc["flops"]["source"])
         out = {
-            "metric": "env steps/sec (whole node), KManipSoloArm @4096 envs, 1/2/4/8 MI355X",
+            "metric": metric,
             "value": total_env_steps / dt, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.envs_total else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, %d envs per GPU (%d total), no cameras, random U(-1,1) actions, 64-step episodes with auto-reset"
-                                   % (args.env, n, total_envs),
+            "timed_window_s": dt,
+            "config": {"workload": "%s, %d envs per GPU (%d total), %s, random U(-1,1) actions, 64-step episodes with auto-reset, %s"
+                                   % (args.env, n, total_envs, ("%dx%d float32 grip_r depth render in the step" % (args.depth, args.depth)) if args.depth else "no cameras",
+                                      "phase-locked envs" if args.no_stagger else "envs desynchronised (episode phase = global env id % 64, one pre-rolled episode)"),
                        "envs_per_gpu": n, "depth_image": ("%dx%d float32 grip_r" % (args.depth, args.depth)) if args.depth else None,
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
-                       "collective": "async all_gather of (reward, done) per step" if gather is not None else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                       "collective": "async all_gather of (reward, done) per step" if gather is not None else "none",
+                       "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None, "library": version},
+            "roofline": {"bound": "hbm", "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": cc["traffic"], "traffic_source": cc["traffic_source"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "bytes_per_env_step": algorithmic_bytes_per_env_step(cm),
-                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1)},
-                         "valu": measured_valu() if (args.solver == "newton" and args.env == "KManipSoloArm" and n == 4096) else None,
+                         "bytes_per_env_step": bpe,
+                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1), "launches_timed": nt},
+                         "valu": valu,
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }
-        if not args.no_pgs_variant and args.solver == "newton" and world == 1:
-            out["pgs_variant"] = measure_variant(args.env, "pgs", n, local_rank, rank)
-        if args.chunk > 1 and world == 1 and not args.depth:
-            out["chunked_variant"] = measure_chunked(env, cm, n, args.chunk, gen)
+        if dt < 0.25:
+            out["warning"] = "timed window %.3f s < 0.25 s: too short for a stable rate (use --steps >= %d)" % (dt, int(0.3 / (dt / args.steps)) + 1)
+        if world == 1 and not args.no_variants:
+            torch.cuda.synchronize()
+            if not args.depth:
+                out["seam_variant"] = measure_seam(torch, w)
+                if args.chunk > 1:
+                    out["chunked_variant"] = measure_chunked(torch, w, args.chunk)
+            w.close()
+            if not args.no_stagger:
+                out["phase_locked"] = measure_variant(torch, args, n, local_rank, rank, args.solver, False, 4 * EPISODE, EPISODE)
+                out["phase_locked"]["note"] = "all envs reset together (what plain auto-reset stepping gives: episodes never end early); whole episodes timed"
+            if args.solver == "newton":
+                out["pgs_variant"] = measure_variant(torch, args, n, local_rank, rank, "pgs", not args.no_stagger, 32, 8)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(cm, n)
             out["cpu_baseline"]["solver"] = args.solver
         print(json.dumps(out), flush=True)
-    env.k_close()
+    try:
+        w.close()
+    except Exception:  # noqa: BLE001
+        pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args, argv)          # nothing above this line touches the GPU
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

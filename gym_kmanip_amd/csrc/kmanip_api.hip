@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.1 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.2 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -31,6 +31,28 @@ struct KHandle_ {
   bool ik_unfused = false;      // KMANIP_IK_UNFUSED=1: before_step as its own launch (A/B timing only)
   bool ik_serial = false;       // KMANIP_IK_SERIAL=1: one-lane-per-problem IK kernel (A/B and cross-check only)
   std::vector<void*> allocs;
+};
+
+// Every entry point works on the handle's device and leaves the caller's current device as it found it (a
+// multi-device process -- e.g. torch with several GPUs -- must not have its current device changed under it).
+struct DevGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+  }
+  ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define KM_ENTER(h)                                                                         \
+  DevGuard dev_guard_((h)->device);                                                         \
+  if (!dev_guard_.ok) { (h)->err = "hipSetDevice failed"; return -1; }
+
+// device scratch freed on every exit path
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <class T> T* as() const { return (T*)p; }
 };
 
 #define HIPCHK(h, call)                                                                     \
@@ -137,7 +159,8 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
     delete h; return -3;
   }
 #define CR(call) do { hipError_t e2 = (call); if (e2 != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e2); kmanip_destroy(h); return -4; } } while (0)
-  CR(hipSetDevice(device));
+  DevGuard dev_guard_(device);
+  if (!dev_guard_.ok) { g_create_error = "kmanip_create: hipSetDevice failed"; delete h; return -4; }
   const int nl = desc->nlink, nv = nl + 6, nq = nl + 7;
   const size_t N = (size_t)num_envs;
   auto dalloc = [&](void** p, size_t bytes) -> hipError_t {
@@ -162,8 +185,15 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.num_envs = num_envs;
   h->st.env_id_offset = env_id_offset;
   h->st.seed = seed;
+  h->st.sim_time = nullptr;
+  h->st.control_dt = desc->n_sub_steps * desc->timestep;
   { const char* e = getenv("KMANIP_IK_SERIAL"); h->ik_serial = e && e[0] == '1'; }
   { const char* e = getenv("KMANIP_IK_UNFUSED"); h->ik_unfused = e && e[0] == '1'; }
+#ifndef KM_DIAG_SERIAL_IK
+  if (h->ik_serial) { g_create_error = "KMANIP_IK_SERIAL needs the diagnostic build (make diag): the one-lane IK kernel is not in the product library"; kmanip_destroy(h); return -5; }
+#endif
+  // the initialisation above ran on the null stream; the caller's (non-blocking) streams must not start before it
+  CR(hipDeviceSynchronize());
 #undef CR
   *out = h;
   return 0;
@@ -171,7 +201,7 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
 
 void kmanip_destroy(KHandle h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DevGuard dev_guard_(h->device);
   for (void* p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
@@ -182,15 +212,16 @@ int kmanip_num_envs(KHandle h) { return h ? h->num_envs : 0; }
 
 int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stream) {
   if (!h) return -1;
-  HIPCHK(h, hipSetDevice(h->device));
+  KM_ENTER(h);
   kmanip_launch_reset(h->dmodel, h->desc, h->st, mask_dev, 0, obs_dev, (hipStream_t)stream);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
 
 static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, void* stream) {
-  if (!h || !act_dev || !obs_dev || !reward_dev || !done_dev) { if (h) h->err = "kmanip_step: null buffer"; return -1; }
-  HIPCHK(h, hipSetDevice(h->device));
+  if (!h) { g_create_error = "kmanip_step: null handle"; return -1; }
+  if (!act_dev || !obs_dev || !reward_dev || !done_dev) { h->err = "kmanip_step: null buffer"; return -1; }
+  KM_ENTER(h);
   hipStream_t s = (hipStream_t)stream;
   const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
   hipEvent_t* ev = tm ? &h->ev[3 * (size_t)h->timed_steps] : nullptr;
@@ -199,8 +230,11 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1 / KMANIP_IK_SERIAL=1)
   const bool split = h->ik_serial || h->ik_unfused;
   if (split && nchunk != 1) { h->err = "kmanip_step_chunk needs the fused path (unset KMANIP_IK_UNFUSED / KMANIP_IK_SERIAL)"; return -1; }
+#ifdef KM_DIAG_SERIAL_IK
   if (h->ik_serial) kmanip_launch_ik(h->dmodel, h->desc, h->st, act_dev, s);
-  else if (h->ik_unfused) kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
+  else
+#endif
+  if (h->ik_unfused) kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
   kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);
   if (tm) { HIPCHK(h, hipEventRecord(ev[2], s)); h->timed_steps++; }
@@ -218,9 +252,9 @@ int kmanip_step_chunk(KHandle h, int nsteps, const float* act_dev, double* obs_d
 }
 
 int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream) {
-  if (!h || !depth_dev || cam < 0 || cam >= KM_MAX_ARMS || height <= 0 || width <= 0) { if (h) h->err = "kmanip_render_depth: bad arguments"; return -1; }
-  if (!h->desc.cam_present[cam]) { h->err = "kmanip_render_depth: this model has no such gripper camera"; return -1; }
-  HIPCHK(h, hipSetDevice(h->device));
+  if (!h || !depth_dev || cam < 0 || cam >= KM_MAX_CAMS || height <= 0 || width <= 0) { if (h) h->err = "kmanip_render_depth: bad arguments"; return -1; }
+  if (!h->desc.cam_present[cam]) { h->err = "kmanip_render_depth: this model has no such camera"; return -1; }
+  KM_ENTER(h);
   kmanip_launch_render_depth(h->dmodel, h->st, cam, height, width, depth_dev, (hipStream_t)stream);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -231,7 +265,7 @@ int kmanip_scripted_action(KHandle h, float* act_dev, void* stream) {
   if (!h->desc.arm_present[0] || h->desc.act_col[KM_ACT_EER_POS] < 0) {
     h->err = "kmanip_scripted_action: this env id has no eer_pos action (the scripted policy drives the right EE delta)"; return -1;
   }
-  HIPCHK(h, hipSetDevice(h->device));
+  KM_ENTER(h);
   kmanip_launch_scripted_action(h->dmodel, h->st, act_dev, (hipStream_t)stream);
   HIPCHK(h, hipGetLastError());
   return 0;
@@ -239,7 +273,7 @@ int kmanip_scripted_action(KHandle h, float* act_dev, void* stream) {
 
 int kmanip_enable_timing(KHandle h, int enable) {
   if (!h) return -1;
-  HIPCHK(h, hipSetDevice(h->device));
+  KM_ENTER(h);
   if (enable && h->ev.empty()) {
     h->ev.resize(3 * KM_TIMING_SLOTS, nullptr);
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
@@ -250,7 +284,7 @@ int kmanip_enable_timing(KHandle h, int enable) {
 }
 int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, int32_t* nsteps) {
   if (!h) return -1;
-  HIPCHK(h, hipSetDevice(h->device));
+  KM_ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
   double a = 0, b = 0;
   for (int k = 0; k < h->timed_steps; k++) {
@@ -286,7 +320,7 @@ static int push(KHandle h, double* dev, const double* host, int ncomp) {
 
 int kmanip_get_state(KHandle h, double* qpos, double* qvel, double* ctrl, double* qacc_warm, int32_t* step_idx) {
   if (!h) return -1;
-  HIPCHK(h, hipSetDevice(h->device));
+  KM_ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
   const int nl = h->desc.nlink;
   int rc = 0;
@@ -300,7 +334,7 @@ int kmanip_get_state(KHandle h, double* qpos, double* qvel, double* ctrl, double
 int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const double* ctrl, const double* qacc_warm,
                      const int32_t* step_idx) {
   if (!h) return -1;
-  HIPCHK(h, hipSetDevice(h->device));
+  KM_ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
   const int nl = h->desc.nlink;
   int rc = 0;
@@ -309,12 +343,56 @@ int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const do
   if ((rc = push(h, h->st.ctrl, ctrl, nl))) return rc;
   if ((rc = push(h, h->st.warm, qacc_warm, nl + 6))) return rc;
   if (step_idx) HIPCHK(h, hipMemcpy(h->st.step_idx, step_idx, sizeof(int32_t) * h->num_envs, hipMemcpyHostToDevice));
+  HIPCHK(h, hipDeviceSynchronize());      // pageable-memory copies may return early; order them before the caller's streams
+  return 0;
+}
+
+int kmanip_get_episode(KHandle h, int32_t* episode) {
+  if (!h || !episode) { if (h) h->err = "kmanip_get_episode: null pointer"; return -1; }
+  KM_ENTER(h);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(episode, h->st.episode, sizeof(int32_t) * h->num_envs, hipMemcpyDeviceToHost));
+  return 0;
+}
+int kmanip_set_episode(KHandle h, const int32_t* episode) {
+  if (!h || !episode) { if (h) h->err = "kmanip_set_episode: null pointer"; return -1; }
+  KM_ENTER(h);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(h->st.episode, episode, sizeof(int32_t) * h->num_envs, hipMemcpyHostToDevice));
+  HIPCHK(h, hipDeviceSynchronize());
+  return 0;
+}
+
+int kmanip_bind_sim_time(KHandle h, double* sim_time_dev) {
+  if (!h) return -1;
+  h->st.sim_time = sim_time_dev;
+  return 0;
+}
+
+int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes) {
+  if (!h) return -1;
+  KM_ENTER(h);
+  h->st.seed = seed;
+  if (restart_episodes) {
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemset(h->st.episode, 0xFF, sizeof(int32_t) * (size_t)h->num_envs));   // -1: the next reset is episode 0
+    HIPCHK(h, hipDeviceSynchronize());
+  }
+  return 0;
+}
+
+int kmanip_get_counters(KHandle h, int32_t* step_idx_dev, int32_t* episode_dev, void* stream) {
+  if (!h) return -1;
+  KM_ENTER(h);
+  const size_t bytes = sizeof(int32_t) * (size_t)h->num_envs;
+  if (step_idx_dev) HIPCHK(h, hipMemcpyAsync(step_idx_dev, h->st.step_idx, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (episode_dev) HIPCHK(h, hipMemcpyAsync(episode_dev, h->st.episode, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 
 int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status) {
   if (!h) return -1;
-  HIPCHK(h, hipSetDevice(h->device));
+  KM_ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
   const size_t N = (size_t)h->num_envs;
   if (contact_mask) HIPCHK(h, hipMemcpy(contact_mask, h->st.contact_mask, sizeof(uint32_t) * N, hipMemcpyDeviceToHost));
@@ -332,29 +410,60 @@ int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t
 
 int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos, const double* goal_quat, double* q_out,
               int32_t* nfev, int32_t* status) {
-  if (!h || arm < 0 || arm >= KM_MAX_ARMS || !h->desc.arm_present[arm] || n <= 0) { if (h) h->err = "kmanip_ik: bad arguments"; return -1; }
-  HIPCHK(h, hipSetDevice(h->device));
+  if (!h) { g_create_error = "kmanip_ik: null handle"; return -1; }
+  if (arm < 0 || arm >= KM_MAX_ARMS || !h->desc.arm_present[arm] || n <= 0 || !qpos || !goal_pos || !goal_quat || !q_out) {
+    h->err = "kmanip_ik: bad arguments"; return -1;
+  }
+  KM_ENTER(h);
   const int nq = h->desc.nlink + 7, nik = h->desc.arm_nq[arm];
-  double *dq = nullptr, *dgp = nullptr, *dgq = nullptr, *dqo = nullptr;
-  int32_t *dnf = nullptr, *dst = nullptr;
-  HIPCHK(h, hipMalloc((void**)&dq, sizeof(double) * n * nq));
-  HIPCHK(h, hipMalloc((void**)&dgp, sizeof(double) * n * 3));
-  HIPCHK(h, hipMalloc((void**)&dgq, sizeof(double) * n * 4));
-  HIPCHK(h, hipMalloc((void**)&dqo, sizeof(double) * n * nik));
-  HIPCHK(h, hipMalloc((void**)&dnf, sizeof(int32_t) * n));
-  HIPCHK(h, hipMalloc((void**)&dst, sizeof(int32_t) * n));
-  HIPCHK(h, hipMemcpy(dq, qpos, sizeof(double) * n * nq, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(dgp, goal_pos, sizeof(double) * n * 3, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(dgq, goal_quat, sizeof(double) * n * 4, hipMemcpyHostToDevice));
-  if (h->ik_serial) kmanip_launch_ik_standalone(h->dmodel, h->desc, arm, n, dq, dgp, dgq, dqo, dnf, dst, nullptr);
-  else kmanip_launch_ik_coop_standalone(h->dmodel, h->desc, arm, n, dq, dgp, dgq, dqo, dnf, dst, nullptr);
+  DevBuf dq, dgp, dgq, dqo, dnf, dst;        // freed on every exit path
+  HIPCHK(h, hipMalloc(&dq.p, sizeof(double) * n * nq));
+  HIPCHK(h, hipMalloc(&dgp.p, sizeof(double) * n * 3));
+  HIPCHK(h, hipMalloc(&dgq.p, sizeof(double) * n * 4));
+  HIPCHK(h, hipMalloc(&dqo.p, sizeof(double) * n * nik));
+  HIPCHK(h, hipMalloc(&dnf.p, sizeof(int32_t) * n));
+  HIPCHK(h, hipMalloc(&dst.p, sizeof(int32_t) * n));
+  HIPCHK(h, hipMemcpy(dq.p, qpos, sizeof(double) * n * nq, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dgp.p, goal_pos, sizeof(double) * n * 3, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dgq.p, goal_quat, sizeof(double) * n * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipDeviceSynchronize());
+#ifdef KM_DIAG_SERIAL_IK
+  if (h->ik_serial) kmanip_launch_ik_standalone(h->dmodel, h->desc, arm, n, dq.as<double>(), dgp.as<double>(), dgq.as<double>(), dqo.as<double>(), dnf.as<int32_t>(), dst.as<int32_t>(), nullptr);
+  else
+#endif
+  kmanip_launch_ik_coop_standalone(h->dmodel, h->desc, arm, n, dq.as<double>(), dgp.as<double>(), dgq.as<double>(), dqo.as<double>(), dnf.as<int32_t>(), dst.as<int32_t>(), nullptr);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemcpy(qpos, dq, sizeof(double) * n * nq, hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemcpy(q_out, dqo, sizeof(double) * n * nik, hipMemcpyDeviceToHost));
-  if (nfev) HIPCHK(h, hipMemcpy(nfev, dnf, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-  if (status) HIPCHK(h, hipMemcpy(status, dst, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-  (void)hipFree(dq); (void)hipFree(dgp); (void)hipFree(dgq); (void)hipFree(dqo); (void)hipFree(dnf); (void)hipFree(dst);
+  HIPCHK(h, hipMemcpy(qpos, dq.p, sizeof(double) * n * nq, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(q_out, dqo.p, sizeof(double) * n * nik, hipMemcpyDeviceToHost));
+  if (nfev) HIPCHK(h, hipMemcpy(nfev, dnf.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(h, hipMemcpy(status, dst.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int kmanip_ik_eval(KHandle h, int arm, int n, const double* qpos, const double* goal_pos, const double* goal_quat,
+                   double* res, double* jac) {
+  if (!h) { g_create_error = "kmanip_ik_eval: null handle"; return -1; }
+  if (arm < 0 || arm >= KM_MAX_ARMS || !h->desc.arm_present[arm] || n <= 0 || !qpos || !goal_pos || !goal_quat || !res || !jac) {
+    h->err = "kmanip_ik_eval: bad arguments"; return -1;
+  }
+  KM_ENTER(h);
+  const int nq = h->desc.nlink + 7, nik = h->desc.arm_nq[arm], mrow = 6 + 2 * nik;
+  DevBuf dq, dgp, dgq, dres, djac;
+  HIPCHK(h, hipMalloc(&dq.p, sizeof(double) * n * nq));
+  HIPCHK(h, hipMalloc(&dgp.p, sizeof(double) * n * 3));
+  HIPCHK(h, hipMalloc(&dgq.p, sizeof(double) * n * 4));
+  HIPCHK(h, hipMalloc(&dres.p, sizeof(double) * n * mrow));
+  HIPCHK(h, hipMalloc(&djac.p, sizeof(double) * n * mrow * nik));
+  HIPCHK(h, hipMemcpy(dq.p, qpos, sizeof(double) * n * nq, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dgp.p, goal_pos, sizeof(double) * n * 3, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(dgq.p, goal_quat, sizeof(double) * n * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipDeviceSynchronize());
+  kmanip_launch_ik_eval_coop(h->dmodel, h->desc, arm, n, dq.as<double>(), dgp.as<double>(), dgq.as<double>(), dres.as<double>(), djac.as<double>(), nullptr);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(res, dres.p, sizeof(double) * n * mrow, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(jac, djac.p, sizeof(double) * n * mrow * nik, hipMemcpyDeviceToHost));
   return 0;
 }
 

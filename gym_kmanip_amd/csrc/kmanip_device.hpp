@@ -219,6 +219,8 @@ struct KDeviceState {
   uint32_t* contact_mask;  // [N]
   int32_t* ik_nfev;   // [2][N]
   int32_t* ik_status; // [2][N]
+  double* sim_time;   // [N] caller-owned (kmanip_bind_sim_time), may be NULL: data.time of every env = step_idx * control_dt
+  double control_dt;  // n_sub_steps * timestep
   int num_envs;
   int64_t env_id_offset;
   uint64_t seed;
@@ -231,6 +233,8 @@ void kmanip_launch_ik_coop(const KDeviceModel* dm, const KModelDesc& hd, const K
 void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
                                       const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
                                       int32_t* status, hipStream_t stream);
+void kmanip_launch_ik_eval_coop(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, const double* qpos_env_major,
+                                const double* goal_pos, const double* goal_quat, double* res, double* jac, hipStream_t stream);
 void kmanip_launch_ik_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
                                  const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
                                  int32_t* status, hipStream_t stream);

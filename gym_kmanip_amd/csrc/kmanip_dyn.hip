@@ -58,6 +58,10 @@ struct LModel {
   // soft-constraint constants of the two parameter sets (0 = default pairs / joint rows, 1 = pairs with the cube):
   // stiffness k, damping b (mj_makeImpedance / solref), impedance at zero distance
   real kb[2][2], imp0[2];
+  // MuJoCo's qpos0-time constants (mj_setConst): efc_diagApprox of this link's single-dof rows (dof_invweight0), of the
+  // FIRST pyramid edge of every contact slot (tran + mu^2 tran, tran = summed body_invweight0 of the pair), of the cube's
+  // friction-loss rows (linear, angular), and the solvers' termination scale 1 / (meaninertia * nv)
+  real dofw[NL], slotA[Dim<NL>::NC], cubew[2], scale;
 };
 
 // Solver view of one pyramidal contact (group-uniform scalars).  Basis index 0 = normal, 1..2 = tangents,
@@ -98,7 +102,6 @@ struct Ws {
 #if KM_VAR_SOLVER == KM_SOLVER_PGS
   real as[NV], tmp2[NV], tmp3[NV];
 #endif
-  real Mtrace;
   int ns, bad, touch_fc, touch_ct;
   uint32_t contact_mask;   // KM_CON_* bits (which candidate pairs touch)
   uint32_t cact;           // active contact slots
@@ -469,9 +472,6 @@ __device__ __forceinline__ void bias_project(Ws<NL>& w, const LModel<NL>& lm, in
 // synchronisation inside the n^2 loop.
 template <int NL, int G>
 __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
-  real tr = 0;
-  for (int i = 0; i < NL; i++) tr += w.Minv[i][i];
-  if (sub == 0) w.Mtrace = tr;
   real a[NL];
 #pragma unroll
   for (int j = 0; j < NL; j++) a[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
@@ -687,7 +687,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
     real pos = w.s_pos[r];
     real imp = impedance(m->con_def_solimp, pos), kk, bb;
     get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
-    const real R = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+    const real R = fmax(MJ_MINVAL, (1 - imp) / imp * lm.dofw[j]);      // efc_diagApprox = dof_invweight0, not the exact A_ii
     w.s_R[r] = R;
     w.s_den[r] = Ad + R;
     w.s_inv[r] = 1.0 / (Ad + R);
@@ -777,7 +777,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
 #pragma unroll
         for (int l = 0; l < 4; l++) Ge[l] = Gm[l][0] + sm * Gm[l][k];        // J_l . M^-1 (J_0 + sm J_k)^T
         const real Ad = Ge[0] + sm * Ge[k];
-        if (e == 0) R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
+        if (e == 0) R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * lm.slotA[c]);
         const real vel = vb[0] + sm * vb[k];
         if (sub == 0) {
           rc.den[e] = Ad + R;
@@ -839,7 +839,7 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
   if (my_row) {
     real imp = impedance(m->con_def_solimp, 0.0), kk, bb;
     get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
-    my_R = fmax(MJ_MINVAL, (1 - imp) / imp * invm);
+    my_R = fmax(MJ_MINVAL, (1 - imp) / imp * lm.cubew[sub < NL + 3 ? 0 : 1]);
     my_den = invm + my_R;
     my_inv = 1.0 / my_den;
     my_aref = -bb * w.qvel[sub];
@@ -905,7 +905,7 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
   // M^-1, so the owning lanes update them locally and simultaneously -- identical to one after another,
   // and no cross-lane traffic.  A row on an arm dof needs one broadcast; a contact needs four DPP row
   // reductions (its basis projections u = J a), then its pyramid edges run on precomputed Gram rows.
-  const real scale = 1.0 / (w.Mtrace + 3 * m->cube_mass + m->cube_inertia[0] + m->cube_inertia[1] + m->cube_inertia[2]);
+  const real scale = lm.scale;
   const int maxit = m->solver_iterations;
   const real tol = m->solver_tolerance;
   for (int iter = 0; iter < maxit; iter++) {
@@ -1061,7 +1061,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   cr.fl = 0; cr.Rf = 1; cr.Df = 1; cr.areff = 0; cr.sg = 0; cr.Rl = 1; cr.Dl = 1; cr.arefl = 0;
   if (sub < NV) {
-    const real Ad = sub < NL ? w.Minv[sub][sub] : invm;
+    const real Ad = sub < NL ? lm.dofw[sub] : lm.cubew[sub < NL + 3 ? 0 : 1];     // efc_diagApprox (qpos0 constants)
     const real qv = w.qvel[sub];
     const real kk = lm.kb[0][0], bb = lm.kb[0][1];
     const real fl = sub < NL ? lm.floss[sub] : m->cube_frictionloss;
@@ -1114,16 +1114,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       const real* sr = cube ? m->con_cube_solref : m->con_def_solref;
       const real* si = cube ? m->con_cube_solimp : m->con_def_solimp;
       real mu[3] = {fr[0], fr[0], fr[1]};
-      // first pyramid edge v = J_0 + mu J_1 and M^-1 v (arm lanes need the whole row: stage through LDS)
-      const real v = cr.jb[c][0] + mu[0] * cr.jb[c][1];
-      real Mv = sub >= NL ? v * invm : 0.0;
-      if (kind != 0) {                       // (w.stage aliases the records being written here: use w.tmp)
-        if (sub < NV) w.tmp[sub] = v;
-        GSYNC();
-        if (sub < NL) { real s = 0; for (int j = 0; j < NL; j++) s += w.Minv[sub][j] * w.tmp[j]; Mv = s; }
-        GSYNC();
-      }
-      const real Ad = gsum<G>(v * Mv);
+      const real Ad = lm.slotA[c];         // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
       real vb[4];
       if (kind == 0) plane_proj<NL>(w, c, qlin, qangw, vb);
       else {
@@ -1344,7 +1335,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
   real cost = newton_eval<NL, G, true>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm);
   if (!(cost < cs)) { a = a_s; Mr = 0; cost = newton_eval<NL, G, true>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm); }
-  const real scale = 1.0 / (w.Mtrace + 3 * m->cube_mass + m->cube_inertia[0] + m->cube_inertia[1] + m->cube_inertia[2]);
+  const real scale = lm.scale;
   const real tol = m->solver_tolerance;
   const int maxit = m->solver_iterations;
   pf.ph(6);
@@ -1598,7 +1589,17 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
       get_kb(m, m->con_cube_solref, m->con_cube_solimp, lm.kb[1][0], lm.kb[1][1]);
       lm.imp0[0] = impedance(m->con_def_solimp, 0.0);
       lm.imp0[1] = impedance(m->con_cube_solimp, 0.0);
+      lm.cubew[0] = m->cube_invweight0[0]; lm.cubew[1] = m->cube_invweight0[1];
+      lm.scale = 1.0 / (m->meaninertia * (NL + 6));
+      for (int c = 0; c < Dim<NL>::NC; c++) {
+        const int kind = slot_kind<NL>(c), sp = slot_sphere<NL>(c);
+        const real lw = (kind != 0 && sp < m->nsphere) ? m->body_invweight0[m->sphere_link[sp]][0] : 0.0;
+        const real tran = (kind != 2 ? m->cube_invweight0[0] : 0.0) + lw;
+        const real mu = kind != 2 ? m->con_cube_friction[0] : m->con_def_friction[0];
+        lm.slotA[c] = tran + mu * mu * tran;
+      }
     }
+    lm.dofw[i] = m->dof_invweight0[i];
     lm.floss[i] = m->frictionloss[i]; lm.kp[i] = m->kp[i]; lm.mass[i] = m->mass[i]; lm.q_home[i] = m->q_home[i];
     for (int c = 0; c < 3; c++) { lm.pos[i][c] = m->link_pos[i][c]; lm.jaxis[i][c] = m->jnt_axis[i][c]; lm.com[i][c] = m->com[i][c]; lm.inertia[i][c] = m->inertia[i][c]; }
     for (int c = 0; c < 4; c++) lm.quat[i][c] = m->link_quat[i][c];
@@ -1722,7 +1723,10 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub == 0) { reward[(size_t)kc * NE + env] = rew; done[(size_t)kc * NE + env] = dn; }
   GSYNC();
   }   // chunk
-  if (sub == 0) { st.step_idx[env] = step_idx; st.episode[env] = episode; }
+  if (sub == 0) {
+    st.step_idx[env] = step_idx; st.episode[env] = episode;
+    if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
+  }
   store_state<NL, G>(w, st, env, sub);
   pf.ph(14);
   pf.flush();
@@ -1750,7 +1754,7 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   pf.start();
   reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
   if (obs) write_obs<NL, G>(w, lm, m, sub, obs + (size_t)env * m->obs_dim);
-  if (sub == 0) { st.step_idx[env] = 0; st.episode[env] = episode; st.contact_mask[env] = 0; }
+  if (sub == 0) { st.step_idx[env] = 0; st.episode[env] = episode; st.contact_mask[env] = 0; if (st.sim_time) st.sim_time[env] = 0; }
   GSYNC();
   store_state<NL, G>(w, st, env, sub);
 }

@@ -96,3 +96,47 @@ void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& 
   else
     hipLaunchKernelGGL(k_ik_coop_standalone<6>, grid, dim3(64), 0, stream, dm, arm, n, nq, qpos, goal_pos, goal_quat, q_out, nfev, status);
 }
+
+// ik_res / ik_jac (ik_mujoco.py:20-97) of the cooperative IK's own evaluation code at x = qpos[q_mask], q_pos_prev = x:
+// res [n][6+2N], jac [n][(6+2N) x N] row-major -- for parity tests against the NumPy/SciPy fixtures (res0 / jac0).
+template <int N>
+__global__ __launch_bounds__(64) void k_ik_eval_coop(const KDeviceModel* __restrict__ dm, int arm, int n, int nq, const double* qpos,
+                                                     const double* goal_pos, const double* goal_quat, double* res, double* jac) {
+  __shared__ CoopLds<N> lds[PPW];
+  const KModelDesc* m = &dm->d;
+  const int slot = threadIdx.x / GI, c = threadIdx.x % GI;
+  const int e = blockIdx.x * PPW + slot;
+  if (e >= n) return;
+  const double* qp = qpos + (size_t)e * nq;
+  CoopCtx<N> P;
+  P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N;
+  coop_chain_setup<N>(P);
+  const int q = m->arm_q_id[arm][P.on ? c : 0];
+  const real x0 = P.on ? qp[q] : 0.0;
+  P.q_prev = x0; P.q_home = m->q_home[q]; P.lb = m->jnt_range[q][0]; P.ub = m->jnt_range[q][1];
+  P.qfix = (P.clen > N) ? qp[dm->x.chain_link[arm][P.clen - 1]] : 0.0;
+  for (int k = 0; k < 3; k++) P.goal_pos[k] = goal_pos[3 * e + k];
+  for (int k = 0; k < 4; k++) P.goal_quat[k] = goal_quat[4 * e + k];
+  real ft[6], Jc[6];
+  coop_eval<N, true>(P, x0, ft, Jc, nullptr, nullptr);
+  constexpr int M = 6 + 2 * N;
+  double* r = res + (size_t)e * M;
+  double* J = jac + (size_t)e * M * N;
+  if (c == 0) for (int k = 0; k < 6; k++) r[k] = ft[k];
+  if (P.on) {
+    r[6 + c] = m->ik_res_reg_prev * (x0 - P.q_prev);
+    r[6 + N + c] = m->ik_res_reg_home * (x0 - P.q_home);
+    for (int k = 0; k < M; k++) J[k * N + c] = 0;
+    for (int k = 0; k < 6; k++) J[k * N + c] = Jc[k];
+    J[(6 + c) * N + c] = m->ik_jac_reg;          // both regulariser blocks use IK_JAC_REG (ik_mujoco.py:92,97)
+    J[(6 + N + c) * N + c] = m->ik_jac_reg;
+  }
+}
+
+void kmanip_launch_ik_eval_coop(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, const double* qpos,
+                                const double* goal_pos, const double* goal_quat, double* res, double* jac, hipStream_t stream) {
+  int nq = hd.nlink + 7;
+  dim3 grid((n + PPW - 1) / PPW);
+  if (hd.arm_nq[arm] == 7) hipLaunchKernelGGL(k_ik_eval_coop<7>, grid, dim3(64), 0, stream, dm, arm, n, nq, qpos, goal_pos, goal_quat, res, jac);
+  else hipLaunchKernelGGL(k_ik_eval_coop<6>, grid, dim3(64), 0, stream, dm, arm, n, nq, qpos, goal_pos, goal_quat, res, jac);
+}

@@ -58,8 +58,11 @@ __device__ void render_setup(const KDeviceModel* dm, const KDeviceState& st, int
   real co[3], to[3], t[3];
   real cp[3] = {m->cam_pos[cam][0], m->cam_pos[cam][1], m->cam_pos[cam][2]};
   real tp[3] = {m->cam_target_pos[cam][0], m->cam_target_pos[cam][1], m->cam_target_pos[cam][2]};
-  mat_vec3(t, xmat[cl], cp); co[0] = xpos[cl][0] + t[0]; co[1] = xpos[cl][1] + t[1]; co[2] = xpos[cl][2] + t[2];
-  mat_vec3(t, xmat[tl], tp); to[0] = xpos[tl][0] + t[0]; to[1] = xpos[tl][1] + t[1]; to[2] = xpos[tl][2] + t[2];
+  // (a link of -1 = world frame: the fixed `top` / `head` cameras and their target, the table body)
+  if (cl < 0) { co[0] = cp[0]; co[1] = cp[1]; co[2] = cp[2]; }
+  else { mat_vec3(t, xmat[cl], cp); co[0] = xpos[cl][0] + t[0]; co[1] = xpos[cl][1] + t[1]; co[2] = xpos[cl][2] + t[2]; }
+  if (tl < 0) { to[0] = tp[0]; to[1] = tp[1]; to[2] = tp[2]; }
+  else { mat_vec3(t, xmat[tl], tp); to[0] = xpos[tl][0] + t[0]; to[1] = xpos[tl][1] + t[1]; to[2] = xpos[tl][2] + t[2]; }
   real z[3] = {co[0] - to[0], co[1] - to[1], co[2] - to[2]}, up[3] = {0, 0, 1}, x[3], y[3];
   normalize3(z);
   cross3(x, up, z); normalize3(x);

@@ -31,6 +31,13 @@ class RewardDoneGather:
         self.all = [torch.zeros((world * n_local, 2), dtype=torch.float64, device=device) for _ in range(2)]
         self.pending = [None, None]
         self.k = 0
+        # gloo has no device collectives: when a one-GPU box rehearses the multi-rank path over gloo, the records are
+        # staged through host memory (synchronously); RCCL (backend "nccl") gathers the device buffers directly
+        self.host_stage = bool(dist is not None and world > 1 and dist.get_backend() == "gloo"
+                               and torch.device(device).type == "cuda")
+        if self.host_stage:
+            self.h_rec = torch.zeros((n_local, 2), dtype=torch.float64)
+            self.h_all = torch.zeros((world * n_local, 2), dtype=torch.float64)
 
     def post(self, reward, done):
         """Pack this step's local results and start the collective; returns the buffer index."""
@@ -40,7 +47,11 @@ class RewardDoneGather:
             self.pending[b].wait()
         self.rec[b][:, 0].copy_(reward)
         self.rec[b][:, 1].copy_(done)
-        if self.dist is not None and self.world > 1:
+        if self.host_stage:
+            self.h_rec.copy_(self.rec[b])
+            self.dist.all_gather_into_tensor(self.h_all, self.h_rec)
+            self.all[b].copy_(self.h_all)
+        elif self.dist is not None and self.world > 1:
             self.pending[b] = self.dist.all_gather_into_tensor(self.all[b], self.rec[b], async_op=True)
         else:
             self.all[b].copy_(self.rec[b])

@@ -54,7 +54,12 @@ class KManipEnvHip:
         self.reward = torch.zeros((n,), dtype=torch.float64, device=self.device)
         self.done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
         self.act = torch.zeros((n, cm.act_dim), dtype=torch.float32, device=self.device)
-        self.sim_step = 0
+        # k_step return values that never change (terminated is always False in the reference: get_termination -> None,
+        # discount 1.0) and the device-side counters behind sim_time: allocated once, no per-step allocation or sync
+        self.terminated = torch.zeros((n,), dtype=torch.bool, device=self.device)
+        self.discount = torch.ones((n,), dtype=torch.float64, device=self.device)
+        self.sim_time = torch.zeros((n,), dtype=torch.float64, device=self.device)
+        self._check(self.L.kmanip_bind_sim_time(self.h, C.c_void_p(self.sim_time.data_ptr())), "kmanip_bind_sim_time")
 
     # ------------------------------------------------------------------ helpers
     def _check(self, rc, what):
@@ -73,10 +78,38 @@ class KManipEnvHip:
                 out[key] = obs[:, self.cm.obs_slices[key]]
         return out
 
+    def _check_buf(self, t, shape, dtype, what):
+        """Device / dtype / layout checks of a caller-supplied tensor whose raw pointer goes to the kernel (a float64
+        action, a CPU tensor, a strided view or a wrong leading dimension would otherwise be silent garbage or a fault)."""
+        torch = _torch()
+        if not isinstance(t, torch.Tensor):
+            raise _libmod.KManipError("%s must be a torch tensor on %s, got %s" % (what, self.device, type(t).__name__))
+        if (not t.is_cuda) or t.device != self.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise _libmod.KManipError("%s must be a contiguous %s tensor of shape %s on %s; got %s %s on %s%s" % (
+                what, dtype, tuple(shape), self.device, t.dtype, tuple(t.shape), t.device,
+                "" if t.is_contiguous() else " (non-contiguous)"))
+
     def pack_action(self, action) -> "object":
-        """dict of arrays keyed like the reference action space (env_base.py:151-188) -> flat [N, act_dim]."""
+        """dict of arrays keyed like the reference action space (env_base.py:151-188) -> flat [N, act_dim].  A dict of
+        DEVICE tensors is packed on the device (one strided copy per key into the handle's action buffer: no host
+        round trip, no allocation); NumPy / list values go through one host buffer and a single upload."""
         torch = _torch()
         if isinstance(action, dict):
+            if any(isinstance(v, torch.Tensor) and v.is_cuda for v in action.values()):
+                keys = list(self.cm.act_slices)
+                if all(k in action and isinstance(action[k], torch.Tensor) and action[k].is_cuda
+                       and action[k].dtype == torch.float32 for k in keys):
+                    # the usual case: every key present, on the device -> ONE concatenation kernel into the action buffer
+                    torch.cat([action[k].reshape(self.num_envs, -1) for k in keys], dim=1, out=self.act)
+                    return self.act
+                self.act.zero_()
+                for key, sl in self.cm.act_slices.items():
+                    if key in action:
+                        v = action[key]
+                        if not isinstance(v, torch.Tensor):
+                            v = torch.as_tensor(np.asarray(v, dtype=np.float32))
+                        self.act[:, sl].copy_(v.reshape(self.num_envs, -1), non_blocking=True)
+                return self.act
             flat = np.zeros((self.num_envs, self.cm.act_dim), dtype=np.float32)
             for key, sl in self.cm.act_slices.items():
                 if key in action:
@@ -96,11 +129,11 @@ class KManipEnvHip:
             mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
             mp = C.c_void_p(mask.data_ptr())
         self._check(self.L.kmanip_reset(self.h, mp, C.c_void_p(self.obs.data_ptr()), self._stream()), "kmanip_reset")
-        terminated = torch.zeros((self.num_envs,), dtype=torch.bool, device=self.device)
-        return terminated, None, None, self.obs_dict(), 0.0
+        return self.terminated, None, None, self.obs_dict(), 0.0
 
     def step_flat(self, act):
         """Raw batched step on device tensors: returns (obs, reward, done) views of the handle's buffers."""
+        self._check_buf(act, (self.num_envs, self.cm.act_dim), _torch().float32, "act")
         self._check(self.L.kmanip_step(self.h, C.c_void_p(act.data_ptr()), C.c_void_p(self.obs.data_ptr()),
                                        C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
                                        self._stream()), "kmanip_step")
@@ -113,6 +146,11 @@ class KManipEnvHip:
         torch = _torch()
         K = int(acts.shape[0])
         n = self.num_envs
+        self._check_buf(acts, (K, n, self.cm.act_dim), torch.float32, "acts")
+        for t, shp, dt, nm in ((obs, (K, n, self.cm.obs_dim), torch.float64, "obs"), (reward, (K, n), torch.float64, "reward"),
+                               (done, (K, n), torch.uint8, "done")):
+            if t is not None:
+                self._check_buf(t, shp, dt, nm)
         if obs is None:
             obs = torch.empty((K, n, self.cm.obs_dim), dtype=torch.float64, device=self.device)
         if reward is None:
@@ -131,10 +169,9 @@ class KManipEnvHip:
         torch = _torch()
         act = self.pack_action(action)
         self.step_flat(act)
-        terminated = torch.zeros((self.num_envs,), dtype=torch.bool, device=self.device)
-        discount = torch.ones((self.num_envs,), dtype=torch.float64, device=self.device)
-        sim_time = self.step_counters().astype(np.float64) * CONTROL_TIMESTEP
-        return terminated, self.reward, discount, self.obs_dict(), sim_time
+        # sim_time = data.time of each env (env_sim.py:194,200) = steps since its last reset x control_timestep: the step
+        # kernel itself fills the bound device buffer -- no extra launch, no host synchronisation
+        return self.terminated, self.reward, self.discount, self.obs_dict(), self.sim_time
 
     def render_depth(self, cam="grip_r", height: int = 64, width: int = 64, out=None):
         """float32 depth image [num_envs, height, width] (metres along the optical axis) of every env's current state
@@ -188,6 +225,30 @@ class KManipEnvHip:
                     "kmanip_get_state")
         return step
 
+    def set_seed(self, seed: int, restart_episodes: bool = True):
+        """Re-key the cube-spawn stream (KManipEnv.reset(seed=...)); with restart_episodes the next k_reset is episode 0."""
+        self._check(self.L.kmanip_set_seed(self.h, C.c_uint64(int(seed)), int(restart_episodes)), "kmanip_set_seed")
+
+    def get_episode(self):
+        """Per-env episode counter (keys the cube-spawn stream together with seed and global env id)."""
+        ep = np.zeros(self.num_envs, dtype=np.int32)
+        self._check(self.L.kmanip_get_episode(self.h, ep.ctypes.data_as(C.POINTER(C.c_int32))), "kmanip_get_episode")
+        return ep
+
+    def set_episode(self, episode):
+        ep = np.ascontiguousarray(episode, dtype=np.int32)
+        assert ep.shape == (self.num_envs,)
+        self._check(self.L.kmanip_set_episode(self.h, ep.ctypes.data_as(C.POINTER(C.c_int32))), "kmanip_set_episode")
+
+    def checkpoint(self):
+        """Complete restartable state: (qpos, qvel, ctrl, qacc_warmstart, step_idx, episode) as host arrays."""
+        return self.get_state() + (self.get_episode(),)
+
+    def restore(self, ckpt):
+        qpos, qvel, ctrl, warm, step, episode = ckpt
+        self.set_state(qpos, qvel, ctrl, warm, step)
+        self.set_episode(episode)
+
     def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None, step=None):
         def p(a, dt, t):
             if a is None:
@@ -220,6 +281,17 @@ class KManipEnvHip:
         p = lambda a, t=C.c_double: a.ctypes.data_as(C.POINTER(t))
         self._check(self.L.kmanip_ik(self.h, arm, n, p(qpos), p(gp), p(gq), p(q), p(nfev, C.c_int32), p(st, C.c_int32)), "kmanip_ik")
         return q, qpos, nfev, st
+
+    def ik_eval(self, arm, qpos, goal_pos, goal_quat):
+        """(ik_res, ik_jac) of the device IK at x = qpos[q_mask], q_pos_prev = x: res [n, 6+2N], jac [n, 6+2N, N]."""
+        qpos = np.ascontiguousarray(qpos, dtype=np.float64)
+        n = qpos.shape[0]
+        gp = np.ascontiguousarray(goal_pos, dtype=np.float64); gq = np.ascontiguousarray(goal_quat, dtype=np.float64)
+        nik = self.cm.desc.arm_nq[arm]
+        res = np.zeros((n, 6 + 2 * nik)); jac = np.zeros((n, 6 + 2 * nik, nik))
+        p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        self._check(self.L.kmanip_ik_eval(self.h, arm, n, p(qpos), p(gp), p(gq), p(res), p(jac)), "kmanip_ik_eval")
+        return res, jac
 
     def enable_timing(self, on=True):
         self._check(self.L.kmanip_enable_timing(self.h, int(on)), "kmanip_enable_timing")

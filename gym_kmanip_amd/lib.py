@@ -19,7 +19,7 @@ _lib = None
 # every symbol include/kmanip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "kmanip_model_desc_size", "kmanip_create", "kmanip_reset", "kmanip_step", "kmanip_step_chunk", "kmanip_get_state",
-    "kmanip_set_state", "kmanip_get_diag", "kmanip_timing_summary", "kmanip_enable_timing", "kmanip_ik",
+    "kmanip_set_state", "kmanip_get_episode", "kmanip_set_episode", "kmanip_get_counters", "kmanip_bind_sim_time", "kmanip_set_seed", "kmanip_get_diag", "kmanip_timing_summary", "kmanip_enable_timing", "kmanip_ik", "kmanip_ik_eval",
     "kmanip_render_depth", "kmanip_scripted_action", "kmanip_num_envs", "kmanip_last_error", "kmanip_version", "kmanip_destroy",
 ]
 
@@ -53,10 +53,16 @@ def load():
     lib.kmanip_step_chunk.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.kmanip_get_state.argtypes = [vp, f64p, f64p, f64p, f64p, i32p]
     lib.kmanip_set_state.argtypes = [vp, f64p, f64p, f64p, f64p, i32p]
+    lib.kmanip_get_episode.argtypes = [vp, i32p]
+    lib.kmanip_set_episode.argtypes = [vp, i32p]
+    lib.kmanip_get_counters.argtypes = [vp, vp, vp, vp]
+    lib.kmanip_bind_sim_time.argtypes = [vp, vp]
+    lib.kmanip_set_seed.argtypes = [vp, C.c_uint64, C.c_int]
     lib.kmanip_get_diag.argtypes = [vp, C.POINTER(C.c_uint32), i32p, i32p]
     lib.kmanip_timing_summary.argtypes = [vp, f64p, f64p, i32p]
     lib.kmanip_enable_timing.argtypes = [vp, C.c_int]
     lib.kmanip_ik.argtypes = [vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, i32p, i32p]
+    lib.kmanip_ik_eval.argtypes = [vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p]
     lib.kmanip_render_depth.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.kmanip_scripted_action.argtypes = [vp, vp, vp]
     lib.kmanip_num_envs.argtypes = [vp]

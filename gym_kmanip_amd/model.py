@@ -23,6 +23,8 @@ KM_MAX_LINKS = 20
 KM_MAX_ARMS = 2
 KM_MAX_IK = 7
 KM_MAX_SPHERES = 4
+KM_MAX_CAMS = 4
+KM_CAM_INDEX = {"grip_r": 0, "grip_l": 1, "top": 2, "head": 3}
 KM_ACT_KEYS = ["eel_pos", "eel_orn", "eer_pos", "eer_orn", "grip_l", "grip_r", "q_pos_r", "q_pos_l"]
 KM_DONE_TRUNCATED = 1
 KM_DONE_DIVERGED = 2
@@ -145,10 +147,12 @@ class KModelDesc(C.Structure):
         ("max_q_vel", C.c_double), ("epsilon", C.c_double),
         ("reward_vel_penalty", C.c_double), ("reward_grip_dist", C.c_double),
         ("reward_touch_cube", C.c_double), ("reward_lift_cube", C.c_double),
-        ("cam_present", C.c_int32 * KM_MAX_ARMS), ("cam_link", C.c_int32 * KM_MAX_ARMS),
-        ("cam_target_link", C.c_int32 * KM_MAX_ARMS), ("pad3_", C.c_int32 * 2),
-        ("cam_pos", (C.c_double * 3) * KM_MAX_ARMS), ("cam_target_pos", (C.c_double * 3) * KM_MAX_ARMS),
-        ("cam_fovy", C.c_double * KM_MAX_ARMS), ("cam_znear", C.c_double), ("cam_zfar", C.c_double),
+        ("cam_present", C.c_int32 * KM_MAX_CAMS), ("cam_link", C.c_int32 * KM_MAX_CAMS),
+        ("cam_target_link", C.c_int32 * KM_MAX_CAMS),
+        ("cam_pos", (C.c_double * 3) * KM_MAX_CAMS), ("cam_target_pos", (C.c_double * 3) * KM_MAX_CAMS),
+        ("cam_fovy", C.c_double * KM_MAX_CAMS), ("cam_znear", C.c_double), ("cam_zfar", C.c_double),
+        ("dof_invweight0", C.c_double * KM_MAX_LINKS), ("body_invweight0", (C.c_double * 2) * KM_MAX_LINKS),
+        ("cube_invweight0", C.c_double * 2), ("meaninertia", C.c_double),
     ]
 
 
@@ -180,6 +184,67 @@ class CompiledModel:
 
 
 SOLVERS = {"pgs": 0, "newton": 1}
+
+
+def _quat2mat(q):
+    w, x, y, z = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
+def invweight0(d: "KModelDesc"):
+    """What MuJoCo's mj_setConst computes at qpos0 (every joint at 0; no `ref`/`springref` in any reference XML) and the
+    constraint code then uses for efc_diagApprox and the solver scale -- from the model's own (surrogate) inertias:
+      dof_invweight0[i]   = (M^-1)_ii
+      body_invweight0[b]  = (mean of the translational, mean of the rotational) diagonal of J_b M^-1 J_b^T, J_b = the
+                            6 x nv Jacobian of body b at its centre of mass
+      cube (free body)    = (1/m, mean_k 1/I_k); free-joint dof_invweight0 is averaged per 3-dof block the same way
+      meaninertia         = trace(M) / nv over all nv = nlink + 6 dofs
+    Returns (dofw[nl], bodyw[nl][2], cubew[2], meaninertia)."""
+    nl = d.nlink
+    xpos = np.zeros((nl, 3)); xmat = np.zeros((nl, 3, 3)); axis = np.zeros((nl, 3)); cpos = np.zeros((nl, 3))
+    for i in range(nl):
+        p = d.link_parent[i]
+        R0 = _quat2mat(list(d.link_quat[i]))
+        lp = np.array(list(d.link_pos[i]))
+        if p < 0:
+            xpos[i], xmat[i] = lp, R0
+        else:
+            xpos[i], xmat[i] = xpos[p] + xmat[p] @ lp, xmat[p] @ R0          # joint value 0: no joint motion
+        axis[i] = xmat[i] @ np.array(list(d.jnt_axis[i]))
+        cpos[i] = xpos[i] + xmat[i] @ np.array(list(d.com[i]))
+    anc = []
+    for i in range(nl):
+        a, j = [], i
+        while j >= 0:
+            a.append(j); j = d.link_parent[j]
+        anc.append(a)
+
+    def jac(b, pt):
+        J = np.zeros((6, nl))
+        for j in anc[b]:
+            if d.jnt_type[j] == 1:
+                J[:3, j] = axis[j]
+            else:
+                J[:3, j] = np.cross(axis[j], pt - xpos[j]); J[3:, j] = axis[j]
+        return J
+
+    M = np.zeros((nl, nl))
+    Js = []
+    for b in range(nl):
+        J = jac(b, cpos[b]); Js.append(J)
+        Iw = xmat[b] @ np.diag(list(d.inertia[b])) @ xmat[b].T
+        M += d.mass[b] * J[:3].T @ J[:3] + J[3:].T @ Iw @ J[3:]
+    Minv = np.linalg.inv(M)
+    dofw = np.diag(Minv).copy()
+    bodyw = np.zeros((nl, 2))
+    for b in range(nl):
+        A = Js[b] @ Minv @ Js[b].T
+        bodyw[b] = [np.trace(A[:3, :3]) / 3.0, np.trace(A[3:, 3:]) / 3.0]
+    cubew = (1.0 / d.cube_mass, float(np.mean([1.0 / d.cube_inertia[k] for k in range(3)])))
+    trace = np.trace(M) + 3 * d.cube_mass + sum(d.cube_inertia[k] for k in range(3))
+    return dofw, bodyw, cubew, float(trace / (nl + 6))
 
 
 def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool = False,
@@ -318,7 +383,7 @@ def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool
     d.reward_touch_cube, d.reward_lift_cube = REWARD_TOUCH_CUBE, REWARD_LIFT_CUBE
 
     # ---- gripper cameras (targetbody mode); znear from scene.xml:5 (<map znear="0.1"/> x extent ~1 m)
-    for ci, cname in enumerate(["grip_r", "grip_l"]):
+    for cname, ci in KM_CAM_INDEX.items():
         cams = [c for c in asset["cameras"] if c["name"] == cname]
         if not cams:
             continue
@@ -332,6 +397,14 @@ def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool
             d.cam_pos[ci][k] = cam["pos"][k]
             d.cam_target_pos[ci][k] = tgt["pos"][k]
     d.cam_znear, d.cam_zfar = 0.01, 5.0
+
+    # ---- qpos0-time constants (MuJoCo mj_setConst)
+    dofw, bodyw, cubew, meaninertia = invweight0(d)
+    for i in range(nl):
+        d.dof_invweight0[i] = dofw[i]
+        d.body_invweight0[i][0], d.body_invweight0[i][1] = bodyw[i]
+    d.cube_invweight0[0], d.cube_invweight0[1] = cubew
+    d.meaninertia = meaninertia
 
     obs_slices = {"q_pos": slice(0, nl), "q_vel": slice(nl, 2 * nl),
                   "cube_pos": slice(2 * nl, 2 * nl + 3), "cube_orn": slice(2 * nl + 3, 2 * nl + 7)}

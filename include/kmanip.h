@@ -32,6 +32,8 @@ extern "C" {
 #define KM_MAX_ARMS    2    /* arm 0 = right ("eer"), arm 1 = left ("eel")                         */
 #define KM_MAX_IK      7    /* IK unknowns per arm (7 solo/dual, 6 torso)                          */
 #define KM_MAX_SPHERES 4    /* finger sphere colliders                                             */
+#define KM_MAX_CAMS    4    /* cameras: 0 = grip_r, 1 = grip_l, 2 = top, 3 = head (__init__.py:157-161) */
+enum { KM_CAM_GRIP_R = 0, KM_CAM_GRIP_L = 1, KM_CAM_TOP = 2, KM_CAM_HEAD = 3 };
 #define KM_NQ_CUBE     7
 #define KM_NV_CUBE     6
 
@@ -134,17 +136,26 @@ typedef struct KModelDesc {
   double  epsilon;                              /* 1e-6, __init__.py:192                           */
   double  reward_vel_penalty, reward_grip_dist, reward_touch_cube, reward_lift_cube; /* :205-208  */
 
-  /* ---- gripper cameras (mode="targetbody", arm_r_body.xml:68 / arm_l_body.xml:68 / torso_body.xml:104,173);
-   * index 0 = grip_r, 1 = grip_l.  Surrogate scene for rendering = the collision primitives (cube box, table
-   * plane, finger spheres). */
-  int32_t cam_present[KM_MAX_ARMS];
-  int32_t cam_link[KM_MAX_ARMS];
-  int32_t cam_target_link[KM_MAX_ARMS];
-  int32_t pad3_[2];
-  double  cam_pos[KM_MAX_ARMS][3];          /* in cam_link's frame                                    */
-  double  cam_target_pos[KM_MAX_ARMS][3];   /* target body origin in cam_target_link's frame          */
-  double  cam_fovy[KM_MAX_ARMS];            /* degrees                                                */
+  /* ---- cameras, all mode="targetbody": gripper cameras on the hand links tracking the EE site body
+   * (arm_r_body.xml:68 / arm_l_body.xml:68 / torso_body.xml:104,173) and the world-fixed `top` / `head` cameras
+   * tracking the table (_env_solo_arm.xml:11-12 and siblings).  Index = KM_CAM_*.  A link of -1 = world frame.
+   * The rendered scene is the build's surrogate geometry = its collision primitives. */
+  int32_t cam_present[KM_MAX_CAMS];
+  int32_t cam_link[KM_MAX_CAMS];
+  int32_t cam_target_link[KM_MAX_CAMS];
+  double  cam_pos[KM_MAX_CAMS][3];          /* in cam_link's frame                                    */
+  double  cam_target_pos[KM_MAX_CAMS][3];   /* target body origin in cam_target_link's frame          */
+  double  cam_fovy[KM_MAX_CAMS];            /* degrees                                                */
   double  cam_znear, cam_zfar;              /* metres; depth is clipped to [znear, zfar], no hit = zfar */
+
+  /* ---- quantities MuJoCo precomputes at qpos0 (mj_setConst): they set the regulariser of every constraint row
+   * (efc_diagApprox -> R = (1-d)/d * diagApprox) and the solvers' termination scale 1/(meaninertia * nv).
+   * dof_invweight0[i] = (M^-1)_ii; body_invweight0[b] = mean translational / rotational diagonal of J_b M^-1 J_b^T
+   * with J_b the 6 x nv Jacobian at body b's centre of mass; the cube (free body): (1/m, mean 1/I_k). */
+  double  dof_invweight0[KM_MAX_LINKS];
+  double  body_invweight0[KM_MAX_LINKS][2];
+  double  cube_invweight0[2];
+  double  meaninertia;                      /* trace(M(qpos0)) / nv, all nv = nlink + 6 dofs          */
 } KModelDesc;
 
 typedef struct KHandle_* KHandle;
@@ -182,6 +193,25 @@ int kmanip_get_state(KHandle h, double* qpos, double* qvel, double* ctrl, double
 int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const double* ctrl,
                      const double* qacc_warm, const int32_t* step_idx);
 
+/* The episode counter completes the checkpoint: the cube-spawn stream is keyed (seed, global env id, episode), so a
+ * restored run draws the same spawns as the original only if `episode` is restored too.  HOST int32[num_envs]. Synchronous. */
+int kmanip_get_episode(KHandle h, int32_t* episode);
+int kmanip_set_episode(KHandle h, const int32_t* episode);
+
+/* Asynchronous device-to-device copy of the per-env counters into caller-owned DEVICE buffers (int32[num_envs] each, either
+ * may be NULL) on `stream`: lets the k_step seam return sim_time (= step_idx * control_timestep, env_sim.py:194,200) as a
+ * device tensor without synchronising. */
+int kmanip_get_counters(KHandle h, int32_t* step_idx_dev, int32_t* episode_dev, void* stream);
+
+/* Bind a caller-owned DEVICE buffer double[num_envs] that every kmanip_step / kmanip_reset also fills with the env's
+ * simulation time (dm_control's data.time, the last element of k_step's return tuple, env_sim.py:194,200) =
+ * steps since the env's last reset x control_timestep.  NULL unbinds.  The buffer must outlive the binding. */
+int kmanip_bind_sim_time(KHandle h, double* sim_time_dev);
+
+/* KManipEnv.reset(seed=...) (env_base.py:219-220): re-key the cube-spawn stream.  restart_episodes != 0 also rewinds every
+ * env's episode counter so that the next kmanip_reset draws episode 0 of the new seed (reset(seed=s) is then reproducible). */
+int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes);
+
 /* Per-env diagnostics of the last kmanip_step (HOST pointers, may be NULL):
  * contact_mask uint32 (KM_CON_* bits, from the trailing mj_step1), ik_nfev int32[num_envs, 2],
  * ik_status int32[num_envs, 2]. Synchronous. */
@@ -211,6 +241,12 @@ int kmanip_step_chunk(KHandle h, int nsteps, const float* act_dev, double* obs_d
  * (the clipped result.x that the reference writes into ctrl). Synchronous. */
 int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos,
               const double* goal_quat, double* q_out, int32_t* nfev, int32_t* status);
+
+/* ik_res / ik_jac (reference ik_mujoco.py:20-53 / :56-97) as the device IK evaluates them, at x = qpos[q_mask] with
+ * q_pos_prev = x, for parity tests: qpos HOST double[n, nq], goal_pos [n,3], goal_quat [n,4] (wxyz);
+ * res double[n, 6 + 2*arm_nq], jac double[n, (6 + 2*arm_nq) x arm_nq] row-major.  Synchronous. */
+int kmanip_ik_eval(KHandle h, int arm, int n, const double* qpos, const double* goal_pos,
+                   const double* goal_quat, double* res, double* jac);
 
 /* Replaces KManipEnvSim.k_render (env_sim.py:187-188) / the camera branch of get_observation
  * (env_sim.py:140-145) for the gripper cameras, as BASELINE.json config 5 defines it: a height x width

@@ -71,6 +71,26 @@ def test_ik_golden_scipy_gpu(env):
 
 
 @pytest.mark.parametrize("env", ENVS3)
+def test_ik_residual_and_jacobian_vs_scipy_fixture(env):
+    """ik_res / ik_jac as the HIP IK evaluates them (coop_eval + its regulariser rows) at x0 against the res0 / jac0 columns
+    of the NumPy/SciPy fixtures (ik_mujoco.py:20-97, incl. the deliberately inconsistent 9e-3 regulariser rows): 1e-12."""
+    _torch()
+    g = np.load(os.path.join(GOLDEN, "ik_scipy_%s.npz" % env))
+    cm, dev, orc = _mk(env, 1)
+    for arm in range(2):
+        sel = np.where(g["arm"] == arm)[0]
+        if len(sel) == 0:
+            continue
+        n = cm.desc.arm_nq[arm]
+        res, jac = dev.ik_eval(arm, g["qpos"][sel], g["goal_pos"][sel], g["goal_quat"][sel])
+        m = 6 + 2 * n
+        assert np.abs(res - g["res0"][sel][:, :m]).max() < 1e-12
+        assert np.abs(jac.reshape(len(sel), -1) - g["jac0"][sel][:, :m * n]).max() < 1e-12
+        assert np.abs(jac[:, 6:6 + n, :] - 9e-3 * np.eye(n)).max() == 0 and np.abs(jac[:, 6 + n:, :] - 9e-3 * np.eye(n)).max() == 0
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
 def test_reset_parity(env):
     torch = _torch()
     cm, dev, orc = _mk(env, 32, seed=11, off=1000)
@@ -210,18 +230,55 @@ def test_full_size_properties_4096():
         e.k_close()
 
 
-def test_dual_and_torso_full_size_smoke():
-    """BASELINE configs 3/4 per-GPU sizes run and stay finite (8192 envs each)."""
+@pytest.mark.parametrize("env_id", ["KManipDualArm", "KManipTorso"])
+def test_full_size_configs_3_and_4_shard(env_id):
+    """BASELINE config 3 (KManipDualArm @ 8192, IK on both arms) and the per-GPU shard of config 4 (KManipTorso, 65536 envs
+    = 8 x 8192) at full size on the 32-lanes-per-env path, 70 control steps (across the 64-step auto-reset):
+      * bitwise determinism (two handles, same seed and actions),
+      * shard independence: a 1024-env handle created with env_id_offset = 4096 reproduces envs 4096..5119 bit for bit,
+        i.e. what rank r of the 8-GPU job computes does not depend on the shard layout,
+      * an oracle comparison on a 16-env slice of the same batch (global env ids 4096..4111), every step,
+      * invariants: unit cube quaternion, observations inside their Box bounds, done = TimeLimit only."""
     torch = _torch()
     from gym_kmanip_amd import env_hip
-    for env_id in ["KManipDualArm", "KManipTorso"]:
-        e = env_hip.make(env_id, num_envs=8192, seed=1)
-        e.k_reset()
-        act = torch.rand((8192, 14), device="cuda") * 2 - 1
-        for k in range(3):
-            e.step_flat(act)
-        assert torch.isfinite(e.obs).all() and torch.isfinite(e.reward).all()
-        assert not (e.done & KM_DONE_DIVERGED).any()
+    from oracle.oracle import Oracle
+    n, lo, ns, no = 8192, 4096, 1024, 16
+    a = env_hip.make(env_id, num_envs=n, seed=3)
+    b = env_hip.make(env_id, num_envs=n, seed=3)
+    c = env_hip.make(env_id, num_envs=ns, seed=3, env_id_offset=lo)
+    orc = Oracle(a.cm, no, seed=3, env_id_offset=lo)
+    nl, ad = a.cm.nlink, a.cm.act_dim
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    a.k_reset(); b.k_reset(); c.k_reset(); orc.reset()
+    saw_contact = False
+    for k in range(70):
+        act = torch.rand((n, ad), generator=gen, device="cuda") * 2 - 1
+        a.step_flat(act); b.step_flat(act.clone()); c.step_flat(act[lo:lo + ns].contiguous())
+        oo, ro, do = orc.step(act[lo:lo + no].cpu().numpy())
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), k
+        assert torch.equal(a.obs[lo:lo + ns], c.obs) and torch.equal(a.reward[lo:lo + ns], c.reward) and torch.equal(a.done[lo:lo + ns], c.done), k
+        assert np.abs(a.obs[lo:lo + no].cpu().numpy() - oo).max() < TOL_Q, k
+        assert np.abs(a.reward[lo:lo + no].cpu().numpy() - ro).max() < TOL_R, k
+        assert np.array_equal(a.done[lo:lo + no].cpu().numpy(), do), k
+        done = a.done.cpu().numpy()
+        assert not (done & KM_DONE_DIVERGED).any(), k
+        assert (done == (KM_DONE_TRUNCATED if k == 63 else 0)).all(), k
+        if k in (20, 62, 69):
+            mg = a.get_diag()[0]; mo = orc.get_diag()[0]
+            assert np.array_equal(mg[lo:lo + no], mo), k                 # contact masks bit-exact on the slice
+            saw_contact |= bool(mg.any())
+    sa, sb, sc, so = a.get_state(), b.get_state(), c.get_state(), orc.get_state()
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+    for x, z in zip(sa, sc):
+        assert np.array_equal(x[lo:lo + ns], z)
+    assert np.abs(sa[0][lo:lo + no] - so[0]).max() < TOL_Q and np.abs(sa[1][lo:lo + no] - so[1]).max() < TOL_V
+    assert np.array_equal(sa[2][lo:lo + no], so[2])
+    assert saw_contact and (sa[4] == 6).all()
+    assert np.abs(np.linalg.norm(sa[0][:, nl + 3:], axis=1) - 1).max() < 1e-12
+    obs = a.obs.cpu().numpy()
+    assert np.isfinite(obs).all() and (np.abs(obs) <= 1).all() and (obs[:, :nl] >= 0).all()
+    for e in (a, b, c):
         e.k_close()
 
 
@@ -250,33 +307,55 @@ def test_render_depth_parity(env, cams):
 
 
 def test_render_depth_config5_size():
-    """BASELINE config 5 size: 2048 envs x 64x64 depth; deterministic and finite."""
+    """BASELINE config 5 size: 2048 envs x 64x64 gripper-cam depth rendered after every control step, across the auto-reset:
+    deterministic (two handles), finite, inside [znear, zfar], and equal to the oracle's ray caster on a slice of the batch."""
     torch = _torch()
     from gym_kmanip_amd import env_hip
-    e = env_hip.make("KManipSoloArm", num_envs=2048, seed=1)
-    e.k_reset()
-    act = torch.rand((2048, 7), device="cuda") * 2 - 1
-    for k in range(3):
-        e.step_flat(act)
-    a = e.render_depth("grip_r", 64, 64); b = e.render_depth("grip_r", 64, 64)
-    assert a.shape == (2048, 64, 64) and torch.equal(a, b) and torch.isfinite(a).all()
-    e.k_close()
+    from oracle.oracle import Oracle
+    n = 2048
+    e = env_hip.make("KManipSoloArm", num_envs=n, seed=1); f = env_hip.make("KManipSoloArm", num_envs=n, seed=1)
+    orc = Oracle(e.cm, 8, seed=1, env_id_offset=1000)
+    e.k_reset(); f.k_reset(); orc.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    buf_e = torch.empty((n, 64, 64), dtype=torch.float32, device="cuda"); buf_f = torch.empty_like(buf_e)
+    for k in range(66):
+        act = torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1
+        e.step_flat(act); f.step_flat(act)
+        e.render_depth("grip_r", 64, 64, out=buf_e); f.render_depth("grip_r", 64, 64, out=buf_f)
+        orc.step(act[1000:1008].cpu().numpy())
+        if k in (0, 30, 63, 65):
+            assert torch.equal(buf_e, buf_f) and torch.isfinite(buf_e).all(), k
+            assert (buf_e >= e.cm.desc.cam_znear - 1e-6).all() and (buf_e <= e.cm.desc.cam_zfar + 1e-6).all()
+            qpos = orc.get_state()[0]
+            img = buf_e[1000:1008].cpu().numpy()
+            for j in range(8):
+                bad = np.abs(img[j] - orc.render_depth(qpos[j], 0, 64, 64)) > 1e-6
+                assert bad.mean() < 5e-4, (k, j, bad.sum())
+    e.k_close(); f.k_close()
 
 
 @pytest.mark.parametrize("env", ["KManipSoloArm", "KManipTorso"])
 def test_fused_and_split_launches_agree(env, monkeypatch):
-    """The product path runs before_step inside k_step; KMANIP_IK_UNFUSED=1 (and the one-lane KMANIP_IK_SERIAL=1
-    kernel) keep it as separate launches.  Same device code on the same inputs => bit-identical state/obs/reward."""
+    """The product path runs before_step inside k_step; KMANIP_IK_UNFUSED=1 keeps it as separate launches.  Same device
+    code on the same inputs => bit-identical state/obs/reward.  (The one-lane-per-problem IK kernel is a diagnostic build
+    only -- `make -C gym_kmanip_amd/csrc diag` -- and the product library refuses KMANIP_IK_SERIAL=1.)"""
     torch = _torch()
     from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.lib import KManipError
     n = 96
     cm = compile_model(env)
     envs = {}
-    for name, var in (("fused", None), ("split", "KMANIP_IK_UNFUSED"), ("serial", "KMANIP_IK_SERIAL")):
+    for name, var in (("fused", None), ("split", "KMANIP_IK_UNFUSED")):
         monkeypatch.delenv("KMANIP_IK_UNFUSED", raising=False); monkeypatch.delenv("KMANIP_IK_SERIAL", raising=False)
         if var:
             monkeypatch.setenv(var, "1")
         envs[name] = env_hip.KManipEnvHip(cm, num_envs=n, seed=9)      # the switch is read at kmanip_create
+    monkeypatch.delenv("KMANIP_IK_UNFUSED", raising=False)
+    if "diag" not in os.path.basename(env_hip._libmod.LIB_PATH):
+        monkeypatch.setenv("KMANIP_IK_SERIAL", "1")
+        with pytest.raises(KManipError, match="diagnostic build"):
+            env_hip.KManipEnvHip(cm, num_envs=4, seed=9)
+        monkeypatch.delenv("KMANIP_IK_SERIAL", raising=False)
     gen = torch.Generator(device="cuda"); gen.manual_seed(4)
     for e in envs.values():
         e.k_reset()
@@ -291,9 +370,6 @@ def test_fused_and_split_launches_agree(env, monkeypatch):
     df, ds = envs["fused"].get_diag(), envs["split"].get_diag()
     for x, y in zip(df, ds):
         assert np.array_equal(x, y)
-    # the serial kernel is a different implementation of the same TRF (one lane per problem): tolerance, not bits
-    sf, ss = envs["fused"].get_state(), envs["serial"].get_state()
-    assert np.abs(sf[0] - ss[0]).max() < TOL_Q and np.abs(sf[1] - ss[1]).max() < TOL_V
     for e in envs.values():
         e.k_close()
 
@@ -433,3 +509,84 @@ def test_episode_logger_from_device_buffers(tmp_path):
     assert np.array_equal(z["observations/qpos"], np.stack(qps)[:, 7].astype(np.float32))
     assert np.array_equal(z["observations/qvel"], np.stack(qvs)[:, 7].astype(np.float32))
     e.k_close()
+
+
+def test_raw_step_rejects_malformed_tensors():
+    """step_flat / step_chunk hand raw pointers to the kernel: wrong dtype / device / shape / layout must raise, not run."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.lib import KManipError
+    e = env_hip.make("KManipSoloArm", num_envs=8)
+    e.k_reset()
+    good = torch.zeros((8, 7), dtype=torch.float32, device="cuda")
+    e.step_flat(good)
+    for bad in (good.double(), good.cpu(), torch.zeros((7, 7), dtype=torch.float32, device="cuda"),
+                torch.zeros((8, 14), dtype=torch.float32, device="cuda")[:, ::2], good.cpu().numpy()):
+        with pytest.raises(KManipError):
+            e.step_flat(bad)
+    with pytest.raises(KManipError):
+        e.step_chunk(torch.zeros((3, 8, 7), dtype=torch.float64, device="cuda"))
+    with pytest.raises(KManipError):
+        e.step_chunk(torch.zeros((3, 8, 7), dtype=torch.float32, device="cuda"), obs=torch.zeros((3, 8, 27), dtype=torch.float32, device="cuda"))
+    e.k_close()
+
+
+def test_checkpoint_restores_the_spawn_stream():
+    """get_state + get_episode is a complete checkpoint: a restored handle reproduces the original run bit for bit ACROSS
+    the next auto-reset (the cube spawn is keyed by seed, global env id and the episode counter)."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    n = 64
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=41, env_id_offset=100)
+    a.k_reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(6)
+    acts = [(torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1) for _ in range(100)]
+    for k in range(70):                                   # into episode 1
+        a.step_flat(acts[k])
+    ck = a.checkpoint()
+    assert (ck[5] == 1).all() and (ck[4] == 6).all()
+    b = env_hip.make("KManipSoloArm", num_envs=n, seed=41, env_id_offset=100)
+    b.restore(ck)
+    for k in range(70, 100):                              # 70 + 58 = 128: crosses the second auto-reset
+        a.step_flat(acts[k]); b.step_flat(acts[k])
+        if k in (75, 99):
+            assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), k
+    for k in range(100, 130):
+        act = acts[k - 100]
+        a.step_flat(act); b.step_flat(act)
+    assert torch.equal(a.obs, b.obs)
+    for x, y in zip(a.checkpoint(), b.checkpoint()):
+        assert np.array_equal(x, y)
+    assert (a.get_episode() == 2).all()
+    # without the episode counter the spawn after the next reset differs
+    c = env_hip.make("KManipSoloArm", num_envs=n, seed=41, env_id_offset=100)
+    c.set_state(*ck[:5])
+    for k in range(70, 130):
+        c.step_flat(acts[k % 100])
+    assert not torch.equal(a.obs, c.obs)
+    for e in (a, b, c):
+        e.k_close()
+
+
+def test_seam_k_step_device_dict_no_host_roundtrip():
+    """k_step with a dict of DEVICE tensors == step_flat on the packed action, returns device tensors only (sim_time too),
+    and keeps the caller's current device."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    n = 128
+    a = env_hip.make("KManipDualArm", num_envs=n, seed=3); b = env_hip.make("KManipDualArm", num_envs=n, seed=3)
+    a.k_reset(); b.k_reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    for k in range(66):
+        flat = (torch.rand((n, a.cm.act_dim), generator=gen, device="cuda") * 2 - 1)
+        d = {key: flat[:, sl] for key, sl in a.cm.act_slices.items()}          # strided device views, reference key names
+        terminated, reward, discount, obs, sim_time = a.k_step(d)
+        b.step_flat(flat)
+        assert torch.equal(a.obs, b.obs) and torch.equal(reward, b.reward)
+        assert all(t.is_cuda for t in (terminated, reward, discount, sim_time)) and all(v.is_cuda for v in obs.values())
+    assert not terminated.any() and (discount == 1).all()
+    # 66 steps = one auto-reset at 64 + 2 steps: sim_time is each env's data.time
+    assert torch.allclose(sim_time, torch.full((n,), 2 * 0.02, dtype=torch.float64, device="cuda"), atol=0, rtol=0)
+    assert list(obs.keys()) == ["q_pos", "q_vel", "cube_pos", "cube_orn"]
+    assert torch.cuda.current_device() == 0
+    a.k_close(); b.k_close()

@@ -1,0 +1,85 @@
+"""The N > 1 path with the HIP engine: world_size-2 rank processes, each stepping its contiguous env shard through the
+C ABI and all-gathering (reward, done) every step, must reproduce a single-process run of all envs BIT FOR BIT (envs
+share only the read-only model -- one independent Physics per env in the reference, env_sim.py:206-211 -- and the RNG is
+keyed by the global env id).  With >= 2 GPUs: one rank per GPU over RCCL.  On a one-GPU box the same code is rehearsed
+with both ranks on cuda:0 and gloo in place of RCCL (RCCL refuses two ranks on one device)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_ranks(out, world, extra):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "rank_worker.py"), "--out", out] + extra, env=env))
+    try:
+        codes = [p.wait(timeout=300) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0] * world, codes
+
+
+@pytest.mark.parametrize("env_id,total,steps", [("KManipSoloArm", 512, 70), ("KManipTorso", 128, 66)])
+def test_two_ranks_match_one_rank_bitwise(tmp_path, env_id, total, steps):
+    import torch
+    assert torch.cuda.is_available()
+    from gym_kmanip_amd import env_hip
+    multi = torch.cuda.device_count() >= 2
+    extra = ["--env", env_id, "--total", str(total), "--steps", str(steps)]
+    extra += ["--backend", "nccl"] if multi else ["--backend", "gloo", "--same-device"]
+    _run_ranks(str(tmp_path), 2, extra)
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2)]
+    # single-process reference over all envs
+    ref = env_hip.make(env_id, num_envs=total, seed=9, env_id_offset=0)
+    ref.k_reset()
+    gen = torch.Generator(); gen.manual_seed(1234)
+    for k in range(steps):
+        act_all = torch.rand((total, ref.cm.act_dim), generator=gen) * 2 - 1
+        ref.step_flat(act_all.cuda())
+        rew, done = ref.reward.cpu().numpy(), ref.done.cpu().numpy()
+        for r in ranks:                                     # every rank saw the whole job's (reward, done) at every step
+            assert np.array_equal(r["rew"][k], rew), k
+            assert np.array_equal(r["done"][k], done), k
+    assert ranks[0]["done"][63].all() and not ranks[0]["done"][62].any()      # the auto-reset boundary was crossed
+    st = ref.get_state(); obs = ref.obs.cpu().numpy()
+    for r in ranks:
+        lo, hi = int(r["lo"]), int(r["hi"])
+        assert np.array_equal(r["obs"], obs[lo:hi]) and np.array_equal(r["qpos"], st[0][lo:hi])
+        assert np.array_equal(r["qvel"], st[1][lo:hi]) and np.array_equal(r["ctrl"], st[2][lo:hi])
+    assert int(ranks[0]["hi"]) == int(ranks[1]["lo"]) == total // 2
+    ref.k_close()
+
+
+def test_bench_self_launch_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun) end to end: the parent spawns both ranks, rank 0 prints the one JSON line.
+    One-GPU boxes rehearse it with KMANIP_BENCH_ONE_GPU=1 / KMANIP_BENCH_BACKEND=gloo (both ranks on cuda:0)."""
+    import json
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    if torch.cuda.device_count() < 2:
+        env.update(KMANIP_BENCH_ONE_GPU="1", KMANIP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+                        "--envs-per-gpu", "256", "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["envs_per_gpu"] == 256 and d["value"] > 0 and d["steps"] == 8
+    assert "collective" in d["config"] and d["config"]["collective"].startswith("async all_gather")

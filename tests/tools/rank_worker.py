@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""One rank of a multi-process HIP-engine run (started by tests/test_multi_rank_gpu.py with the torch.distributed
+environment of its rank): steps its contiguous env shard on its GPU, all-gathers (reward, done) every step, and saves what
+it saw.  `--same-device` puts every rank on cuda:0 and `--backend gloo` swaps RCCL for gloo, so that the whole multi-rank
+code path can be rehearsed on a one-GPU box (RCCL itself refuses two ranks on one device)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--env", default="KManipSoloArm")
+    ap.add_argument("--total", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=70)
+    ap.add_argument("--seed", type=int, default=9)
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--same-device", action="store_true")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.dist import RewardDoneGather, shard_range
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = 0 if a.same_device else int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(dev)
+    kw = {"device_id": torch.device("cuda", dev)} if a.backend == "nccl" else {}
+    dist.init_process_group(a.backend, rank=rank, world_size=world, **kw)
+    lo, hi = shard_range(a.total, world, rank)
+    n = hi - lo
+    env = env_hip.make(a.env, num_envs=n, device=dev, seed=a.seed, env_id_offset=lo)
+    env.k_reset()
+    g = RewardDoneGather(n, world, torch.device("cuda", dev), dist)
+    gen = torch.Generator(); gen.manual_seed(1234)                      # CPU generator: the same stream on every rank
+    rew, done = [], []
+    for k in range(a.steps):
+        act_all = torch.rand((a.total, env.cm.act_dim), generator=gen) * 2 - 1
+        env.step_flat(act_all[lo:hi].contiguous().cuda())
+        b = g.post(env.reward, env.done)
+        r_all, d_all = g.result(b)
+        rew.append(r_all.cpu().numpy().copy()); done.append(d_all.cpu().numpy().copy())
+    st = env.get_state()
+    np.savez(os.path.join(a.out, "rank%d.npz" % rank), rew=np.array(rew), done=np.array(done), obs=env.obs.cpu().numpy(),
+             qpos=st[0], qvel=st[1], ctrl=st[2], lo=lo, hi=hi)
+    env.k_close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
