@@ -37,12 +37,21 @@ def _mk(env_id, n, seed=0, off=0, **kw):
     return cm, env_hip.KManipEnvHip(cm, num_envs=n, seed=seed, env_id_offset=off), Oracle(cm, n, seed=seed, env_id_offset=off)
 
 
-def _cmp_state(g, o, k=""):
+def _cmp_state(g, o, k="", resync=None):
+    """qpos / qvel within tolerance, step counters and ctrl bit-exact.  ctrl is float32-quantised (env_sim.py:40,71), so a
+    free-running comparison has one legitimate failure mode: two float64 IK results that agree to 1e-9 can straddle a
+    float32 rounding boundary.  With `resync` (a one-element list used as a counter) such a flip -- every mismatching entry
+    within one float32 ulp -- re-synchronises the oracle to the device state instead of failing; callers bound the count."""
     sg, so = g.get_state(), o.get_state()
     assert np.abs(sg[0] - so[0]).max() < TOL_Q, ("qpos", k, np.abs(sg[0] - so[0]).max())
     assert np.abs(sg[1] - so[1]).max() < TOL_V, ("qvel", k, np.abs(sg[1] - so[1]).max())
-    assert np.array_equal(sg[2], so[2]), ("ctrl", k)
     assert np.array_equal(sg[4], so[4]), ("step_idx", k)
+    if not np.array_equal(sg[2], so[2]):
+        bad = sg[2] != so[2]
+        ulp = np.spacing(np.abs(so[2][bad]).astype(np.float32)).astype(np.float64)
+        assert resync is not None and (np.abs(sg[2][bad] - so[2][bad]) <= ulp).all(), ("ctrl", k, sg[2][bad], so[2][bad])
+        resync[0] += 1
+        o.set_state(*sg)
 
 
 @pytest.mark.parametrize("env", ENVS3)
@@ -119,11 +128,12 @@ def test_step_parity_vs_oracle(env, n, steps, solver):
     dev.k_reset(); orc.reset()
     rng = np.random.default_rng(42)
     saw_contact = saw_reset = False
+    resync = [0]
     for k in range(steps):
         act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
         dev.step_flat(torch.from_numpy(act).cuda())
         oo, ro, do = orc.step(act)
-        _cmp_state(dev, orc, k)
+        _cmp_state(dev, orc, k, resync)
         assert np.abs(dev.obs.cpu().numpy() - oo).max() < TOL_Q, k
         assert np.abs(dev.reward.cpu().numpy() - ro).max() < TOL_R, k
         assert np.array_equal(dev.done.cpu().numpy(), do), k
@@ -132,6 +142,7 @@ def test_step_parity_vs_oracle(env, n, steps, solver):
         assert np.array_equal(stg == -2, sto == -2) and np.abs(nfg - nfo).max() <= 1, k
         saw_contact |= bool(mg.any()); saw_reset |= bool(do.any())
     assert saw_contact and saw_reset
+    assert resync[0] <= (2 if solver == "pgs" else 0), resync      # float32 ctrl flips: none with the converging solver
     dev.k_close()
 
 
