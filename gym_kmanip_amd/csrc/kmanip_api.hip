@@ -69,6 +69,10 @@ static int validate(const KModelDesc* d, std::string& err) {
   if (d->nsphere < 0 || d->nsphere > KM_MAX_SPHERES || d->nsphere > 2 * (d->nlink / 10)) { err = "too many finger spheres"; return -1; }
   if (d->obs_dim != 2 * d->nlink + 7) { err = "obs_dim != 2*nlink+7"; return -1; }
   if (d->n_sub_steps < 1 || d->solver_iterations < 0) { err = "bad n_sub_steps / solver_iterations"; return -1; }
+  for (const double* si : {d->con_def_solimp, d->con_cube_solimp}) {
+    const double power = si[4] < 1 ? 1 : si[4];
+    if (power != 1 && power != 2) { err = "solimp power must be 1 or 2 (MuJoCo's default is 2; the device impedance spline has no pow)"; return -1; }
+  }
   for (int i = 0; i < d->nlink; i++)
     if (d->link_parent[i] >= i || d->link_parent[i] < -1) { err = "links must be ordered parents-first"; return -1; }
   int nik = 0;

@@ -122,6 +122,29 @@ __device__ __forceinline__ real rsqrt_nr(real s) {
   return y;
 }
 
+// 1/x to double precision: hardware estimate + two Newton steps (6 instructions instead of the ~14 of an IEEE divide; last-bit
+// differences only).  Used on the physics path; the IK keeps IEEE divides (its TRF control flow mirrors SciPy's decisions).
+__device__ __forceinline__ real frcp(real x) {
+  real r = __builtin_amdgcn_rcp(x);
+  r = r + r * (1.0 - x * r);
+  r = r + r * (1.0 - x * r);
+  return r;
+}
+// mju_normalize3 / normalize4 without sqrt + divide sequences (physics path)
+__device__ __forceinline__ real normalize3_fast(real* v) {
+  const real s = dot3(v, v);
+  if (s < MJ_MINVAL * MJ_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return sqrt(s); }
+  const real inv = rsqrt_nr(s);
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  return s * inv;
+}
+__device__ __forceinline__ void normalize4_fast(real* q) {
+  const real s = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (s < MJ_MINVAL * MJ_MINVAL) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
+  const real inv = rsqrt_nr(s);
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+
 // cross-lane double move with a DPP control word (a DPP row is 16 lanes)
 template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
   int lo = __double2loint(v), hi = __double2hiint(v);

@@ -31,6 +31,9 @@
 //   PGS              : per-contact block form on the 4x4 Gram matrix (algebraically the same row order)
 #include "kmanip_ik_coop.hpp"
 #include <stdlib.h>
+// tree loops over link candidates (static addresses + a mask bit each): fully unrolled for the 10-link model, where all the
+// loads can be in flight together; the 20-link models sit at the 512-register limit and keep them rolled
+#define KM_TREE_UNROLL(NL) NL <= 10 ? NL : 1
 #define KM_TARGET_WAVES 1024   // 256 CUs x 4 SIMDs: below this many workgroups, fewer envs per wave fills more SIMDs
 
 template <int NL> struct Dim {
@@ -62,6 +65,9 @@ struct LModel {
   // FIRST pyramid edge of every contact slot (tran + mu^2 tran, tran = summed body_invweight0 of the pair), of the cube's
   // friction-loss rows (linear, angular), and the solvers' termination scale 1 / (meaninertia * nv)
   real dofw[NL], slotA[Dim<NL>::NC], cubew[2], scale;
+  // solimp of the two parameter sets, clamped like mj_makeImpedance clamps it, with the reciprocals the spline divides by
+  // (mode 0: constant (d0 + dw) / 2; 1: linear; 2: MuJoCo's default quadratic spline)
+  struct Imp { real d0, dw, iw, mid, imid, i1mid; int mode; } imp[2];
 };
 
 // Solver view of one pyramidal contact (group-uniform scalars).  Basis index 0 = normal, 1..2 = tangents,
@@ -223,7 +229,7 @@ __device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int
     w.k.xpos[sub][0] = p[0]; w.k.xpos[sub][1] = p[1]; w.k.xpos[sub][2] = p[2];
   } else if (sub == NL) {
     real cq[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]}, cm[9];
-    normalize4(cq);
+    normalize4_fast(cq);
     quat2mat(cm, cq);
 #pragma unroll
     for (int c = 0; c < 9; c++) w.k.cube_mat[c] = cm[c];
@@ -307,16 +313,32 @@ __device__ __forceinline__ void composite_accumulate(Ws<NL>& w, const LModel<NL>
   real acc[16];
   const bool on = sub < NL;
   if (on) {
+    if constexpr (NL <= 10) {
+    // every candidate j at a compile-time address (all loads can be in flight together; no mask-driven pointer chase),
+    // taken or not by its descendant bit.  Links are ordered parents-first, so descendants have larger indices.
+    const uint32_t dm = lm.desc[sub];
 #pragma unroll
-    for (int k = 0; k < 10; k++) acc[k] = w.f.comp[sub][k];
+    for (int k = 0; k < 16; k++) acc[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) acc[10 + k] = w.f.FN[sub][k];
-    for (uint32_t mk = lm.desc[sub] & ~(1u << sub); mk; mk &= mk - 1) {
-      const int j = __ffs(mk) - 1;
+    for (int j = 0; j < NL; j++) {
+      const bool take = (dm >> j) & 1u;                 // (bit `sub` itself is set: the link's own contribution)
 #pragma unroll
-      for (int k = 0; k < 10; k++) acc[k] += w.f.comp[j][k];
+      for (int k = 0; k < 10; k++) { const real v = w.f.comp[j][k]; acc[k] += take ? v : 0.0; }
 #pragma unroll
-      for (int k = 0; k < 6; k++) acc[10 + k] += w.f.FN[j][k];
+      for (int k = 0; k < 6; k++) { const real v = w.f.FN[j][k]; acc[10 + k] += take ? v : 0.0; }
+    }
+    } else {                                            // (the 20-link kernels sit at the 512-register limit: rolled mask walk)
+#pragma unroll
+      for (int k = 0; k < 10; k++) acc[k] = w.f.comp[sub][k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[10 + k] = w.f.FN[sub][k];
+      for (uint32_t mk = lm.desc[sub] & ~(1u << sub); mk; mk &= mk - 1) {
+        const int j = __ffs(mk) - 1;
+#pragma unroll
+        for (int k = 0; k < 10; k++) acc[k] += w.f.comp[j][k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[10 + k] += w.f.FN[j][k];
+      }
     }
   }
   GSYNC();
@@ -349,18 +371,17 @@ __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int
       cross3(t, h, aO);
       N[0] += t[0]; N[1] += t[1]; N[2] += t[2];
     }
-    for (int i = 0; i < NL; i++) w.Minv[i][j] = 0;            // non-ancestors (filled symmetric below)
-    for (int i = j; i >= 0; i = lm.parent[i]) {
-      real val;
+    // rows i = ancestors of j (incl. j), every candidate i at a compile-time address and taken by its ancestor bit -- no
+    // pointer chase up the tree through LDS; non-ancestors get the zero they need (the reader mirrors the triangle)
+    const uint32_t am = lm.anc[j];
+#pragma unroll KM_TREE_UNROLL(NL)
+    for (int i = 0; i < NL; i++) {
       const real ai[3] = {w.k.axis[i][0], w.k.axis[i][1], w.k.axis[i][2]};
-      if (lm.jtype[i] == KM_JNT_SLIDE) val = dot3(ai, F);
-      else {
-        const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
-        cross3(t, oi, F);
-        real mo[3] = {N[0] - t[0], N[1] - t[1], N[2] - t[2]};
-        val = dot3(ai, mo);
-      }
-      w.Minv[i][j] = val;
+      const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
+      cross3(t, oi, F);
+      const real mo[3] = {N[0] - t[0], N[1] - t[1], N[2] - t[2]};
+      const real val = lm.jtype[i] == KM_JNT_SLIDE ? dot3(ai, F) : dot3(ai, mo);
+      w.Minv[i][j] = ((am >> i) & 1u) ? val : 0.0;
     }
   }
 }
@@ -395,14 +416,24 @@ __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>
   GSYNC();
   real wp[3] = {0, 0, 0}, cz[3] = {0, 0, 0};
   if (on) {
-    for (uint32_t mk = up; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; wp[0] += wvb[3 * j]; wp[1] += wvb[3 * j + 1]; wp[2] += wvb[3 * j + 2]; }
+#pragma unroll KM_TREE_UNROLL(NL)
+    for (int j = 0; j < NL; j++) {                                     // (static addresses, taken by the ancestor bit; root-to-leaf order)
+      const bool take = (up >> j) & 1u;
+      const real v0 = wvb[3 * j], v1 = wvb[3 * j + 1], v2 = wvb[3 * j + 2];
+      wp[0] += take ? v0 : 0.0; wp[1] += take ? v1 : 0.0; wp[2] += take ? v2 : 0.0;
+    }
     cross3(cz, wp, ax);
     czb[3 * sub] = slide ? 0.0 : cz[0]; czb[3 * sub + 1] = slide ? 0.0 : cz[1]; czb[3 * sub + 2] = slide ? 0.0 : cz[2];
   }
   GSYNC();
   real alp[3] = {0, 0, 0};
   if (on) {
-    for (uint32_t mk = up; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; alp[0] += czb[3 * j]; alp[1] += czb[3 * j + 1]; alp[2] += czb[3 * j + 2]; }
+#pragma unroll KM_TREE_UNROLL(NL)
+    for (int j = 0; j < NL; j++) {
+      const bool take = (up >> j) & 1u;
+      const real v0 = czb[3 * j], v1 = czb[3 * j + 1], v2 = czb[3 * j + 2];
+      alp[0] += take ? v0 : 0.0; alp[1] += take ? v1 : 0.0; alp[2] += take ? v2 : 0.0;
+    }
     const int p = lm.parent[sub];
     real op[3] = {0, 0, 0};
     if (p >= 0) { op[0] = w.k.xpos[p][0]; op[1] = w.k.xpos[p][1]; op[2] = w.k.xpos[p][2]; }
@@ -415,7 +446,13 @@ __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>
   GSYNC();
   if (on) {
     real ai[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]};
-    for (uint32_t mk = lm.anc[sub]; mk; mk &= mk - 1) { const int j = __ffs(mk) - 1; ai[0] += dbb[3 * j]; ai[1] += dbb[3 * j + 1]; ai[2] += dbb[3 * j + 2]; }
+    const uint32_t am = lm.anc[sub];
+#pragma unroll KM_TREE_UNROLL(NL)
+    for (int j = 0; j < NL; j++) {
+      const bool take = (am >> j) & 1u;
+      const real v0 = dbb[3 * j], v1 = dbb[3 * j + 1], v2 = dbb[3 * j + 2];
+      ai[0] += take ? v0 : 0.0; ai[1] += take ? v1 : 0.0; ai[2] += take ? v2 : 0.0;
+    }
     real wi[3] = {wp[0], wp[1], wp[2]}, ali[3] = {alp[0], alp[1], alp[2]};
     if (!slide) {
 #pragma unroll
@@ -483,7 +520,7 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
     constexpr int k = decltype(kc)::value;
     real pk = gbcast<G, k>(a[k]);
     if (!(pk > 0)) { bad = 1; pk = 1; }
-    const real d = 1.0 / pk;
+    const real d = frcp(pk);
     const real aik = a[k];
     const bool me = sub == k;
     static_for<0, NL>([&](auto jc) {
@@ -506,12 +543,12 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
 
 // mju_makeFrame
 __device__ __forceinline__ void make_frame(real* fr) {
-  normalize3(fr);
+  normalize3_fast(fr);
   real y[3] = {0, 0, 0};
   if (fr[1] < 0.5 && fr[1] > -0.5) y[1] = 1; else y[2] = 1;
   real t = dot3(fr, y);
   y[0] -= t * fr[0]; y[1] -= t * fr[1]; y[2] -= t * fr[2];
-  normalize3(y);
+  normalize3_fast(y);
   fr[3] = y[0]; fr[4] = y[1]; fr[5] = y[2];
   cross3(fr + 6, fr, fr + 3);
 }
@@ -567,7 +604,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     real nloc[3], d1;
     if (!inside) {
       nloc[0] = cl[0] - loc[0]; nloc[1] = cl[1] - loc[1]; nloc[2] = cl[2] - loc[2];
-      real dn = normalize3(nloc);
+      real dn = normalize3_fast(nloc);
       d1 = dn - rad;
     } else {
       int best = 0; real bd = INFINITY;
@@ -610,7 +647,24 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
   }
 }
 
-// MuJoCo impedance / reference acceleration parameters
+// MuJoCo impedance d(r) from the staged, pre-clamped solimp constants: no divide, no pow (power is 1 or 2: kmanip_create
+// refuses any other value; every reference model uses the default 2)
+template <class IMP> __device__ __forceinline__ real impedance_c(const IMP& p, real pos) {
+  if (p.mode == 0) return 0.5 * (p.d0 + p.dw);
+  const real x = fabs(pos) * p.iw;
+  if (x >= 1) return p.dw;
+  if (x <= 0) return p.d0;
+  const real y = p.mode == 1 ? x : ((x <= p.mid) ? x * x * p.imid : 1 - (1 - x) * (1 - x) * p.i1mid);
+  return p.d0 + y * (p.dw - p.d0);
+}
+template <class IMP> __device__ __forceinline__ void stage_imp(IMP& p, const real* si) {
+  p.d0 = fmin(fmax(si[0], MJ_MINIMP), MJ_MAXIMP); p.dw = fmin(fmax(si[1], MJ_MINIMP), MJ_MAXIMP);
+  const real width = fmax(MJ_MINVAL, si[2]);
+  p.mid = fmin(fmax(si[3], MJ_MINIMP), MJ_MAXIMP);
+  p.iw = 1.0 / width; p.imid = 1.0 / p.mid; p.i1mid = 1.0 / (1 - p.mid);
+  p.mode = (p.d0 == p.dw || width <= MJ_MINVAL) ? 0 : (fmax(1.0, si[4]) == 1 ? 1 : 2);
+}
+// MuJoCo impedance / reference acceleration parameters (general form; staging only)
 __device__ __forceinline__ real impedance(const real* si, real pos) {
   real d0 = fmin(fmax(si[0], MJ_MINIMP), MJ_MAXIMP), dw = fmin(fmax(si[1], MJ_MINIMP), MJ_MAXIMP);
   real width = fmax(MJ_MINVAL, si[2]), mid = fmin(fmax(si[3], MJ_MINIMP), MJ_MAXIMP), power = fmax(1.0, si[4]);
@@ -619,9 +673,8 @@ __device__ __forceinline__ real impedance(const real* si, real pos) {
   if (x >= 1) return dw;
   if (x <= 0) return d0;
   if (power == 1) y = x;
-  else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // MuJoCo's default power
-  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  else y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // power 2, MuJoCo's default (others refused at create)
+  (void)power;
   return d0 + y * (dw - d0);
 }
 __device__ __forceinline__ void get_kb(const KModelDesc* m, const real* sr, const real* si, real& kk, real& bb) {
@@ -685,9 +738,8 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
     const int j = w.s_dof[r];
     real Ad = w.Minv[j][j];
     real pos = w.s_pos[r];
-    real imp = impedance(m->con_def_solimp, pos), kk, bb;
-    get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
-    const real R = fmax(MJ_MINVAL, (1 - imp) / imp * lm.dofw[j]);      // efc_diagApprox = dof_invweight0, not the exact A_ii
+    real imp = impedance_c(lm.imp[0], pos), kk = lm.kb[0][0], bb = lm.kb[0][1];
+    const real R = fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * lm.dofw[j]);      // efc_diagApprox = dof_invweight0, not the exact A_ii
     w.s_R[r] = R;
     w.s_den[r] = Ad + R;
     w.s_inv[r] = 1.0 / (Ad + R);
@@ -764,8 +816,8 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
       const real* si = cube ? m->con_cube_solimp : m->con_def_solimp;
       real mu[3] = {fr[0], fr[0], fr[1]};
       const real dist = w.c_dist[c];
-      real imp = impedance(si, dist), kk, bb;
-      get_kb(m, sr, si, kk, bb);
+      real imp = impedance_c(lm.imp[cube ? 1 : 0], dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
+      (void)sr; (void)si;
       const int ne = kind == 2 ? 4 : 6;
       real R = 0;
       ConRec& rc = w.rec[c];
@@ -777,7 +829,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
 #pragma unroll
         for (int l = 0; l < 4; l++) Ge[l] = Gm[l][0] + sm * Gm[l][k];        // J_l . M^-1 (J_0 + sm J_k)^T
         const real Ad = Ge[0] + sm * Ge[k];
-        if (e == 0) R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * lm.slotA[c]);
+        if (e == 0) R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * lm.slotA[c]);
         const real vel = vb[0] + sm * vb[k];
         if (sub == 0) {
           rc.den[e] = Ad + R;
@@ -837,9 +889,8 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
   real my_f = 0, my_aref = 0, my_R = 1, my_den = 1, my_inv = 0;
   const real my_fl = m->cube_frictionloss;
   if (my_row) {
-    real imp = impedance(m->con_def_solimp, 0.0), kk, bb;
-    get_kb(m, m->con_def_solref, m->con_def_solimp, kk, bb);
-    my_R = fmax(MJ_MINVAL, (1 - imp) / imp * lm.cubew[sub < NL + 3 ? 0 : 1]);
+    real imp = lm.imp0[0], bb = lm.kb[0][1];
+    my_R = fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * lm.cubew[sub < NL + 3 ? 0 : 1]);
     my_den = invm + my_R;
     my_inv = 1.0 / my_den;
     my_aref = -bb * w.qvel[sub];
@@ -1067,16 +1118,16 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
     const real fl = sub < NL ? lm.floss[sub] : m->cube_frictionloss;
     if (fl > 0) {
       const real imp = lm.imp0[0];
-      cr.fl = fl; cr.Rf = fmax(MJ_MINVAL, (1 - imp) / imp * Ad); cr.Df = 1.0 / cr.Rf; cr.areff = -bb * qv;
+      cr.fl = fl; cr.Rf = fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad); cr.Df = frcp(cr.Rf); cr.areff = -bb * qv;
     }
     if (sub < NL) {
       const real dl = w.qpos[sub] - lm.range[sub][0], du = lm.range[sub][1] - w.qpos[sub];
       const real pos = dl < 0 ? dl : du;
       if (pos < 0) {                                       // (lower and upper cannot both be violated: range lo < hi)
-        const real imp = impedance(m->con_def_solimp, pos);
+        const real imp = impedance_c(lm.imp[0], pos);
         cr.sg = dl < 0 ? 1.0 : -1.0;
-        cr.Rl = fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
-        cr.Dl = 1.0 / cr.Rl;
+        cr.Rl = fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad);
+        cr.Dl = frcp(cr.Rl);
         cr.arefl = -bb * (cr.sg * qv) - kk * imp * pos;
       }
     }
@@ -1122,12 +1173,12 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
         for (int k = 0; k < 4; k++) vb[k] = gsum<G>(cr.jb[c][k] * qv);
       }
       const real dist = w.c_dist[c];
-      const real imp = impedance(si, dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
-      (void)sr;
+      const real imp = impedance_c(lm.imp[cube ? 1 : 0], dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
+      (void)sr; (void)si;
       if (sub == 0) {
         ConRec& rc = w.rec[c];
-        rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) / imp * Ad);
-        rc.D = 1.0 / rc.R;
+        rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad);
+        rc.D = frcp(rc.R);
         rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2];
 #pragma unroll
         for (int e = 0; e < 6; e++) rc.f[e] = 0;       // edge forces (the unused edges of a condim-3 pair stay 0)
@@ -1405,7 +1456,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
         if (hi - lo <= 1e-14 * hi) break;               // bracket collapsed to roundoff
       }
       if (it == 50) break;
-      real an = alpha - d1 / d2;
+      real an = alpha - d1 * frcp(d2);
       if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
       alpha = an;
     }
@@ -1480,12 +1531,12 @@ __device__ __forceinline__ void integrate(Ws<NL>& w, const KModelDesc* m, int su
   GSYNC();
   if (sub == 0) {
     real ax[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
-    real ang = dt * normalize3(ax), qr[4], qn[4];
+    real ang = dt * normalize3_fast(ax), qr[4], qn[4];
     real q[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]};
     axis_angle2quat(qr, ax, ang);
-    normalize4(q);
+    normalize4_fast(q);
     qmul(qn, q, qr);
-    normalize4(qn);
+    normalize4_fast(qn);
     w.qpos[NL + 3] = qn[0]; w.qpos[NL + 4] = qn[1]; w.qpos[NL + 5] = qn[2]; w.qpos[NL + 6] = qn[3];
   }
   GSYNC();
@@ -1589,6 +1640,7 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
       get_kb(m, m->con_cube_solref, m->con_cube_solimp, lm.kb[1][0], lm.kb[1][1]);
       lm.imp0[0] = impedance(m->con_def_solimp, 0.0);
       lm.imp0[1] = impedance(m->con_cube_solimp, 0.0);
+      stage_imp(lm.imp[0], m->con_def_solimp); stage_imp(lm.imp[1], m->con_cube_solimp);
       lm.cubew[0] = m->cube_invweight0[0]; lm.cubew[1] = m->cube_invweight0[1];
       lm.scale = 1.0 / (m->meaninertia * (NL + 6));
       for (int c = 0; c < Dim<NL>::NC; c++) {

@@ -12,11 +12,12 @@ names = ["fk", "bias_serial", "collide+rows", "mass+bias_proj", "invert_mass", "
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 n = 4096
 env = env_hip.make("KManipSoloArm", num_envs=n, seed=0, solver=solver)
+import numpy as _np
+env.k_reset(); env.set_state(step=(_np.arange(n) % 64).astype(_np.int32))   # desynchronised episode phases (as bench.py)
 L = env.L
-env.k_reset()
 gen = torch.Generator(device="cuda"); gen.manual_seed(0)
 acts = [(torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1) for _ in range(8)]
-for k in range(16): env.step_flat(acts[k % 8])
+for k in range(80): env.step_flat(acts[k % 8])
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 16)()
 L.kmanip_dbg_prof(buf, 1)
