@@ -28,6 +28,9 @@ struct KHandle_ {
   std::vector<hipEvent_t> ev;   // 3 events per timed step
   bool timing = false;
   int timed_steps = 0;
+  // render target bound to the step (BASELINE config 5: "depth render in the step"): kmanip_step then also renders
+  int step_cam = -1, step_h = 0, step_w = 0;
+  float* step_depth = nullptr;
   bool ik_unfused = false;      // KMANIP_IK_UNFUSED=1: before_step as its own launch (A/B timing only)
   bool ik_serial = false;       // KMANIP_IK_SERIAL=1: one-lane-per-problem IK kernel (A/B and cross-check only)
   std::vector<void*> allocs;
@@ -242,6 +245,8 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
   kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);
   if (tm) { HIPCHK(h, hipEventRecord(ev[2], s)); h->timed_steps++; }
+  if (h->step_depth && nchunk == 1)       // the observation's camera branch (env_sim.py:140-145) of the state just produced
+    kmanip_launch_render_depth(h->dmodel, h->st, h->step_cam, h->step_h, h->step_w, h->step_depth, s);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -261,6 +266,24 @@ int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_
   KM_ENTER(h);
   kmanip_launch_render_depth(h->dmodel, h->st, cam, height, width, depth_dev, (hipStream_t)stream);
   HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint8_t* rgb_dev, void* stream) {
+  if (!h) { g_create_error = "kmanip_render_rgb: null handle"; return -1; }
+  if (!rgb_dev || cam < 0 || cam >= KM_MAX_CAMS || height <= 0 || width <= 0) { h->err = "kmanip_render_rgb: bad arguments"; return -1; }
+  if (!h->desc.cam_present[cam]) { h->err = "kmanip_render_rgb: this model has no such camera"; return -1; }
+  KM_ENTER(h);
+  kmanip_launch_render_rgb(h->dmodel, h->st, cam, height, width, rgb_dev, (hipStream_t)stream);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int kmanip_bind_step_depth(KHandle h, int cam, int height, int width, float* depth_dev) {
+  if (!h) { g_create_error = "kmanip_bind_step_depth: null handle"; return -1; }
+  if (!depth_dev) { h->step_depth = nullptr; h->step_cam = -1; return 0; }
+  if (cam < 0 || cam >= KM_MAX_CAMS || height <= 0 || width <= 0 || !h->desc.cam_present[cam]) { h->err = "kmanip_bind_step_depth: bad camera / size"; return -1; }
+  h->step_cam = cam; h->step_h = height; h->step_w = width; h->step_depth = depth_dev;
   return 0;
 }
 

@@ -269,4 +269,6 @@ void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDe
                          int use_done_bits, double* obs, hipStream_t stream);
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
                                 hipStream_t stream);
+void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, uint8_t* rgb,
+                              hipStream_t stream);
 void kmanip_launch_scripted_action(const KDeviceModel* dm, const KDeviceState& st, float* act, hipStream_t stream);

@@ -254,6 +254,17 @@ int kmanip_ik_eval(KHandle h, int arm, int n, const double* qpos, const double* 
  * depth_dev: float[num_envs, height, width] device memory owned by the caller. */
 int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream);
 
+/* The same cameras as uint8 RGB, what dm_control's physics.render(height, width, camera_id) returns for the camera
+ * observations of the *Vision env ids (env_sim.py:140-145; shapes env_base.py:140-146, cameras __init__.py:157-161) and for
+ * KManipEnv.render() (env_base.py:215-217, the `top` camera): rgb_dev uint8[num_envs, height, width, 3], caller-owned
+ * device memory.  Lambert shading of the surrogate scene under the reference's lights (scene.xml:8-13). */
+int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint8_t* rgb_dev, void* stream);
+
+/* BASELINE config 5 ("64x64 gripper-cam depth render in the step"): bind a caller-owned device buffer
+ * float[num_envs, height, width]; every kmanip_step then ends by rendering camera `cam` of the state it produced into it,
+ * on the step's stream (one C call per control step).  depth_dev == NULL unbinds. */
+int kmanip_bind_step_depth(KHandle h, int cam, int height, int width, float* depth_dev);
+
 /* The scripted data-generation policy of reference examples/2_synthetic_data.py:28-41, for every env, on device:
  * act_dev float[num_envs, act_dim] arrives holding action_space.sample() (the caller draws it) and leaves with its
  * eer_pos columns overwritten by the unit vector from the right end-effector site to the cube centre

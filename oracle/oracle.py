@@ -189,6 +189,11 @@ class Oracle:
         self.L.ko_render_depth(C.byref(self.desc), _p(_f64(qpos)), cam, h, w, _p(out, C.c_float))
         return out
 
+    def render_rgb(self, qpos, cam=0, h=40, w=60):
+        out = np.zeros((h, w, 3), dtype=np.uint8)
+        self.L.ko_render_rgb(C.byref(self.desc), _p(_f64(qpos)), cam, h, w, _p(out, C.c_uint8))
+        return out
+
     def scripted_eer_pos(self, qpos):
         o = np.zeros(3)
         self.L.ko_scripted_eer_pos(C.byref(self.desc), _p(_f64(qpos)), _p(o))
