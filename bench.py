@@ -351,12 +351,12 @@ def run_rank(args):
             from gym_kmanip_amd.dist import RewardDoneGather
             gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist)
 
-    depth_buf = torch.empty((n, args.depth, args.depth), dtype=torch.float32, device="cuda") if args.depth else None
+    # BASELINE config 5: the gripper-cam depth render is bound to the step (kmanip_bind_step_depth): every kmanip_step call
+    # ends by rendering the state it produced, on the same stream
+    depth_buf = env.bind_step_depth("grip_r", args.depth, args.depth) if args.depth else None
 
     def one_step():
         w.step()
-        if depth_buf is not None:
-            env.render_depth("grip_r", args.depth, args.depth, out=depth_buf)
         if gather is not None:
             gather.post(env.reward, env.done)
 

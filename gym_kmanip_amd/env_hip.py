@@ -19,7 +19,7 @@ from typing import Optional
 import numpy as np
 
 from . import lib as _libmod
-from .model import (CONTROL_TIMESTEP, ENV_SPECS, KM_ACT_KEYS, CompiledModel, EnvSpec, compile_model)
+from .model import (CAMERAS, CONTROL_TIMESTEP, ENV_SPECS, KM_ACT_KEYS, KM_CAM_INDEX, CompiledModel, EnvSpec, compile_model)
 
 MJCF_TO_ASSET = {"_env_solo_arm.xml": "solo_arm", "_env_dual_arm.xml": "dual_arm", "_env_torso.xml": "torso"}
 
@@ -173,15 +173,56 @@ class KManipEnvHip:
         # kernel itself fills the bound device buffer -- no extra launch, no host synchronisation
         return self.terminated, self.reward, self.discount, self.obs_dict(), self.sim_time
 
+    def _cam_index(self, cam):
+        name = getattr(cam, "name", cam)
+        if name not in KM_CAM_INDEX or not self.cm.desc.cam_present[KM_CAM_INDEX[name]]:
+            have = [n for n, i in KM_CAM_INDEX.items() if self.cm.desc.cam_present[i]]
+            raise _libmod.KManipError("no camera %r in this model; cameras: %s" % (name, ", ".join(have)))
+        return KM_CAM_INDEX[name]
+
     def render_depth(self, cam="grip_r", height: int = 64, width: int = 64, out=None):
         """float32 depth image [num_envs, height, width] (metres along the optical axis) of every env's current state
-        from a gripper camera -- BASELINE.json config 5's observation (camera branch of env_sim.py:140-145)."""
+        -- BASELINE.json config 5's observation (camera branch of env_sim.py:140-145)."""
         torch = _torch()
-        ci = {"grip_r": 0, "grip_l": 1}[getattr(cam, "name", cam)]
+        ci = self._cam_index(cam)
         if out is None:
             out = torch.empty((self.num_envs, height, width), dtype=torch.float32, device=self.device)
+        else:
+            self._check_buf(out, (self.num_envs, height, width), torch.float32, "depth")
         self._check(self.L.kmanip_render_depth(self.h, ci, height, width, C.c_void_p(out.data_ptr()), self._stream()),
                     "kmanip_render_depth")
+        return out
+
+    def render_rgb(self, cam="top", height=None, width=None, out=None):
+        """uint8 RGB image [num_envs, height, width, 3] -- what physics.render(height, width, camera_id) returns in the
+        reference (env_sim.py:141-145,187-188).  Size defaults to the camera's reference resolution (__init__.py:157-161)."""
+        torch = _torch()
+        ci = self._cam_index(cam)
+        spec = CAMERAS[getattr(cam, "name", cam)]
+        height = spec.h if height is None else height
+        width = spec.w if width is None else width
+        if out is None:
+            out = torch.empty((self.num_envs, height, width, 3), dtype=torch.uint8, device=self.device)
+        else:
+            self._check_buf(out, (self.num_envs, height, width, 3), torch.uint8, "rgb")
+        self._check(self.L.kmanip_render_rgb(self.h, ci, height, width, C.c_void_p(out.data_ptr()), self._stream()),
+                    "kmanip_render_rgb")
+        return out
+
+    def bind_step_depth(self, cam="grip_r", height: int = 64, width: int = 64, out=None):
+        """BASELINE config 5: every step_flat / k_step from now on also renders `cam` into the returned buffer
+        (float32 [num_envs, height, width]), in the same C call.  bind_step_depth(None) unbinds."""
+        torch = _torch()
+        if cam is None:
+            self._check(self.L.kmanip_bind_step_depth(self.h, 0, 0, 0, None), "kmanip_bind_step_depth")
+            self.step_depth = None
+            return None
+        if out is None:
+            out = torch.empty((self.num_envs, height, width), dtype=torch.float32, device=self.device)
+        self._check_buf(out, (self.num_envs, height, width), torch.float32, "depth")
+        self._check(self.L.kmanip_bind_step_depth(self.h, self._cam_index(cam), height, width, C.c_void_p(out.data_ptr())),
+                    "kmanip_bind_step_depth")
+        self.step_depth = out                     # keeps the buffer alive while it is bound
         return out
 
     def scripted_action(self, act=None, generator=None):
@@ -194,9 +235,10 @@ class KManipEnvHip:
         self._check(self.L.kmanip_scripted_action(self.h, C.c_void_p(act.data_ptr()), self._stream()), "kmanip_scripted_action")
         return act
 
-    def k_render(self, cam, height: int = 64, width: int = 64):
-        """KManipEnvSim.k_render (env_sim.py:187-188) for the gripper cameras: depth of the surrogate scene."""
-        return self.render_depth(cam, height, width)
+    def k_render(self, cam):
+        """KManipEnvSim.k_render (env_sim.py:187-188): physics.render(cam.h, cam.w, camera_id=cam.name) -> uint8 RGB,
+        for every env ([num_envs, h, w, 3], device tensor).  `cam` is a Cam (model.CAMERAS) or a camera name."""
+        return self.render_rgb(cam)
 
     def k_close(self):
         if getattr(self, "h", None):

@@ -1,12 +1,14 @@
 """Caller side of the seam: a KManipEnv-compatible shell over the HIP backend.
 
 Mirrors reference gym_kmanip/env_base.py:16-267 (constructor kwargs, Dict observation/action spaces with
-the same keys, order, shapes, dtypes and bounds, the `info` dict, reset/step signatures) and the
-TimeLimit(max_episode_steps=64) wrapper that `gym.make` adds (__init__.py:28,247).  `self.env` is chosen
-exactly like env_base.py:192-200 does -- by calling a module-level `new(self)` -- here `env_hip.new`.
+the same keys, order, shapes, dtypes and bounds -- camera Boxes included --, the `info` dict, reset/step/render
+signatures) and the TimeLimit(max_episode_steps=64) wrapper that `gym.make` adds (__init__.py:28,247).  `self.env` is
+chosen exactly like env_base.py:192-200 does -- by calling a module-level `new(self)` -- here `env_hip.new`.
 gymnasium is not installed in the build image, so spaces degrade to duck-typed shims (`contains`, `sample`,
 `shape`, `dtype`, `low`, `high`); when gymnasium is importable its real spaces are used.
 With num_envs == 1 and squeeze=True the return values have the reference's single-env shapes.
+With device_outputs=True nothing crosses PCIe: observations, reward, terminated, truncated are device tensors and the
+step never synchronises (the drop-in path at full speed); the default returns host NumPy like the reference.
 """
 from __future__ import annotations
 
@@ -17,7 +19,7 @@ from typing import Any, Dict
 import numpy as np
 
 from . import env_hip
-from .model import (ENV_SPECS, MAX_EPISODE_STEPS, REWARD_SUCCESS_THRESHOLD, KM_DONE_DIVERGED, EnvSpec)
+from .model import (CAMERAS, ENV_SPECS, MAX_EPISODE_STEPS, REWARD_SUCCESS_THRESHOLD, KM_DONE_DIVERGED, EnvSpec)
 
 OBS_DTYPE = np.float64   # __init__.py:50
 ACT_DTYPE = np.float32   # __init__.py:51
@@ -40,6 +42,8 @@ class Box:
         return x.shape == self.shape and x.dtype == self.dtype and bool(np.all(x >= self.low) and np.all(x <= self.high))
 
     def sample(self):
+        if np.issubdtype(self.dtype, np.integer):
+            return self._rng.integers(self.low, self.high, endpoint=True, dtype=self.dtype)
         return self._rng.uniform(self.low, self.high).astype(self.dtype)
 
     def seed(self, seed=None):
@@ -76,12 +80,14 @@ class KManipEnv:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 30}
 
     def __init__(self, env_id: str = "KManipSoloArm", num_envs: int = 1, device: int = 0, seed: int = 0,
-                 squeeze: bool = False, env_id_offset: int = 0, **overrides):
+                 squeeze: bool = False, env_id_offset: int = 0, device_outputs: bool = False, **overrides):
         spec: EnvSpec = ENV_SPECS[env_id]
         self.env_id = env_id
         self.seed = seed
         self.num_envs = num_envs
         self.squeeze = squeeze and num_envs == 1
+        self.device_outputs = device_outputs
+        assert not (self.squeeze and device_outputs), "squeeze returns host scalars; device_outputs returns device tensors"
         self.step_idx = 0
         self.episode_idx = 0
         # the attributes env_sim.new / env_hip.new read (env_base.py:61-78,110-115)
@@ -94,7 +100,8 @@ class KManipEnv:
         self.ctrl_id_l_grip = spec.ctrl_id_l_grip
         self.obs_list = [o for o in spec.obs_list]
         self.act_list = list(spec.act_list)
-        self.cameras = [o.split("/")[-1] for o in self.obs_list if "camera" in o]
+        # env_base.py:110-113: the Cam records of the "camera/<name>" observation keys
+        self.cameras = [CAMERAS[o.split("/")[-1]] for o in self.obs_list if "camera" in o]
         # observation space, env_base.py:115-147
         od = OrderedDict()
         if "q_pos" in self.obs_list:
@@ -105,6 +112,8 @@ class KManipEnv:
             od["cube_pos"] = _box(-1, 1, (3,), OBS_DTYPE)
         if "cube_orn" in self.obs_list:
             od["cube_orn"] = _box(-1, 1, (4,), OBS_DTYPE)
+        for cam in self.cameras:
+            od[cam.log_name] = _box(cam.low, cam.high, (cam.h, cam.w, 3), cam.dtype)
         self.observation_space = _dict(od)
         # action space, env_base.py:149-190 (insertion order == flat column order)
         ad = OrderedDict()
@@ -130,38 +139,68 @@ class KManipEnv:
             "cameras": self.cameras, "sim": self.sim,
         }
 
-    def _host_obs(self, obs):
+    # ------------------------------------------------------------------ observations
+    def _observation(self, state_obs):
+        """state keys from the backend + one RGB render per camera observation (env_sim.py:140-145), in obs_list order."""
+        obs = OrderedDict((k, v) for k, v in state_obs.items() if k in self.obs_list)
+        for cam in self.cameras:
+            obs[cam.log_name] = self.env.k_render(cam)
+        if self.device_outputs:
+            return obs
         out = OrderedDict()
         for k, v in obs.items():
-            a = v.detach().cpu().numpy().astype(OBS_DTYPE, copy=False)
+            a = v.detach().cpu().numpy()
+            if a.dtype != np.uint8:
+                a = a.astype(OBS_DTYPE, copy=False)
             out[k] = a[0] if self.squeeze else a
         return out
 
+    # ------------------------------------------------------------------ gym API
     def reset(self, seed=None, options=None):
+        """env_base.py:219-239.  reset(seed=s) re-keys the cube-spawn stream and restarts its episode counter, so two resets
+        with the same seed give the same first observation (the reference ignores the seed: its spawn draws from the global
+        NumPy RNG, env_sim.py:34, and its ids are registered nondeterministic=True)."""
+        if seed is not None:
+            self.seed = int(seed)
+            self.env.set_seed(self.seed, restart_episodes=True)
         terminated, reward, _, observation, sim_time = self.env.k_reset()
         self.step_idx = 0
         self.episode_idx += 1
         self.info.update(step=self.step_idx, episode=self.episode_idx, sim_time=sim_time, cpu_time=time.time(),
                          reward=reward, is_success=False, terminated=False)
-        return self._host_obs(observation), self.info
+        return self._observation(observation), self.info
 
     def step(self, action):
+        """env_base.py:241-259 + the TimeLimit wrapper: (observation, reward, terminated, truncated, info)."""
         if self.squeeze and isinstance(action, dict):
             action = {k: np.asarray(v)[None] for k, v in action.items()}
         terminated, reward, _, observation, sim_time = self.env.k_step(action)
         self.step_idx += 1
+        trunc_now = self.step_idx >= MAX_EPISODE_STEPS                              # TimeLimit wrapper
+        if self.device_outputs:
+            torch = env_hip._torch()
+            trunc = torch.full((self.num_envs,), trunc_now, dtype=torch.bool, device=reward.device)
+            self.info.update(step=self.step_idx, episode=self.episode_idx, sim_time=sim_time, cpu_time=time.time(),
+                             reward=reward, is_success=reward > REWARD_SUCCESS_THRESHOLD, terminated=terminated,
+                             diverged=(self.env.done & KM_DONE_DIVERGED) != 0)
+            return self._observation(observation), reward, terminated, trunc, self.info
         r = reward.detach().cpu().numpy()
         term = terminated.cpu().numpy()
-        trunc = np.full(self.num_envs, self.step_idx >= MAX_EPISODE_STEPS)          # TimeLimit wrapper
-        self.info.update(step=self.step_idx, episode=self.episode_idx, sim_time=sim_time, cpu_time=time.time(),
+        trunc = np.full(self.num_envs, trunc_now)
+        self.info.update(step=self.step_idx, episode=self.episode_idx, sim_time=sim_time.cpu().numpy(), cpu_time=time.time(),
                          reward=r, is_success=r > REWARD_SUCCESS_THRESHOLD, terminated=term,
                          diverged=(self.env.done.cpu().numpy() & KM_DONE_DIVERGED) != 0)
         if self.squeeze:
-            return self._host_obs(observation), float(r[0]), bool(term[0]), bool(trunc[0]), self.info
-        return self._host_obs(observation), r, term, trunc, self.info
+            return self._observation(observation), float(r[0]), bool(term[0]), bool(trunc[0]), self.info
+        return self._observation(observation), r, term, trunc, self.info
 
     def render(self):
-        return self.env.k_render("top")
+        """env_base.py:215-217: the `top` camera as uint8 RGB [h, w, 3] ([num_envs, h, w, 3] for a batch)."""
+        img = self.env.k_render(CAMERAS["top"])
+        if self.device_outputs:
+            return img
+        img = img.cpu().numpy()
+        return img[0] if self.squeeze else img
 
     def close(self):
         self.env.k_close()

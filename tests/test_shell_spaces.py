@@ -33,17 +33,22 @@ def stub_backend(monkeypatch):
 def test_spaces_match_reference_declarations(env_id, stub_backend):
     env = gym_shell.KManipEnv(env_id, num_envs=3)
     obs_e, act_e = EXPECT[env_id.replace("Vision", "")]
+    cams_e = {}
     if env_id.endswith("Vision"):
-        # the *Vision ids trade cube_pos / cube_orn for camera images (__init__.py:306-311); the uint8 RGB renders of the
-        # reference's meshes are out of scope, so the shell exposes the proprioceptive keys only
+        # the *Vision ids trade cube_pos / cube_orn for camera images (__init__.py:306-311,366-372,429-435): uint8 RGB Boxes of
+        # the cameras' reference resolutions (env_base.py:140-146; head 480x640, grippers 40x60: __init__.py:157-161)
         obs_e = dict(q_pos=obs_e["q_pos"], q_vel=obs_e["q_vel"])
-        assert env.cameras and all(c in ("head", "grip_l", "grip_r") for c in env.cameras)
+        names = ["head", "grip_r"] if "Solo" in env_id else ["head", "grip_l", "grip_r"]
+        cams_e = {"camera/" + n: ((480, 640, 3) if n == "head" else (40, 60, 3)) for n in names}
+        assert [c.name for c in env.cameras] == names and env.info["cameras"] is env.cameras
     obs_s, act_s = env.observation_space.spaces, env.action_space.spaces
-    assert list(obs_s.keys()) == list(obs_e.keys())
+    assert list(obs_s.keys()) == list(obs_e.keys()) + list(cams_e.keys())
     assert list(act_s.keys()) == list(act_e.keys())
     for k, w in obs_e.items():
         assert obs_s[k].shape == (w,) and obs_s[k].dtype == np.float64            # OBS_DTYPE, __init__.py:50
         assert float(obs_s[k].low.min()) == -1.0 and float(obs_s[k].high.max()) == 1.0
+    for k, shp in cams_e.items():
+        assert obs_s[k].shape == shp and obs_s[k].dtype == np.uint8 and int(obs_s[k].low.min()) == 0 and int(obs_s[k].high.max()) == 255
     for k, w in act_e.items():
         assert act_s[k].shape == (w,) and act_s[k].dtype == np.float32            # ACT_DTYPE, __init__.py:51
     # backend seam: the shell asks for no auto-reset (the TimeLimit wrapper owns truncation, as in the reference)
