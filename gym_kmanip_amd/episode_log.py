@@ -2,16 +2,20 @@
 
 The reference writes one `episode_<n>.hdf5` per episode from inside `KManipEnv.step` (gym_kmanip/log_h5py.py:13-61,
 called at env_base.py:231-263): attrs `sim`, group `metadata` (the `info` dict as attrs), float32 datasets
-`observations/qpos [64, q_len]`, `observations/qvel [64, q_len]`, `action [64, a_len]`, group `observations/images`.
+`observations/qpos [64, q_len]`, `observations/qvel [64, q_len]`, `action [64, a_len]`, group `observations/images`
+and, per camera (log_h5py.cam, :36-46), a group `metadata/camera/<name>` with attrs `resolution`, `focal_length`,
+`principal_point` plus a uint8 dataset `observations/images/<name> [64, h, w, 3]` chunked one frame at a time.
 It flushes the file every step of its single env.  Here a whole batch is logged: every step appends the batch's
-observation / action rows to a device-resident ring `[64, num_envs, width]` (no host traffic on the step path); at the
-episode boundary the ring crosses PCIe once and one file per selected env is written with the same internal paths.
+observation / action rows (and the selected envs' camera frames) to device-resident rings (no host traffic on the step
+path); at the episode boundary the rings cross PCIe once and one file per selected env is written with the same
+internal paths.
 
-`h5py` is not installable in the build image, so the writer is chosen at run time: `h5py` when importable (exact
-reference layout), otherwise `.npz` archives whose member names are the HDF5 dataset paths (`observations/qpos`, ...)
-plus a `metadata` JSON member -- the same tree, loadable with numpy alone.  One reference quirk is NOT copied by
-default: log_h5py.py:55 stores `action["grip_r"]` broadcast over the whole action row; `reference_action_quirk=True`
-reproduces that, the default stores the flat action row (Dict-space insertion order, include/kmanip.h).
+`h5py` is not installable in the build image or on the GPU box (profiles/r02_probe_imports.txt), so the writer is chosen
+at run time: `h5py` when importable (the reference's layout, through the same calls log_h5py.py makes), otherwise `.npz`
+archives whose member names are the HDF5 dataset paths (`observations/qpos`, ...) plus a `metadata` JSON member -- the
+same tree, loadable with numpy alone.  One reference quirk is NOT copied by default: log_h5py.py:55 stores
+`action["grip_r"]` broadcast over the whole action row; `reference_action_quirk=True` reproduces that, the default stores
+the flat action row (Dict-space insertion order, include/kmanip.h).
 """
 from __future__ import annotations
 
@@ -23,19 +27,83 @@ import numpy as np
 
 from .model import MAX_EPISODE_STEPS
 
-try:  # pragma: no cover - absent in the build image
-    import h5py as _h5py
-except Exception:  # noqa: BLE001
-    _h5py = None
+H5PY_CHUNK_SIZE_BYTES = 1024 ** 2 * 2          # gym_kmanip/__init__.py:216 (rdcc_nbytes of the reference's h5py.File)
+
+
+def _import_h5py():
+    try:
+        import h5py
+        return h5py
+    except Exception:  # noqa: BLE001
+        return None
+
+
+class _H5Tree:
+    """The calls log_h5py.py makes, on an h5py(-compatible) module: File, attrs, create_group, create_dataset."""
+    suffix = ".hdf5"
+
+    def __init__(self, stem, h5):
+        self.path = stem + self.suffix
+        self.f = h5.File(self.path, "w", rdcc_nbytes=H5PY_CHUNK_SIZE_BYTES)
+
+    def root_attr(self, key, value):
+        self.f.attrs[key] = value
+
+    def group_attrs(self, path, attrs):
+        g = self.f.create_group(path)
+        for k, v in attrs.items():
+            try:
+                g.attrs[k] = v
+            except TypeError:                      # log_h5py.py:22-23: values h5py cannot store are skipped
+                pass
+
+    def group(self, path):
+        self.f.create_group(path)
+
+    def dataset(self, path, data, chunks=None):
+        kw = {"chunks": chunks} if chunks is not None else {}
+        self.f.create_dataset(path, data=data, **kw)
+
+    def close(self):
+        self.f.close()
+        return self.path
+
+
+class _NpzTree:
+    """Same tree as members of one .npz: dataset paths are member names, groups' attrs go into a `metadata` JSON member."""
+    suffix = ".npz"
+
+    def __init__(self, stem, _unused=None):
+        self.path = stem + self.suffix
+        self.members, self.meta = {}, {}
+
+    def root_attr(self, key, value):
+        self.meta.setdefault("/", {})[key] = value
+
+    def group_attrs(self, path, attrs):
+        self.meta[path] = dict(attrs)
+
+    def group(self, path):
+        self.meta.setdefault(path, {})
+
+    def dataset(self, path, data, chunks=None):
+        self.members[path.lstrip("/")] = data
+
+    def close(self):
+        flat = dict(self.meta.get("metadata", {}))
+        flat["_groups"] = {k: v for k, v in self.meta.items() if k != "metadata"}
+        np.savez(self.path, **self.members, metadata=np.frombuffer(json.dumps(flat, default=str).encode(), dtype=np.uint8))
+        return self.path
 
 
 class EpisodeLogger:
     def __init__(self, log_dir: str, num_envs: int, q_len: int, a_len: int, device="cpu", env_ids: Optional[Iterable[int]] = None,
                  info: Optional[Dict[str, Any]] = None, grip_r_col: Optional[int] = None,
-                 reference_action_quirk: bool = False, backend: Optional[str] = None):
+                 reference_action_quirk: bool = False, backend: Optional[str] = None, h5py_module=None):
         import torch
         assert os.path.exists(log_dir), f"Directory {log_dir} does not exist"      # log_h5py.py:14
         self.torch = torch
+        self.device = device
         self.log_dir, self.n, self.q_len, self.a_len = log_dir, num_envs, q_len, a_len
         self.env_ids = list(range(num_envs)) if env_ids is None else list(env_ids)
         self.info = dict(info or {})
@@ -43,18 +111,29 @@ class EpisodeLogger:
         self.quirk = reference_action_quirk
         if self.quirk and grip_r_col is None:
             raise ValueError("reference_action_quirk needs the grip_r column of the flat action")
-        self.backend = backend or ("h5py" if _h5py is not None else "npz")
-        if self.backend == "h5py" and _h5py is None:
+        self.h5 = h5py_module or _import_h5py()
+        self.backend = backend or ("h5py" if self.h5 is not None else "npz")
+        if self.backend == "h5py" and self.h5 is None:
             raise RuntimeError("h5py is not importable here; use backend='npz'")
         T = MAX_EPISODE_STEPS
         self.qpos = torch.zeros((T, num_envs, q_len), dtype=torch.float32, device=device)
         self.qvel = torch.zeros((T, num_envs, q_len), dtype=torch.float32, device=device)
         self.action = torch.zeros((T, num_envs, a_len), dtype=torch.float32, device=device)
+        self.cams = {}                 # name -> (Cam, ring uint8 [T, len(env_ids), h, w, c])
+        self._sel = torch.as_tensor(self.env_ids, dtype=torch.long, device=device)
         self.t = 0
         self.episode = 0
 
-    def step(self, act_flat, obs_q_pos, obs_q_vel) -> None:
-        """Append one control step (log_h5py.step): device-to-device copies only."""
+    def cam(self, cam) -> None:
+        """log_h5py.cam (:36-46): register a camera -- its metadata group and a uint8 image dataset per episode.  Frames of
+        the selected envs only are kept (a 480x640 head frame is 0.9 MB per env and step)."""
+        torch = self.torch
+        ring = torch.zeros((MAX_EPISODE_STEPS, len(self.env_ids), cam.h, cam.w, cam.c), dtype=torch.uint8, device=self.device)
+        self.cams[cam.name] = (cam, ring)
+
+    def step(self, act_flat, obs_q_pos, obs_q_vel, images: Optional[Dict[str, Any]] = None) -> None:
+        """Append one control step (log_h5py.step): device-to-device copies only.  `images`: camera name -> uint8
+        [num_envs, h, w, 3] (e.g. KManipEnvHip.render_rgb) for every registered camera."""
         if self.t >= MAX_EPISODE_STEPS:
             raise RuntimeError("episode longer than MAX_EPISODE_STEPS: call end_episode() at the TimeLimit boundary")
         self.qpos[self.t].copy_(obs_q_pos)          # float64 obs -> float32 datasets, as h5py's default dtype does
@@ -63,36 +142,36 @@ class EpisodeLogger:
             self.action[self.t].copy_(act_flat[:, self.grip_r_col:self.grip_r_col + 1].expand(-1, self.a_len))
         else:
             self.action[self.t].copy_(act_flat)
+        for name, (cam, ring) in self.cams.items():
+            if images is None or name not in images and cam.log_name not in images:
+                raise KeyError("no frame for registered camera %r in this step" % name)
+            img = images[name] if name in images else images[cam.log_name]
+            ring[self.t].copy_(img.index_select(0, self._sel))
         self.t += 1
 
     def end_episode(self):
         """Write `episode_<n>_env<e>` files for the selected envs (one PCIe crossing for the whole batch)."""
         self.episode += 1
         qpos = self.qpos.cpu().numpy(); qvel = self.qvel.cpu().numpy(); action = self.action.cpu().numpy()
+        frames = {name: ring.cpu().numpy() for name, (cam, ring) in self.cams.items()}
+        Tree = _H5Tree if self.backend == "h5py" else _NpzTree
         paths = []
-        for e in self.env_ids:
+        for k, e in enumerate(self.env_ids):
             meta = dict(self.info, episode=self.episode, env=e, steps=self.t, q_len=self.q_len, a_len=self.a_len)
-            stem = os.path.join(self.log_dir, "episode_%d_env%d" % (self.episode, e))
-            if self.backend == "h5py":  # pragma: no cover - exercised only where h5py exists
-                f = _h5py.File(stem + ".hdf5", "w")
-                f.attrs["sim"] = bool(meta.get("sim", True))
-                g = f.create_group("metadata")
-                for k, v in meta.items():
-                    try:
-                        g.attrs[k] = v
-                    except TypeError:
-                        pass
-                f.create_group("observations/images")
-                f.create_dataset("observations/qpos", data=qpos[:, e])
-                f.create_dataset("observations/qvel", data=qvel[:, e])
-                f.create_dataset("action", data=action[:, e])
-                f.close()
-                paths.append(stem + ".hdf5")
-            else:
-                np.savez(stem + ".npz", **{"observations/qpos": qpos[:, e], "observations/qvel": qvel[:, e],
-                                           "action": action[:, e],
-                                           "metadata": np.frombuffer(json.dumps(meta, default=str).encode(), dtype=np.uint8)})
-                paths.append(stem + ".npz")
+            tree = Tree(os.path.join(self.log_dir, "episode_%d_env%d" % (self.episode, e)), self.h5)
+            tree.root_attr("sim", bool(meta.get("sim", True)))                       # log_h5py.py:18
+            tree.group_attrs("metadata", meta)                                       # :19-24
+            tree.group("observations/images")                                        # :25
+            tree.dataset("observations/qpos", qpos[:, e])                            # :26-28
+            tree.dataset("observations/qvel", qvel[:, e])
+            tree.dataset("action", action[:, e])
+            for name, (cam, _) in self.cams.items():                                 # log_h5py.cam :36-46
+                tree.group_attrs("metadata/" + cam.log_name, {"resolution": [cam.w, cam.h], "focal_length": cam.fl,
+                                                              "principal_point": list(cam.pp)})
+                tree.dataset("/observations/images/" + cam.name, frames[name][:, k], chunks=(1, cam.h, cam.w, cam.c))
+            paths.append(tree.close())
         self.t = 0
         self.qpos.zero_(); self.qvel.zero_(); self.action.zero_()
+        for _, ring in self.cams.values():
+            ring.zero_()
         return paths

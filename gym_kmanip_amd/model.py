@@ -30,15 +30,17 @@ KM_CAM_INDEX = {"grip_r": 0, "grip_l": 1, "top": 2, "head": 3}
 class Cam:
     """gym_kmanip/__init__.py:143-161: image size / channels / value range of one camera (fl, pp are logging metadata there)."""
 
-    def __init__(self, w, h, name):
+    def __init__(self, w, h, name, fl=0, pp=(0, 0)):
         self.w, self.h, self.c, self.name, self.log_name = w, h, 3, name, "camera/" + name
+        self.fl, self.pp = fl, tuple(pp)
         self.low, self.high, self.dtype = 0, 255, np.uint8
 
     def __repr__(self):
         return "Cam(%s %dx%d)" % (self.name, self.w, self.h)
 
 
-CAMERAS = {"head": Cam(640, 480, "head"), "top": Cam(640, 480, "top"), "grip_r": Cam(60, 40, "grip_r"), "grip_l": Cam(60, 40, "grip_l")}
+CAMERAS = {"head": Cam(640, 480, "head", 448, (320, 240)), "top": Cam(640, 480, "top", 448, (320, 240)),
+           "grip_r": Cam(60, 40, "grip_r", 45, (30, 20)), "grip_l": Cam(60, 40, "grip_l", 45, (30, 20))}
 KM_ACT_KEYS = ["eel_pos", "eel_orn", "eer_pos", "eer_orn", "grip_l", "grip_r", "q_pos_r", "q_pos_l"]
 KM_DONE_TRUNCATED = 1
 KM_DONE_DIVERGED = 2

@@ -138,3 +138,33 @@ def test_depth_render_bound_to_the_step():
     a.step_flat(act)
     assert torch.equal(buf, keep)                          # unbound: the buffer is no longer written
     a.k_close(); b.k_close()
+
+
+def test_episode_logger_with_camera_frames_from_device(tmp_path):
+    """log_h5py.cam / step on the GPU path: the selected envs' gripper-camera frames go from kmanip_render_rgb into the
+    logger's device ring and come back out of the episode file unchanged (npz tree here: h5py is absent on the GPU box)."""
+    import torch
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.episode_log import EpisodeLogger
+    from gym_kmanip_amd.model import CAMERAS, MAX_EPISODE_STEPS
+    n = 8
+    e = env_hip.make("KManipSoloArmVision", num_envs=n, seed=6, auto_reset=False)
+    cm = e.cm
+    lg = EpisodeLogger(str(tmp_path), n, cm.nlink, cm.act_dim, device="cuda", env_ids=[1, 6], info={"sim": True}, backend="npz")
+    cam = CAMERAS["grip_r"]
+    lg.cam(cam)
+    e.k_reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    frames = []
+    sq, sv = cm.obs_slices["q_pos"], cm.obs_slices["q_vel"]
+    for k in range(MAX_EPISODE_STEPS):
+        act = e.scripted_action(generator=gen)
+        e.step_flat(act)
+        img = e.k_render(cam)
+        lg.step(act, e.obs[:, sq], e.obs[:, sv], images={cam.log_name: img})
+        frames.append(img[6].cpu().numpy())
+    z = np.load(lg.end_episode()[1])
+    got = z["observations/images/grip_r"]
+    assert got.shape == (MAX_EPISODE_STEPS, cam.h, cam.w, 3) and got.dtype == np.uint8
+    assert np.array_equal(got, np.stack(frames)) and np.unique(got).size > 3
+    e.k_close()
