@@ -135,7 +135,7 @@ template <int NL> struct CReg {
 
 // ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
 // their own and never feed an output; the shipped library compiles every call away.
-#define KM_NPH 16
+#define KM_NPH 40
 #ifdef KM_PROFILE
 __device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
 #define KM_PROF_BLOCKS 4096
@@ -1400,15 +1400,15 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
   for (int iter = 0; iter < maxit; iter++) {
     real h[NV];
     newton_hessian<NL, G, S>(w, sub, cr, mdiag, qf, ql, qm, h);
-    pf.ph(7);
+    pf.ph(9 + 6 * S);
     // ---- p = -H^-1 grad
     real invd = 1;
     int hbad = 0;
     chol_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, hbad);
     if (hbad && sub == 0) w.bad = 1;
-    pf.ph(8);
+    pf.ph(10 + 6 * S);
     const real p = chol_solve_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, in ? -grad : 0.0);
-    pf.ph(9);
+    pf.ph(11 + 6 * S);
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
     real Mp;
     if constexpr (S == KM_SUB_CUBE) Mp = mdiag * p; else Mp = mass_mul<NL, G>(cr, sub, mdiag, p);
@@ -1450,7 +1450,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
       }
     }
     const real xf = a - cr.areff, xl = cr.sg * a - cr.arefl, yl = cr.sg * p;
-    pf.ph(10);
+    pf.ph(12 + 6 * S);
     real alpha = 0, lo = 0, hi = INFINITY, d1 = 0, d2 = 0, d10 = 0;
     for (int it = 0; it <= 50; it++) {
       real e1 = 0, e2 = 0;
@@ -1471,7 +1471,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
       if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
       alpha = an;
     }
-    pf.ph(11);
+    pf.ph(13 + 6 * S);
     // ---- advance the point and everything linear in it
     a += alpha * p;
     Mr += alpha * Mp;
@@ -1485,7 +1485,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     const real g1 = in ? grad : 0.0;
     const real improvement = scale * (cost - cost_new), gradient = scale * sqrt(gsum<G>(g1 * g1));
     cost = cost_new;
-    pf.ph(12);
+    pf.ph(14 + 6 * S);
     if (improvement < tol || gradient < tol || w.bad) break;
   }
 }
@@ -1509,6 +1509,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   real a_s = 0;
   if (sub < NL) { for (int j = 0; j < NL; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
   else if (sub < NV) a_s = w.tmp[sub] * invm;
+  pf.ph(7);
   const uint32_t act = w.cact;
   const real warm = sub < NV ? w.warm[sub] : 0.0;
   const real mdiag = (sub >= NL && sub < NV) ? 1.0 / invm : 0.0;
@@ -1520,7 +1521,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
   real cl = newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm);
   if (!(gsum<G>(cl) < cs)) { a = a_s; Mr = 0; cl = newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm); }
-  pf.ph(6);
+  pf.ph(8);
   constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSPH) - 1u) << 4;          // finger-cube slots couple arm and cube
   if (act & FC_MASK) {
     newton_loop<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, gsum<G>(cl), grad, qf, ql, qm, pf);
@@ -1739,7 +1740,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   int step_idx = st.step_idx[env], episode = st.episode[env];
   const size_t NE = (size_t)st.num_envs;
   GSYNC();
-  pf.ph(15);
+  pf.ph(29);
   // nchunk control steps per launch (kmanip_step: 1).  With a chunk of pre-supplied actions every wave runs its envs
   // through all of them without meeting the other waves at a launch boundary, so the batch advances at the MEAN wave
   // speed instead of the slowest wave's; the state stays in LDS between the steps of a chunk.
@@ -1763,14 +1764,14 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
       else coop_before_step<6>(dm, reinterpret_cast<CoopLds<6>*>(L), arm, sub % GI, arow, io);
     }
     GSYNC();
-    pf.ph(15);
+    pf.ph(30);
   }
   int bad = 0;
   const int nsub = m->n_sub_steps;
   for (int s = 0; s < nsub; s++) {
     step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm, pf);      // s == 0: products of the pre-IK state (stale mj_step2)
     real a = solve<NL, G, SOLVER>(w, lm, m, sub, 1, cr, invm, pf);
-    pf.ph(14);
+    pf.ph(28);
     int lb = (sub < NV) && (!isfinite(a) || fabs(a) > 1e10);   // mjWARN_BADQACC
     bad = gor<G>(lb) | w.bad;
     if (bad) break;
@@ -1779,7 +1780,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
       GSYNC();
     }
     integrate<NL, G>(w, m, sub, a);
-    pf.ph(13);
+    pf.ph(27);
   }
   if (!bad) {
     int lb = 0;
@@ -1821,8 +1822,10 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (dn && (m->auto_reset || bad)) {
     episode += 1; step_idx = 0;
     GSYNC();
+    pf.ph(31);
     reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
+    pf.ph(32);
   }
   if (sub == 0) { reward[(size_t)kc * NE + env] = rew; done[(size_t)kc * NE + env] = dn; }
   GSYNC();
@@ -1832,7 +1835,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
   }
   store_state<NL, G>(w, st, env, sub);
-  pf.ph(14);
+  pf.ph(31);
   pf.flush();
 }
 

@@ -6,9 +6,11 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("KMANIP_LIB", os.path.join(ROOT, "gym_kmanip_amd", "libkmanip_hip_prof.so"))
 import numpy as np, torch
 from gym_kmanip_amd import env_hip
-names = ["fk", "bias_serial", "collide+rows", "mass+bias_proj", "invert_mass", "build_constraints", "solve:setup/PGS",
-         "newton:H build", "newton:chol", "newton:tri-solve", "newton:ls setup", "newton:ls loop", "newton:eval",
-         "integrate", "tail(reward/obs/store)", "load"]
+NPH = 40
+names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mass", "build_constraints", "solve (PGS)", "newton: a_s",
+         "newton: start evals"] + ["newton %s: %s" % (sb, ph) for sb in ("ALL", "ARM", "CUBE") for ph in ("H build", "chol", "tri-solve", "ls setup", "ls loop", "eval")] + [
+         "integrate", "post-solve (sibling wait)", "load state", "before_step (decode + IK)", "tail (reward/obs/store)", "auto-reset"]
+names += ["-"] * (NPH - len(names))
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 n = 4096
 env = env_hip.make("KManipSoloArm", num_envs=n, seed=0, solver=solver)
@@ -19,7 +21,7 @@ gen = torch.Generator(device="cuda"); gen.manual_seed(0)
 acts = [(torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1) for _ in range(8)]
 for k in range(80): env.step_flat(acts[k % 8])
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * NPH)()
 L.kmanip_dbg_prof(buf, 1)
 steps = 32
 for k in range(steps): env.step_flat(acts[k % 8])
@@ -36,15 +38,15 @@ for nm, x in zip(names, per):
 # ---- per-workgroup, per-lane-group view of the LAST launch: the kernel ends when its slowest wave does, and a wave is as
 # slow as its slowest env in every phase.  Slot 13 ("integrate") of a group also holds its wait for the sibling envs.
 nb = n // 4
-blk = (C.c_ulonglong * (16 * 4 * nb))()
+blk = (C.c_ulonglong * (NPH * 4 * nb))()
 if hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) == 0:
-    B = np.array(list(blk), dtype=np.float64).reshape(nb, 4, 16)
+    B = np.array(list(blk), dtype=np.float64).reshape(nb, 4, NPH)
     tot_b = B[:, 0, :].sum(1)                       # wave lifetime as seen by lane group 0
     order = np.argsort(tot_b)
     print("last launch: wave totals  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
         tot_b.mean(), np.median(tot_b), np.percentile(tot_b, 90), np.percentile(tot_b, 99), tot_b.max()))
-    newton = [7, 8, 9, 10, 11, 12]
-    work = B.copy(); work[:, :, 13] = 0; work[:, :, 14] = 0     # drop the wait / tail slots: a group's OWN work
+    newton = list(range(9, 27))
+    work = B.copy(); work[:, :, 28] = 0; work[:, :, 31] = 0     # drop the wait / tail slots: a group's OWN work
     own = work.sum(2)                                            # [nb, 4]
     slow_g = own.argmax(1)
     slow = order[-10:]
@@ -54,16 +56,3 @@ if hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) ==
     print("  own work of that group: %.0f of the wave's %.0f cycles; Newton phases %.0f" % (
         np.mean([own[wv, slow_g[wv]] for wv in slow]), tot_b[slow].mean(), np.mean([B[wv, slow_g[wv], newton].sum() for wv in slow])))
 
-# ---- IK kernel phases
-names_ik = ["initial eval+grad", "scaling + normal matrix", "trust-region solve", "select_step", "trial eval (res+jac)", "accept/grad", "tail (divergence wait)", "-"]
-bi = (C.c_ulonglong * 8)()
-L.kmanip_dbg_prof_ik(bi, 1)
-for k in range(steps): env.step_flat(acts[k % 8])
-torch.cuda.synchronize()
-L.kmanip_dbg_prof_ik(bi, 0)
-v = np.array(list(bi), dtype=np.float64) / steps / (n * 4 / 64)
-print("IK kernel (serial variant only; run with KMANIP_IK_SERIAL=1): ticks per wave per step %.0f" % v.sum())
-if v.sum() == 0:
-    sys.exit(0)
-for nm, x in zip(names_ik, v):
-    print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / v.sum()))
