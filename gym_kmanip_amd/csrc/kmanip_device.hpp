@@ -114,6 +114,19 @@ __device__ __forceinline__ void sub_quat(real* res, const real* qa, const real* 
   res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
 }
 
+// mju_subQuat that also hands out sin and |cos| of HALF the (wrapped) rotation angle: tan(|res| / 2) = sn / ac exactly, so
+// mjd_subQuat's half / tan(half) needs no tan()
+__device__ __forceinline__ void sub_quat_sc(real* res, const real* qa, const real* qb, real& sn_out, real& ac_out) {
+  real qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]}, qd[4];
+  qmul(qd, qn, qa);
+  real ax[3] = {qd[1], qd[2], qd[3]};
+  real sn = normalize3(ax);
+  real speed = 2 * atan2(sn, qd[0]);
+  if (speed > M_PI) speed -= 2 * M_PI;
+  res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
+  sn_out = sn; ac_out = fabs(qd[0]);
+}
+
 // 1/sqrt(s) to double precision: hardware estimate + two Newton steps (no IEEE sqrt / divide sequences)
 __device__ __forceinline__ real rsqrt_nr(real s) {
   real y = __builtin_amdgcn_rsq(s);
@@ -213,6 +226,35 @@ template <int K0, int N, class F> __device__ __forceinline__ void static_for(F&&
   if constexpr (K0 < N) { f(std::integral_constant<int, K0>{}); static_for<K0 + 1, N>(f); }
 }
 #define KM_GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
+// their own and never feed an output; the shipped library compiles every call away.
+#define KM_NPH 40
+#ifdef KM_PROFILE
+static __device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
+#define KM_PROF_BLOCKS 4096
+static __device__ unsigned long long g_prof_blk[KM_PROF_BLOCKS][4][KM_NPH];   // last launch, per workgroup and lane group (who is slow?)
+struct Prof {
+  unsigned long long t0, acc[KM_NPH];
+  __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void ph(int i) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[i] += t - t0; t0 = t;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void flush() {
+    if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) atomicAdd(&g_prof[i], acc[i]);
+    if ((threadIdx.x & 15) == 0 && blockIdx.x < KM_PROF_BLOCKS) for (int i = 0; i < KM_NPH; i++) g_prof_blk[blockIdx.x][threadIdx.x >> 4][i] = acc[i];
+  }
+};
+#else
+struct Prof {
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void ph(int) {}
+  __device__ __forceinline__ void flush() {}
+};
+#endif
 
 // Philox4x32-10 (Salmon et al. 2011), counter-based RNG for the cube spawn
 __device__ __host__ inline void philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {

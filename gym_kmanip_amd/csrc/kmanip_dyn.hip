@@ -133,27 +133,7 @@ template <int NL> struct CReg {
   real sg, Rl, Dl, arefl;    // limit row         x = sg * a - arefl     (sg = 0: no row); Dl = 1 / Rl
 };
 
-// ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
-// their own and never feed an output; the shipped library compiles every call away.
-#define KM_NPH 40
 #ifdef KM_PROFILE
-__device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
-#define KM_PROF_BLOCKS 4096
-__device__ unsigned long long g_prof_blk[KM_PROF_BLOCKS][4][KM_NPH];   // last launch, per workgroup and lane group (who is slow?)
-struct Prof {
-  unsigned long long t0, acc[KM_NPH];
-  __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
-  __device__ __forceinline__ void ph(int i) {
-    __builtin_amdgcn_sched_barrier(0);
-    unsigned long long t = __builtin_amdgcn_s_memtime();
-    acc[i] += t - t0; t0 = t;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __device__ __forceinline__ void flush() {
-    if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) atomicAdd(&g_prof[i], acc[i]);
-    if ((threadIdx.x & 15) == 0 && blockIdx.x < KM_PROF_BLOCKS) for (int i = 0; i < KM_NPH; i++) g_prof_blk[blockIdx.x][threadIdx.x >> 4][i] = acc[i];
-  }
-};
 #if KM_VAR_NL == 10 && KM_VAR_SOLVER == 1
 extern "C" int kmanip_dbg_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * KM_NPH) != hipSuccess) return -1;
@@ -165,12 +145,6 @@ extern "C" int kmanip_dbg_prof_blocks(unsigned long long* out, int nblocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_blk), sizeof(unsigned long long) * KM_NPH * 4 * nblocks) == hipSuccess ? 0 : -1;
 }
 #endif
-#else
-struct Prof {
-  __device__ __forceinline__ void start() {}
-  __device__ __forceinline__ void ph(int) {}
-  __device__ __forceinline__ void flush() {}
-};
 #endif
 #define GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -1753,15 +1727,16 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
       if (sub == 0) w.bad = 0;
       GSYNC();
     }
-    // ---- KManipTask.before_step: 8 lanes per arm (lanes 0-7 of the group: right arm, 8-15: left arm), the rest idle.
+    // ---- KManipTask.before_step: 8 lanes per arm, one arm per 16-lane DPP row of the group (lanes 0-7 of row 0: right arm;
+    // of row 1, in the two-row groups: left arm), the rest idle.
     // Fused here so that an env whose IK needs many evaluations delays only its own wave, not the whole batch.
-    const int arm = sub / GI;
-    if (arm < KM_MAX_ARMS && (NL > 10 || arm == 0) && m->arm_present[arm]) {
+    const int arm = sub / GS;
+    if (sub % GS < GI && arm < KM_MAX_ARMS && (NL > 10 || arm == 0) && m->arm_present[arm]) {
       LdsIO<NL> io{w, st, env};
       const float* arow = act + ((size_t)kc * NE + env) * m->act_dim;
       CoopLds<7>* L = &w.ik[NL > 10 ? arm : 0];
-      if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, L, arm, sub % GI, arow, io);
-      else coop_before_step<6>(dm, reinterpret_cast<CoopLds<6>*>(L), arm, sub % GI, arow, io);
+      if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, L, arm, sub % GS, arow, io, &pf);
+      else coop_before_step<6>(dm, reinterpret_cast<CoopLds<6>*>(L), arm, sub % GS, arow, io, &pf);
     }
     GSYNC();
     pf.ph(30);

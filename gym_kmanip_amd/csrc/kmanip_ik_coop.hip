@@ -23,13 +23,14 @@ __global__ __launch_bounds__(64) void k_before_step_coop(const KDeviceModel* __r
   __shared__ CoopLds<N> lds[PPB];
   const KModelDesc* m = &dm->d;
   const int NE = st.num_envs;
-  const int slot = threadIdx.x / GI, c = threadIdx.x % GI;
+  const int slot = threadIdx.x / GS, c = threadIdx.x % GS;
   const int prob = blockIdx.x * PPB + slot;
-  if (slot >= PPB || prob >= nprob) return;      // whole group exits together
+  if (c >= GI || slot >= PPB || prob >= nprob) return;      // whole problem exits together (lanes 8..15 of a row stay idle)
   const int env = prob % NE, arm = prob / NE;
   if (!m->arm_present[arm]) return;
   GlobalIO io{st, env};
-  coop_before_step<N>(dm, &lds[slot], arm, c, act + (size_t)env * m->act_dim, io);
+  Prof pf;
+  coop_before_step<N>(dm, &lds[slot], arm, c, act + (size_t)env * m->act_dim, io, &pf);
 }
 
 __global__ void k_prepare_coop(const KDeviceModel* __restrict__ dm, KDeviceState st) {
@@ -53,8 +54,8 @@ void kmanip_launch_ik_coop(const KDeviceModel* dm, const KModelDesc& hd, const K
   if (forced > 0) ppb = forced;
   else while (ppb > 2 && (nprob + ppb - 1) / ppb < 1024) ppb >>= 1;   // 1024 = SIMDs on the chip
 #define KM_IK_LAUNCH(NN, PP) hipLaunchKernelGGL((k_before_step_coop<NN, PP>), dim3((nprob + PP - 1) / PP), dim3(64), 0, stream, dm, st, act, nprob)
-  if (nik == 7) { if (ppb >= 8) KM_IK_LAUNCH(7, 8); else if (ppb >= 4) KM_IK_LAUNCH(7, 4); else KM_IK_LAUNCH(7, 2); }
-  else { if (ppb >= 8) KM_IK_LAUNCH(6, 8); else if (ppb >= 4) KM_IK_LAUNCH(6, 4); else KM_IK_LAUNCH(6, 2); }
+  if (nik == 7) { if (ppb >= 4) KM_IK_LAUNCH(7, 4); else KM_IK_LAUNCH(7, 2); }
+  else { if (ppb >= 4) KM_IK_LAUNCH(6, 4); else KM_IK_LAUNCH(6, 2); }
 #undef KM_IK_LAUNCH
 }
 
@@ -65,12 +66,13 @@ __global__ __launch_bounds__(64) void k_ik_coop_standalone(const KDeviceModel* _
                                                            double* q_out, int32_t* nfev_o, int32_t* status_o) {
   __shared__ CoopLds<N> lds[PPW];
   const KModelDesc* m = &dm->d;
-  const int slot = threadIdx.x / GI, c = threadIdx.x % GI;
+  const int slot = threadIdx.x / GS, c = threadIdx.x % GS;
   const int e = blockIdx.x * PPW + slot;
-  if (e >= n) return;
+  if (c >= GI || e >= n) return;
   double* qp = qpos + (size_t)e * nq;
   CoopCtx<N> P;
-  P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N;
+  Prof pf;
+  P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N; P.pf = &pf;
   coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? qp[q] : 0.0;
@@ -104,12 +106,13 @@ __global__ __launch_bounds__(64) void k_ik_eval_coop(const KDeviceModel* __restr
                                                      const double* goal_pos, const double* goal_quat, double* res, double* jac) {
   __shared__ CoopLds<N> lds[PPW];
   const KModelDesc* m = &dm->d;
-  const int slot = threadIdx.x / GI, c = threadIdx.x % GI;
+  const int slot = threadIdx.x / GS, c = threadIdx.x % GS;
   const int e = blockIdx.x * PPW + slot;
-  if (e >= n) return;
+  if (c >= GI || e >= n) return;
   const double* qp = qpos + (size_t)e * nq;
   CoopCtx<N> P;
-  P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N;
+  Prof pf;
+  P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N; P.pf = &pf;
   coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? qp[q] : 0.0;

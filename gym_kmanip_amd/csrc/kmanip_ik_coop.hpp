@@ -22,7 +22,10 @@
 // control flow and therefore have to be bitwise identical on every lane of a problem.
 
 #define GI 8            // lanes per problem
-#define PPW (64 / GI)   // problems per wave / workgroup
+#define GS 16           // lane stride between problems: ONE problem per 16-lane DPP row (its lanes 0..7), so that a value of
+                        // problem lane K is `row_newbcast:K` -- a single DPP control, foldable into v_fmac_f64_dpp (the 64-bit
+                        // DPP encodings honour no bank_mask, so two problems per row cannot be told apart; measured)
+#define PPW (64 / GS)   // problems per wave / workgroup
 
 // ---- 8-lane group collectives (DPP half-row patterns); results identical in all 8 lanes
 __device__ __forceinline__ real gsum8(real v) {
@@ -47,6 +50,11 @@ __device__ __forceinline__ bool gall8(bool pred) {
   return ((b >> sh) & 0xFFull) == 0xFFull;
 }
 
+// value of lane K (0..7) of this lane's problem on every lane of the problem, registers only (one problem per DPP row)
+template <int K> __device__ __forceinline__ real bcast8(real v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false); }
+// acc += bcast8<K>(x) * t with the broadcast folded into the FMA
+template <int K> __device__ __forceinline__ void fmac_bcast8(real& acc, real x, real t) { fmac_bcast16<K>(acc, x, t); }
+
 // per-problem LDS scratch
 template <int N>
 struct CoopLds {
@@ -68,6 +76,7 @@ struct CoopCtx {
   // this lane's chain link (position c of the root -> site chain): constant rotation / offset in its parent
   real cR[9], cp[3];
   int clen, cslide;           // chain length; 1 if this lane's link is a slide joint
+  Prof* pf;                   // phase stamps of the diagnostic build (no-ops in the product)
 };
 // per-problem constants of lane c (call once per problem, after arm / c / m / ax are set)
 template <int N>
@@ -167,7 +176,8 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
 #pragma unroll
     for (int j = 0; j < 3; j++) smat[3 * i + j] = mat[3 * i] * Rs[j] + mat[3 * i + 1] * Rs[3 + j] + mat[3 * i + 2] * Rs[6 + j];
   mat2quat(cur, smat);
-  sub_quat(rq, P.goal_quat, cur);
+  real sn_h, ac_h;                                     // sin, |cos| of half the orientation error angle
+  sub_quat_sc(rq, P.goal_quat, cur, sn_h, ac_h);
   if (sp_out) { sp_out[0] = sp[0]; sp_out[1] = sp[1]; sp_out[2] = sp[2]; }
   if (smat_out) {
 #pragma unroll
@@ -180,7 +190,7 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
     real axs[3] = {rq[0], rq[1], rq[2]};
     real half = 0.5 * normalize3(axs);
     real K[9] = {0, -axs[2], axs[1], axs[2], 0, -axs[0], -axs[1], axs[0], 0};
-    real coef = 1.0 - (half < 6e-8 ? 1.0 : half / tan(half));
+    real coef = 1.0 - (half < 6e-8 ? 1.0 : half * ac_h / sn_h);      // half / tan(half), tan(half) = sn_h / ac_h
     real Da[9];
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -231,22 +241,24 @@ __device__ __forceinline__ real coop_grad(const CoopCtx<N>& P, real x, const rea
 // redundant-per-lane Cholesky of (A + alpha I) with A read from the problem's LDS copy; L in registers, the
 // diagonal stored INVERTED (L[j][j] = 1 / l_jj) so that the triangular solves multiply instead of divide
 template <int N>
-__device__ __forceinline__ bool chol_reg(const real (*A)[N], real alpha, real (*L)[N]) {
+__device__ __forceinline__ bool chol_reg(const real (&A)[N][N], real alpha, real (*L)[N]) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < N; j++) {
-    real s = A[j][j] + alpha;
+    // (two partial sums: the dependent chain of the inner products is what this redundant per-lane factorisation costs)
+    real s0 = A[j][j] + alpha, s1 = 0;
 #pragma unroll
-    for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+    for (int k = 0; k < j; k++) { if (k & 1) s1 -= L[j][k] * L[j][k]; else s0 -= L[j][k] * L[j][k]; }
+    real s = s0 + s1;
     if (!(s > 0)) { ok = false; s = 1; }
     const real inv = rsqrt_nr(s);
     L[j][j] = inv;
 #pragma unroll
     for (int i = j + 1; i < N; i++) {
-      real t = A[i][j];
+      real t0 = A[i][j], t1 = 0;
 #pragma unroll
-      for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-      L[i][j] = t * inv;
+      for (int k = 0; k < j; k++) { if (k & 1) t1 -= L[i][k] * L[j][k]; else t0 -= L[i][k] * L[j][k]; }
+      L[i][j] = (t0 + t1) * inv;
     }
   }
   return ok;
@@ -277,8 +289,14 @@ template <int N> __device__ __forceinline__ real vdotN(const real* a, const real
 
 // scipy common.py solve_lsq_trust_region on the normal matrix (redundant per lane; full vectors in registers)
 template <int N>
-__device__ __forceinline__ void solve_tr_reg(const real (*A)[N], const real* g_h, real Delta, real& alpha, real* p) {
+__device__ __forceinline__ void solve_tr_reg(const real (*Alds)[N], const real* g_h, real Delta, real& alpha, real* p) {
   real L[N][N], ng[N], w[N];
+  // the normal matrix (lower triangle) once into registers: every factorisation below (up to twelve) reads it
+  real A[N][N];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) A[i][j] = Alds[i][j];
 #pragma unroll
   for (int i = 0; i < N; i++) ng[i] = -g_h[i];
   bool full_rank = chol_reg<N>(A, 0.0, L);
@@ -430,6 +448,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
   const real jreg2 = 2 * P.m->ik_jac_reg * P.m->ik_jac_reg;
   real ft[6], Jc[6], ft_new[6], Jn[6];
   coop_eval<N, true>(P, x, ft, Jc, nullptr, nullptr);
+  P.pf->ph(33);
   int nfev = 1;
   real cost = coop_cost<N>(P, x, ft);
   real g = coop_grad<N>(P, x, ft, Jc);
@@ -450,20 +469,23 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
     if (g_norm < gtol) status = 1;
     if (status != -1 || nfev == max_nfev) break;
     const real d = sqrt(v), diag_h = g * dv, g_h = d * g;
-    // ---- normal matrix row c into LDS: A[c][j] = d_c d_j (J_c . J_j + 2 reg^2 [c==j]) + diag_h [c==j]
-    if (P.on) {
+    // ---- normal matrix row c: A[c][j] = d_c d_j (J_c . J_j + 2 reg^2 [c==j]) + diag_h [c==j].  The other lanes' Jacobian
+    // columns, scalings and gradient components arrive by half-row DPP broadcasts folded into the FMAs (no LDS all-gather,
+    // no synchronisation); only the finished row goes to LDS, from where every lane reads the whole matrix.
+    real d_full[N], gh_full[N], arow[N];
+    static_for<0, N>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      d_full[j] = bcast8<j>(d);
+      gh_full[j] = bcast8<j>(g_h);
+      real s = 0;
 #pragma unroll
-      for (int r = 0; r < 6; r++) P.L->J[r][P.c] = Jc[r];
-    }
-    real d_full[N], gh_full[N];
-    allgather<N>(P.L->v0, P.c, d, d_full);       // (the sync inside also publishes J)
-    allgather<N>(P.L->v1, P.c, g_h, gh_full);
+      for (int r = 0; r < 6; r++) fmac_bcast8<j>(s, Jc[r], Jc[r]);
+      arow[j] = s;
+    });
     if (P.on) {
 #pragma unroll
       for (int j = 0; j < N; j++) {
-        real s = 0;
-#pragma unroll
-        for (int r = 0; r < 6; r++) s += Jc[r] * P.L->J[r][j];
+        real s = arow[j];
         if (j == P.c) s += jreg2;
         s *= d * d_full[j];
         if (j == P.c) s += diag_h;
@@ -471,21 +493,25 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       }
     }
     KM_GSYNC();
+    P.pf->ph(34);
     const real theta = fmax(0.995, 1 - g_norm);
     real actual = -1, x_new = x;
     while (actual <= 0 && nfev < max_nfev) {
       real ph_full[N];
       solve_tr_reg<N>(P.L->A, gh_full, Delta, alpha, ph_full);
+      P.pf->ph(35);
       real ph = 0;
 #pragma unroll
       for (int i = 0; i < N; i++) if (P.c == i) ph = ph_full[i];
       real step_h;
       const real predicted = coop_select_step<N>(P, x, d, ph, g_h, ph_full, gh_full, Delta, theta, step_h);
       if (!P.on) step_h = 0;
+      P.pf->ph(36);
       const real step = d * step_h;
       x_new = P.on ? lane_strictly_feasible(x + step, P.lb, P.ub, 0.0) : x;
       // ik_res(x_new) and, in the same kinematics pass, what ik_jac(x_new) recomputes if the step is accepted
       coop_eval<N, true>(P, x_new, ft_new, Jn, nullptr, nullptr);
+      P.pf->ph(33);
       x_last = x_new;
       nfev++;
       const real shn = sqrt(gsum8(step_h * step_h));
@@ -508,6 +534,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       if (status != -1) break;
       alpha *= Delta / Delta_new;
       Delta = Delta_new;
+      P.pf->ph(37);
     }
     if (actual > 0) {
       x = x_new;
@@ -543,7 +570,7 @@ __device__ __forceinline__ real f32r_c(real x) { return (real)(float)x; }
 // stand-alone kernel, the LDS workspace when fused into k_step):
 //   real IO::qpos(int i); void IO::set_ctrl(int i, real v); void IO::set_qpos_ik(int i, real v); void IO::set_diag(int arm, int nfev, int status)
 template <int N, class IO>
-__device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds<N>* L, int arm, int c, const float* a, IO& io) {
+__device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds<N>* L, int arm, int c, const float* a, IO& io, Prof* pf) {
   const KModelDesc* m = &dm->d;
   const int grip_key[2] = {KM_ACT_GRIP_R, KM_ACT_GRIP_L};
   const int pos_key[2] = {KM_ACT_EER_POS, KM_ACT_EEL_POS};
@@ -560,7 +587,7 @@ __device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds
     io.set_ctrl(g1, (double)g);
   }
   CoopCtx<N> P;
-  P.m = m; P.ax = &dm->x; P.L = L; P.arm = arm; P.c = c; P.on = c < N;
+  P.m = m; P.ax = &dm->x; P.L = L; P.arm = arm; P.c = c; P.on = c < N; P.pf = pf;
   coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? io.qpos(q) : 0.0;

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): which launches of the bench workload are slow, and why.  Replays bench.py's desynchronised workload,
+times every kmanip_step with events and prints, for the slow ones, the IK evaluation counts (kmanip_get_diag) of the batch."""
+import os, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+import torch
+import bench
+
+args = bench.parse_args(["--no-variants", "--no-cpu-baseline"])
+w = bench.Workload(torch, "KManipSoloArm", 4096, 0, 0, 0, "newton", 100, 1234)
+env = w.env
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+for k in range(steps):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); w.step(); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    mask, nfev, st = env.get_diag()
+    if ms > 2.0 or k < 3:
+        j = int(nfev[:, 0].argmax())
+        print("step %3d  %.3f ms  max nfev %d (env %d, status %d)  nfev>100: %d envs  contact mask of that env %s" % (
+            k, ms, nfev[j, 0], j, st[j, 0], int((nfev[:, 0] > 100).sum()), hex(int(mask[j]))))

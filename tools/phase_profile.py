@@ -9,7 +9,8 @@ from gym_kmanip_amd import env_hip
 NPH = 40
 names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mass", "build_constraints", "solve (PGS)", "newton: a_s",
          "newton: start evals"] + ["newton %s: %s" % (sb, ph) for sb in ("ALL", "ARM", "CUBE") for ph in ("H build", "chol", "tri-solve", "ls setup", "ls loop", "eval")] + [
-         "integrate", "post-solve (sibling wait)", "load state", "before_step (decode + IK)", "tail (reward/obs/store)", "auto-reset"]
+         "integrate", "post-solve (sibling wait)", "load state", "before_step (decode + IK)", "tail (reward/obs/store)", "auto-reset",
+         "IK: residual + Jacobian", "IK: normal matrix", "IK: trust-region solve", "IK: select_step", "IK: ratio / radius / tests"]
 names += ["-"] * (NPH - len(names))
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 n = 4096
