@@ -1128,7 +1128,23 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
     cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
     if (((act >> c) & 1u) && sub < NV) {
       const int kind = slot_kind<NL>(c);
-      const int link = kind == 0 ? -1 : m->sphere_link[slot_sphere<NL>(c) < 0 ? 0 : slot_sphere<NL>(c)];
+      if (kind == 0) {
+        // table plane (world) - cube corner: only the cube's six dofs move the point and the frame is the constant plane
+        // frame (rows n = +z, t1 = +y, t2 = -x), so the basis entries are components of the point's velocity columns
+        if (sub >= NL) {
+          const int e = sub - NL;
+          real dl[3] = {e == 0 ? 1.0 : 0.0, e == 1 ? 1.0 : 0.0, e == 2 ? 1.0 : 0.0}, drz = 0;
+          if (e >= 3) {
+            const int k = e - 3;
+            const real col[3] = {w.k.cube_mat[k], w.k.cube_mat[3 + k], w.k.cube_mat[6 + k]};
+            const real r[3] = {w.c_pos[c][0] - w.qpos[NL], w.c_pos[c][1] - w.qpos[NL + 1], w.c_pos[c][2] - w.qpos[NL + 2]};
+            cross3(dl, col, r);
+            drz = col[2];
+          }
+          cr.jb[c][0] = dl[2]; cr.jb[c][1] = dl[1]; cr.jb[c][2] = -dl[0]; cr.jb[c][3] = drz;
+        }
+      } else {
+      const int link = m->sphere_link[slot_sphere<NL>(c) < 0 ? 0 : slot_sphere<NL>(c)];
       const int b1 = kind == 1 ? link : -1, b2 = kind == 2 ? link : NL;
       real pt[3] = {w.c_pos[c][0], w.c_pos[c][1], w.c_pos[c][2]};
       real p1[3], r1[3], p2[3], r2[3];
@@ -1139,6 +1155,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       cr.jb[c][1] = dot3(w.c_frame[c] + 3, dl);
       cr.jb[c][2] = dot3(w.c_frame[c] + 6, dl);
       cr.jb[c][3] = dot3(w.c_frame[c], dr);
+      }
     }
   }
   GSYNC();
@@ -1372,6 +1389,51 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     if (sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
   }
   for (int iter = 0; iter < maxit; iter++) {
+    real p;
+    // The arm problem's quadratic rows are usually just single-dof rows (the two slider friction-loss rows; now and then a
+    // joint at its limit) -- no finger on the table.  Its Hessian is then M + diag(delta) with at most two nonzero deltas, and
+    // this sub-step already holds M^-1: by the Woodbury identity  p = -(y - M^-1[:,S] z),  y = M^-1 grad,
+    // (diag(1/delta_S) + M^-1[S,S]) z = y_S  -- one row-times-vector product and a 2 x 2 solve instead of a 10-pivot
+    // factorisation and two triangular solves.
+    bool plain = false;
+    uint32_t rows = 0;
+    if constexpr (S == KM_SUB_ARM) {
+      bool cq = false;
+      static_for<0, NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (SS::slot(c)) cq = cq || (((act >> c) & 1u) && qm[c] != 0);
+      });
+      const unsigned long long bal = __ballot(in && (qf | ql));
+      rows = (uint32_t)(bal >> ((threadIdx.x & 63) - sub)) & ((G == 32) ? 0xFFFFFFFFu : 0xFFFFu);
+      plain = !cq && __popc(rows) <= 2;
+    }
+    if (plain) {
+      real y = 0;
+      const BSrc<G> gs = bsrc<G>(in ? grad : 0.0);
+      const int row = sub < NL ? sub : 0;
+      static_for<0, NL>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        fmac_b<G, j>(y, gs, w.Minv[row][j]);
+      });
+      real corr = 0;
+      if (rows) {
+        const int i1 = __ffs(rows) - 1, i2 = (rows & (rows - 1)) ? __ffs(rows & (rows - 1)) - 1 : i1;
+        const real dl = (qf ? cr.Df : 0.0) + (ql ? cr.Dl : 0.0);
+        const real y1 = __shfl(y, i1, G), y2 = __shfl(y, i2, G);
+        const real a11 = frcp(__shfl(dl, i1, G)) + w.Minv[i1][i1];
+        real z1, z2 = 0;
+        if (i2 == i1) z1 = y1 * frcp(a11);
+        else {
+          const real a22 = frcp(__shfl(dl, i2, G)) + w.Minv[i2][i2], a12 = w.Minv[i1][i2];
+          const real idet = frcp(a11 * a22 - a12 * a12);
+          z1 = (a22 * y1 - a12 * y2) * idet;
+          z2 = (a11 * y2 - a12 * y1) * idet;
+        }
+        corr = w.Minv[row][i1] * z1 + (i2 == i1 ? 0.0 : w.Minv[row][i2] * z2);
+      }
+      p = in ? -(y - corr) : 0.0;
+      pf.ph(11 + 6 * S);
+    } else {
     real h[NV];
     newton_hessian<NL, G, S>(w, sub, cr, mdiag, qf, ql, qm, h);
     pf.ph(9 + 6 * S);
@@ -1381,8 +1443,9 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     chol_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, hbad);
     if (hbad && sub == 0) w.bad = 1;
     pf.ph(10 + 6 * S);
-    const real p = chol_solve_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, in ? -grad : 0.0);
+    p = chol_solve_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, in ? -grad : 0.0);
     pf.ph(11 + 6 * S);
+    }
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
     real Mp;
     if constexpr (S == KM_SUB_CUBE) Mp = mdiag * p; else Mp = mass_mul<NL, G>(cr, sub, mdiag, p);
