@@ -221,6 +221,56 @@ template <int G, int K> __device__ __forceinline__ void fnmac_b(real& acc, const
   if constexpr (G == 32) { if constexpr (K < 16) fnmac_bcast16<K>(acc, s.e, t); else fnmac_bcast16<K - 16>(acc, s.o, t); }
   else fnmac_bcast16<K>(acc, s.v, t);
 }
+// ---- runs of broadcast-FMAs behind ONE pair of DPP wait states.  Inside a run no instruction writes a register that a later
+// one reads through DPP (accumulators are plain VALU operands), so only the first DPP read can trail a VALU write of its
+// source and need the two wait states; fmac_b / fnmac_b spend them before EVERY instruction.  Same arithmetic, fewer issue slots.
+template <int G, int K> __device__ __forceinline__ real bsel(const BSrc<G>& s) {
+  if constexpr (G == 32) return K < 16 ? s.e : s.o; else return s.v;
+}
+#define KM_DPPF(N, A, X, T, K) "v_fmac_f64_dpp %" #A ", " N "%" #X ", %" #T " row_newbcast:%" #K " row_mask:0xf bank_mask:0xf\n\t"
+// acc_i (-)= bcast_{K_i}(x_i) * t_i, i = 0..3 (four different accumulators)
+template <bool NEG, int K0, int K1, int K2, int K3>
+__device__ __forceinline__ void dppfma4(real& a0, real x0, real t0, real& a1, real x1, real t1, real& a2, real x2, real t2, real& a3, real x3, real t3) {
+  if constexpr (NEG)
+    asm("s_nop 1\n\t" KM_DPPF("-", 0, 4, 8, 12) KM_DPPF("-", 1, 5, 9, 13) KM_DPPF("-", 2, 6, 10, 14) KM_DPPF("-", 3, 7, 11, 15)
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+  else
+    asm("s_nop 1\n\t" KM_DPPF("", 0, 4, 8, 12) KM_DPPF("", 1, 5, 9, 13) KM_DPPF("", 2, 6, 10, 14) KM_DPPF("", 3, 7, 11, 15)
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+}
+template <bool NEG, int K0, int K1>
+__device__ __forceinline__ void dppfma2(real& a0, real x0, real t0, real& a1, real x1, real t1) {
+  if constexpr (NEG)
+    asm("s_nop 1\n\t" KM_DPPF("-", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 7) : "+v"(a0), "+v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+  else
+    asm("s_nop 1\n\t" KM_DPPF("", 0, 2, 4, 6) KM_DPPF("", 1, 3, 5, 7) : "+v"(a0), "+v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+}
+// acc += sum_i bcast_K(x_i) * t_i, i = 0..NS-1 (one accumulator, NS = 3 or 4 sources, one lane K), in this order
+template <int K>
+__device__ __forceinline__ void dppfma_acc4(real& acc, real x0, real t0, real x1, real t1, real x2, real t2, real x3, real t3) {
+  asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 9) KM_DPPF("", 0, 3, 7, 9) KM_DPPF("", 0, 4, 8, 9)
+      : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void dppfma_acc3(real& acc, real x0, real t0, real x1, real t1, real x2, real t2) {
+  asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 4, 7) KM_DPPF("", 0, 2, 5, 7) KM_DPPF("", 0, 3, 6, 7)
+      : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K));
+}
+// a[j] -= bcast_j(src) * t for j in [J0, J1): the row update of a right-looking factorisation, in runs of four / two / one
+template <int G, int J0, int J1, int N>
+__device__ __forceinline__ void fnmac_cols(real (&a)[N], const BSrc<G>& src, real t) {
+  if constexpr (J1 - J0 >= 4) {
+    dppfma4<true, J0 & 15, (J0 + 1) & 15, (J0 + 2) & 15, (J0 + 3) & 15>(a[J0], bsel<G, J0>(src), t, a[J0 + 1], bsel<G, J0 + 1>(src), t,
+                                                                      a[J0 + 2], bsel<G, J0 + 2>(src), t, a[J0 + 3], bsel<G, J0 + 3>(src), t);
+    fnmac_cols<G, J0 + 4, J1>(a, src, t);
+  } else if constexpr (J1 - J0 >= 2) {
+    dppfma2<true, J0 & 15, (J0 + 1) & 15>(a[J0], bsel<G, J0>(src), t, a[J0 + 1], bsel<G, J0 + 1>(src), t);
+    fnmac_cols<G, J0 + 2, J1>(a, src, t);
+  } else if constexpr (J1 - J0 == 1) {
+    fnmac_b<G, J0>(a[J0], src, t);
+  }
+}
+
 // compile-time counted loop: f(std::integral_constant<int, K>) for K in [K0, N)
 template <int K0, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (K0 < N) { f(std::integral_constant<int, K0>{}); static_for<K0 + 1, N>(f); }

@@ -1028,10 +1028,7 @@ __device__ __forceinline__ void chol_rows(real (&h)[N], real& invd, int sub, int
     h[k] = lik;
     if (sub == k) invd = inv;
     const BSrc<G> lsrc = bsrc<G>(lik);
-    static_for<k + 1, D1>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      fnmac_b<G, j>(h[j], lsrc, lik);
-    });
+    fnmac_cols<G, k + 1, D1>(h, lsrc, lik);
   });
 }
 // x = (L L^T)^-1 b, b distributed one component per lane.  Forward substitution is column-oriented (z_k broadcast,
@@ -1258,8 +1255,10 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const C
         const BSrc<G> j0s = bsrc<G>(cr.jb[c][0]), j1s = bsrc<G>(cr.jb[c][1]), j2s = bsrc<G>(cr.jb[c][2]), j3s = bsrc<G>(cr.jb[c][3]);
         static_for<SS::c0(c), SS::c1(c)>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          fmac_b<G, j>(h[j], j0s, t[0]); fmac_b<G, j>(h[j], j1s, t[1]); fmac_b<G, j>(h[j], j2s, t[2]);
-          if constexpr (SS::kind(c) != 2) fmac_b<G, j>(h[j], j3s, t[3]);      // (condim-3 pairs have no torsion row)
+          if constexpr (SS::kind(c) != 2)
+            dppfma_acc4<j & 15>(h[j], bsel<G, j>(j0s), t[0], bsel<G, j>(j1s), t[1], bsel<G, j>(j2s), t[2], bsel<G, j>(j3s), t[3]);
+          else                                                                  // (condim-3 pairs have no torsion row)
+            dppfma_acc3<j & 15>(h[j], bsel<G, j>(j0s), t[0], bsel<G, j>(j1s), t[1], bsel<G, j>(j2s), t[2]);
         });
       }
     }
@@ -1388,6 +1387,25 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     const real g0 = in ? grad : 0.0;
     if (sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
   }
+  // this lane's share of the subset's contact edges (t = sub + G*q), for the whole solve in registers: the friction sign,
+  // regulariser and its reciprocal never change, and x = J a - aref of the current point is advanced with the step
+  // (x += alpha * J p) instead of being rebuilt from the records every iteration.  lR = 0: no row.
+  constexpr int NEQ = (6 * NC + G - 1) / G;
+  real lx[NEQ], ly[NEQ], lR[NEQ], lD[NEQ], lsm[NEQ];
+#pragma unroll
+  for (int q = 0; q < NEQ; q++) {
+    const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
+    lx[q] = 0; ly[q] = 0; lR[q] = 0; lD[q] = 0; lsm[q] = 0;
+    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2);
+    const bool insub = S == KM_SUB_ALL || (S == KM_SUB_ARM ? kind == 2 : kind == 0);
+    const bool valid = c < NC && insub && ((act >> c) & 1u) && !(kind == 2 && e >= 4);
+    if (valid) {
+      const ConRec& rc = w.rec[c];
+      const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+      lx[q] = rc.inv[0] + sm * rc.inv[k] - rc.aref[e];
+      lR[q] = rc.R; lD[q] = rc.D; lsm[q] = sm;
+    }
+  }
   for (int iter = 0; iter < maxit; iter++) {
     real p;
     // The arm problem's quadratic rows are usually just single-dof rows (the two slider friction-loss rows; now and then a
@@ -1468,22 +1486,13 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
       }
     });
     GSYNC();
-    // this lane's share of the subset's contact edges, hoisted into registers: x(alpha) = lx + alpha * ly per row
-    constexpr int NEQ = (6 * NC + G - 1) / G;
-    real lx[NEQ], ly[NEQ], lR[NEQ], lD[NEQ]; // contact edges t = sub + G*q  (lR = 0: no row)
+    // y = J p of this lane's edges from the records
 #pragma unroll
     for (int q = 0; q < NEQ; q++) {
-      const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
-      lx[q] = 0; ly[q] = 0; lR[q] = 0; lD[q] = 0;
-      const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2);
-      const bool insub = S == KM_SUB_ALL || (S == KM_SUB_ARM ? kind == 2 : kind == 0);
-      const bool valid = c < NC && insub && ((act >> c) & 1u) && !(kind == 2 && e >= 4);
-      if (valid) {
+      if (lR[q] != 0) {
+        const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
         const ConRec& rc = w.rec[c];
-        const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
-        lx[q] = rc.inv[0] + sm * rc.inv[k] - rc.aref[e];
-        ly[q] = rc.den[0] + sm * rc.den[k];
-        lR[q] = rc.R; lD[q] = rc.D;
+        ly[q] = rc.den[0] + lsm[q] * rc.den[k];
       }
     }
     const real xf = a - cr.areff, xl = cr.sg * a - cr.arefl, yl = cr.sg * p;
@@ -1512,13 +1521,9 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     // ---- advance the point and everything linear in it
     a += alpha * p;
     Mr += alpha * Mp;
-    if (sub < 4) {
-      static_for<0, NC>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        if constexpr (SS::slot(c)) { if ((act >> c) & 1u) w.rec[c].inv[sub] += alpha * w.rec[c].den[sub]; }
-      });
-    }
     const real cost_new = newton_eval_step<NL, G, S, NEQ>(w, sub, cr, a, a_s, Mr, lx, ly, lR, lD, alpha, grad, qf, ql, qm);
+#pragma unroll
+    for (int q = 0; q < NEQ; q++) lx[q] += alpha * ly[q];
     const real g1 = in ? grad : 0.0;
     const real improvement = scale * (cost - cost_new), gradient = scale * sqrt(gsum<G>(g1 * g1));
     cost = cost_new;

@@ -57,3 +57,13 @@ if hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) ==
     print("  own work of that group: %.0f of the wave's %.0f cycles; Newton phases %.0f" % (
         np.mean([own[wv, slow_g[wv]] for wv in slow]), tot_b[slow].mean(), np.mean([B[wv, slow_g[wv], newton].sum() for wv in slow])))
 
+
+# ---- the slowest waves one by one: which phase classes make them slow (summed over the wave's 4 groups where it is the max)
+if "B" in dir():
+    ik = [30, 33, 34, 35, 36, 37]; allp = list(range(9, 15)); armp = list(range(15, 21)); cubep = list(range(21, 27))
+    fixed = [0, 1, 2, 3, 4, 5, 7, 8, 27]
+    print("slowest waves: total | per-group max of: IK, ALL loop, ARM loop, CUBE loop, fixed per-sub-step work")
+    for wv in order[-16:][::-1]:
+        g = B[wv]
+        print("  wave %4d  %8.0f | IK %7.0f  ALL %7.0f  ARM %7.0f  CUBE %7.0f  fixed %7.0f" % (
+            wv, tot_b[wv], g[:, ik].sum(1).max(), g[:, allp].sum(1).max(), g[:, armp].sum(1).min(), g[:, cubep].sum(1).max(), g[:, fixed].sum(1).max()))
