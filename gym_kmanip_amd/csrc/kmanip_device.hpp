@@ -256,6 +256,25 @@ __device__ __forceinline__ void dppfma_acc3(real& acc, real x0, real t0, real x1
   asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 4, 7) KM_DPPF("", 0, 2, 5, 7) KM_DPPF("", 0, 3, 6, 7)
       : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K));
 }
+// acc += sum_i bcast_{K_i}(x) * t_i, i = 0..3: four lanes of ONE distributed vector against four coefficients (a row-times-
+// vector product), in this order
+template <int K0, int K1, int K2, int K3>
+__device__ __forceinline__ void dppfma_row4(real& acc, real x0, real x1, real x2, real x3, real t0, real t1, real t2, real t3) {
+  asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 10) KM_DPPF("", 0, 3, 7, 11) KM_DPPF("", 0, 4, 8, 12)
+      : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+}
+// acc += sum_{j in [J0, J1)} bcast_j(x) * row(j), row given as a callable (registers or LDS), runs of four then singles
+template <int G, int J0, int J1, class ROW>
+__device__ __forceinline__ void fmac_rowvec(real& acc, const BSrc<G>& x, ROW&& row) {
+  if constexpr (J1 - J0 >= 4) {
+    dppfma_row4<J0 & 15, (J0 + 1) & 15, (J0 + 2) & 15, (J0 + 3) & 15>(acc, bsel<G, J0>(x), bsel<G, J0 + 1>(x), bsel<G, J0 + 2>(x), bsel<G, J0 + 3>(x),
+                                                                  row(J0), row(J0 + 1), row(J0 + 2), row(J0 + 3));
+    fmac_rowvec<G, J0 + 4, J1>(acc, x, row);
+  } else if constexpr (J1 - J0 >= 1) {
+    fmac_b<G, J0>(acc, x, row(J0));
+    fmac_rowvec<G, J0 + 1, J1>(acc, x, row);
+  }
+}
 // a[j] -= bcast_j(src) * t for j in [J0, J1): the row update of a right-looking factorisation, in runs of four / two / one
 template <int G, int J0, int J1, int N>
 __device__ __forceinline__ void fnmac_cols(real (&a)[N], const BSrc<G>& src, real t) {

@@ -477,6 +477,18 @@ __device__ __forceinline__ void bias_project(Ws<NL>& w, const LModel<NL>& lm, in
   }
 }
 
+// upd[j] -= bcast_K(a[j]) * f for j in [J0, J1), j != K (Gauss-Jordan row update), runs of four / singles
+template <int G, int K, int J0, int J1, int N>
+__device__ __forceinline__ void gj_cols(real (&upd)[N], const real (&a)[N], real f) {
+  if constexpr (G == 16 && J1 - J0 >= 4 && !(K >= J0 && K < J0 + 4)) {
+    dppfma4<true, K, K, K, K>(upd[J0], a[J0], f, upd[J0 + 1], a[J0 + 1], f, upd[J0 + 2], a[J0 + 2], f, upd[J0 + 3], a[J0 + 3], f);
+    gj_cols<G, K, J0 + 4, J1>(upd, a, f);
+  } else if constexpr (J1 - J0 >= 1) {
+    if constexpr (J0 != K) fnmac_b<G, K>(upd[J0], bsrc<G>(a[J0]), f);
+    gj_cols<G, K, J0 + 1, J1>(upd, a, f);
+  }
+}
+
 // Minv <- inverse of the SPD joint-space inertia held in Minv.  Lane i takes row i into registers and the
 // group runs an in-place Gauss-Jordan sweep (no pivoting: every pivot of an SPD matrix is a positive Schur
 // complement); row k reaches the other lanes through DPP row broadcasts, so there is no LDS traffic and no
@@ -497,14 +509,15 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
     const real d = frcp(pk);
     const real aik = a[k];
     const bool me = sub == k;
-    static_for<0, NL>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      if constexpr (j != k) {
-        real upd = a[j];
-        fnmac_b<G, k>(upd, bsrc<G>(a[j]), aik * d);      // a_ij - (a_ik / p) a_kj, row k arriving by DPP
-        a[j] = me ? a[j] * d : upd;
-      }
-    });
+    // a_ij - (a_ik / p) a_kj for every column j != k, row k arriving by DPP: all columns of a pivot are independent, so
+    // they go in runs of four behind one pair of wait states
+    real upd[NL];
+    const real f = aik * d;
+#pragma unroll
+    for (int j = 0; j < NL; j++) upd[j] = a[j];
+    gj_cols<G, k, 0, NL>(upd, a, f);
+#pragma unroll
+    for (int j = 0; j < NL; j++) if (j != k) a[j] = me ? a[j] * d : upd[j];
     a[k] = me ? d : -aik * d;
   });
   if (bad && sub == 0) w.bad = 1;
@@ -1204,10 +1217,7 @@ template <int NL, int G>
 __device__ __forceinline__ real mass_mul(const CReg<NL>& cr, int sub, real mdiag, real x) {
   real s = 0;
   const BSrc<G> xs = bsrc<G>(x);
-  static_for<0, NL>([&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    fmac_b<G, j>(s, xs, cr.mrow[j]);
-  });
+  fmac_rowvec<G, 0, NL>(s, xs, [&](int j) { return cr.mrow[j]; });
   return sub < NL ? s : mdiag * x;
 }
 
@@ -1265,56 +1275,74 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const C
   });
 }
 
-// Newton state at the current point: a, Mr = M (a - a_s) (lane components) and, per active contact, the basis
-// projections u_k = J_k a in the record's inv[] slots (group-uniform, LDS), recomputed from a (start points; afterwards
-// they are advanced incrementally, u += alpha * J p, as MuJoCo does).
-// Returns this lane's SHARE of the cost (callers sum the lanes they want: all, the arm's, the cube's -- a contact's cost
-// is booked on a lane of the part it belongs to); sets the lane's gradient component, the quadratic-zone flags of its
-// own rows and the active-edge mask of every contact (computed redundantly by all lanes, so no exchange).
+// Newton state at a start point: a, Mr = M (a - a_s) (lane components).  The basis projections u_k = J_k a of every active
+// contact go into the record's inv[] slots (group-uniform, LDS; afterwards the loops advance x = J a - aref incrementally, as
+// MuJoCo does); then the contact edges are evaluated DISTRIBUTED over the lanes (edge t on lane t % G, like the line search
+// does), the edge forces are exchanged through the records, and every lane builds its gradient component and the
+// active-edge masks from six forces per contact -- instead of every lane evaluating every edge of every contact.
+// c0 / c1: this lane's share of the cost of the arm part (arm dofs, finger contacts) / the cube part (cube dofs, table-cube
+// contacts); callers sum them over the lanes (total = both).
 template <int NL, int G>
-__device__ __forceinline__ real newton_eval(Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
-                                            real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC]) {
-  constexpr int NC = Dim<NL>::NC;
+__device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
+                                            real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC], real& c0, real& c1) {
+  constexpr int NC = Dim<NL>::NC, NV = Dim<NL>::NV;
   const uint32_t act = w.cact;
   real alin[3] = {0, 0, 0}, aangw[3] = {0, 0, 0};
   cube_part<NL, G>(w, a, alin, aangw);
-  real cost = 0.5 * (a - a_s) * Mr;
-  grad = Mr;
-  qf = 0; ql = 0;
-  if (cr.fl > 0) { real f; cost += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
-  if (cr.sg != 0) { real f; cost += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    qm[c] = 0;
     if ((act >> c) & 1u) {
-      const ConRec& rc = w.rec[c];
-      real u[4], F[4] = {0, 0, 0, 0};
+      real u[4];
       if constexpr (slot_kind<NL>(c) == 0) plane_proj<NL>(w, c, alin, aangw, u);
       else {
 #pragma unroll
         for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
       }
       if (sub == 0) { w.rec[c].inv[0] = u[0]; w.rec[c].inv[1] = u[1]; w.rec[c].inv[2] = u[2]; w.rec[c].inv[3] = u[3]; }
-      const real R = rc.R, Dn = rc.D;
-      uint32_t q = 0;
-      real ce = 0;
-#pragma unroll
-      for (int e = 0; e < 6; e++) {
-        if (slot_kind<NL>(c) == 2 && e >= 4) continue;
-        const int k = e / 2 + 1;
-        const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
-        real f; int quad;
-        ce += row_eval(1, u[0] + sm * u[k] - rc.aref[e], R, Dn, 0.0, f, quad);
-        F[0] += f; F[k] += sm * f;
-        q |= (uint32_t)quad << e;
-      }
-      if (sub == (slot_kind<NL>(c) == 0 ? NL : 0)) cost += ce;      // identical on every lane; one lane of its part books it
-      qm[c] = q;
-#pragma unroll
-      for (int k = 0; k < 4; k++) grad -= cr.jb[c][k] * F[k];
     }
   });
-  return cost;
+  GSYNC();
+  c0 = 0; c1 = 0;
+  grad = Mr;
+  qf = 0; ql = 0;
+  {
+    real co = 0.5 * (a - a_s) * Mr;
+    if (cr.fl > 0) { real f; co += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
+    if (cr.sg != 0) { real f; co += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
+    if (sub < NL) c0 = co; else if (sub < NV) c1 = co;
+  }
+  constexpr int NEQ = (6 * NC + G - 1) / G;
+#pragma unroll
+  for (int q = 0; q < NEQ; q++) {
+    const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
+    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2);
+    if (c < NC && ((act >> c) & 1u) && !(kind == 2 && e >= 4)) {
+      const ConRec& rc = w.rec[c];
+      const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+      real f; int quad;
+      const real ce = row_eval(1, rc.inv[0] + sm * rc.inv[k] - rc.aref[e], rc.R, rc.D, 0.0, f, quad);
+      w.rec[c].f[e] = f;
+      if (kind == 0) c1 += ce; else c0 += ce;
+    }
+  }
+  GSYNC();
+  static_for<0, NC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    qm[c] = 0;
+    if ((act >> c) & 1u) {
+      const ConRec& rc = w.rec[c];
+      real f[6];
+#pragma unroll
+      for (int e = 0; e < 6; e++) f[e] = rc.f[e];
+      uint32_t q = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
+      qm[c] = q;
+      const real F0 = ((f[0] + f[1]) + (f[2] + f[3])) + (f[4] + f[5]);
+      const real F1 = rc.mu[0] * (f[0] - f[1]), F2 = rc.mu[1] * (f[2] - f[3]), F3 = rc.mu[2] * (f[4] - f[5]);
+      grad -= cr.jb[c][0] * F0 + cr.jb[c][1] * F1 + cr.jb[c][2] * F2 + cr.jb[c][3] * F3;
+    }
+  });
 }
 
 // The same evaluation after a line-search step, without touching the projections: the contact edges this lane owns
@@ -1429,10 +1457,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
       real y = 0;
       const BSrc<G> gs = bsrc<G>(in ? grad : 0.0);
       const int row = sub < NL ? sub : 0;
-      static_for<0, NL>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        fmac_b<G, j>(y, gs, w.Minv[row][j]);
-      });
+      fmac_rowvec<G, 0, NL>(y, gs, [&](int j) { return w.Minv[row][j]; });
       real corr = 0;
       if (rows) {
         const int i1 = __ffs(rows) - 1, i2 = (rows & (rows - 1)) ? __ffs(rows & (rows - 1)) - 1 : i1;
@@ -1558,18 +1583,25 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   real grad; int qf, ql; uint32_t qm[NC];
   // ---- warm start: the better of qacc_warmstart and qacc_smooth (primal costs of the WHOLE problem, as MuJoCo compares
   // them).  qacc_smooth first, so that in the usual case (the warm start wins) the state left behind is already the start.
-  const real cs = gsum<G>(newton_eval<NL, G>(w, sub, cr, a_s, a_s, 0.0, grad, qf, ql, qm));
+  real c0, c1;
+  newton_eval<NL, G>(w, sub, cr, a_s, a_s, 0.0, grad, qf, ql, qm, c0, c1);
+  const real cs = gsum<G>(c0) + gsum<G>(c1);
   real a = warm;
   real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
-  real cl = newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm);
-  if (!(gsum<G>(cl) < cs)) { a = a_s; Mr = 0; cl = newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm); }
+  newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1);
+  real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
+  if (!(cost0 + cost1 < cs)) {
+    a = a_s; Mr = 0;
+    newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1);
+    cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
+  }
   pf.ph(8);
   constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSPH) - 1u) << 4;          // finger-cube slots couple arm and cube
   if (act & FC_MASK) {
-    newton_loop<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, gsum<G>(cl), grad, qf, ql, qm, pf);
+    newton_loop<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, qm, pf);
   } else {
-    newton_loop<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, gsum<G>(sub < NL ? cl : 0.0), grad, qf, ql, qm, pf);
-    newton_loop<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, gsum<G>(sub >= NL ? cl : 0.0), grad, qf, ql, qm, pf);
+    newton_loop<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, qm, pf);
+    newton_loop<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, qm, pf);
   }
   return a;
 }
