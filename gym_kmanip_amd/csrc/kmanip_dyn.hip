@@ -1275,6 +1275,22 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const C
   });
 }
 
+// the six edge forces of contact slot C on every lane: edge t = 6 C + e was evaluated by lane t % G, which holds its force in
+// lf[t / G] -- one-row groups fetch it with a row broadcast (compile-time lane and register); two-row groups go through the
+// records in LDS (the caller has synchronised)
+template <int NL, int G, int C, int NEQ>
+__device__ __forceinline__ void edge_forces(const ConRec& rc, const real (&lf)[NEQ], real (&f)[6]) {
+  if constexpr (G == 16) {
+    static_for<0, 6>([&](auto ec) {
+      constexpr int e = decltype(ec)::value, t = 6 * C + e;
+      f[e] = gbcast<G, t % G>(lf[t / G]);
+    });
+  } else {
+#pragma unroll
+    for (int e = 0; e < 6; e++) f[e] = rc.f[e];
+  }
+}
+
 // Newton state at a start point: a, Mr = M (a - a_s) (lane components).  The basis projections u_k = J_k a of every active
 // contact go into the record's inv[] slots (group-uniform, LDS; afterwards the loops advance x = J a - aref incrementally, as
 // MuJoCo does); then the contact edges are evaluated DISTRIBUTED over the lanes (edge t on lane t % G, like the line search
@@ -1312,28 +1328,29 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
     if (sub < NL) c0 = co; else if (sub < NV) c1 = co;
   }
   constexpr int NEQ = (6 * NC + G - 1) / G;
+  real lf[NEQ];                             // forces of this lane's edges (one-row groups exchange them by DPP, not LDS)
 #pragma unroll
   for (int q = 0; q < NEQ; q++) {
     const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
     const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2);
+    lf[q] = 0;
     if (c < NC && ((act >> c) & 1u) && !(kind == 2 && e >= 4)) {
       const ConRec& rc = w.rec[c];
       const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
       real f; int quad;
       const real ce = row_eval(1, rc.inv[0] + sm * rc.inv[k] - rc.aref[e], rc.R, rc.D, 0.0, f, quad);
-      w.rec[c].f[e] = f;
+      if constexpr (G == 16) lf[q] = f; else w.rec[c].f[e] = f;
       if (kind == 0) c1 += ce; else c0 += ce;
     }
   }
-  GSYNC();
+  if constexpr (G != 16) GSYNC();
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     qm[c] = 0;
     if ((act >> c) & 1u) {
       const ConRec& rc = w.rec[c];
       real f[6];
-#pragma unroll
-      for (int e = 0; e < 6; e++) f[e] = rc.f[e];
+      edge_forces<NL, G, c>(rc, lf, f);
       uint32_t q = 0;
 #pragma unroll
       for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
@@ -1366,17 +1383,19 @@ __device__ __forceinline__ real newton_eval_step(Ws<NL>& w, int sub, const CReg<
     if (cr.fl > 0) { real f; cost += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
     if (cr.sg != 0) { real f; cost += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
   }
+  real lf[NEQ];
 #pragma unroll
   for (int q = 0; q < NEQ; q++) {
+    lf[q] = 0;
     if (lR[q] != 0) {
       const int t = sub + G * q, c = t / 6, e = t - 6 * c;
       const real x = lx[q] + alpha * ly[q];
       real f; int quad;
       cost += row_eval(1, x, lR[q], lD[q], 0.0, f, quad);
-      w.rec[c].f[e] = f;
+      if constexpr (G == 16) lf[q] = f; else w.rec[c].f[e] = f;
     }
   }
-  GSYNC();
+  if constexpr (G != 16) GSYNC();
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if constexpr (SS::slot(c)) {
@@ -1384,8 +1403,7 @@ __device__ __forceinline__ real newton_eval_step(Ws<NL>& w, int sub, const CReg<
       if ((act >> c) & 1u) {
         const ConRec& rc = w.rec[c];
         real f[6];
-#pragma unroll
-        for (int e = 0; e < 6; e++) f[e] = rc.f[e];
+        edge_forces<NL, G, c>(rc, lf, f);
         uint32_t q = 0;
 #pragma unroll
         for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
