@@ -1300,24 +1300,39 @@ __device__ __forceinline__ void edge_forces(const ConRec& rc, const real (&lf)[N
 // contacts); callers sum them over the lanes (total = both).
 template <int NL, int G>
 __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
-                                            real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC], real& c0, real& c1) {
+                                            real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC], real& c0, real& c1, real* cs = nullptr) {
+  // cs != nullptr: ALSO the cost of the smooth point a_s (this lane's share), in the same pass -- MuJoCo's warm start compares
+  // the two costs; sharing the contact tables' loads, the synchronisations and the slot loop makes the second evaluation
+  // cost a fraction of a stand-alone one.  The projections of a_s are parked in the records' den[] slots (free until the
+  // first line search).
   constexpr int NC = Dim<NL>::NC, NV = Dim<NL>::NV;
   const uint32_t act = w.cact;
-  real alin[3] = {0, 0, 0}, aangw[3] = {0, 0, 0};
+  real alin[3] = {0, 0, 0}, aangw[3] = {0, 0, 0}, slin[3] = {0, 0, 0}, sangw[3] = {0, 0, 0};
   cube_part<NL, G>(w, a, alin, aangw);
+  if (cs) cube_part<NL, G>(w, a_s, slin, sangw);
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if ((act >> c) & 1u) {
-      real u[4];
-      if constexpr (slot_kind<NL>(c) == 0) plane_proj<NL>(w, c, alin, aangw, u);
-      else {
+      real u[4], us[4] = {0, 0, 0, 0};
+      if constexpr (slot_kind<NL>(c) == 0) {
+        plane_proj<NL>(w, c, alin, aangw, u);
+        if (cs) plane_proj<NL>(w, c, slin, sangw, us);
+      } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
+        if (cs) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) us[k] = gsum<G>(cr.jb[c][k] * a_s);
+        }
       }
-      if (sub == 0) { w.rec[c].inv[0] = u[0]; w.rec[c].inv[1] = u[1]; w.rec[c].inv[2] = u[2]; w.rec[c].inv[3] = u[3]; }
+      if (sub == 0) {
+        w.rec[c].inv[0] = u[0]; w.rec[c].inv[1] = u[1]; w.rec[c].inv[2] = u[2]; w.rec[c].inv[3] = u[3];
+        if (cs) { w.rec[c].den[0] = us[0]; w.rec[c].den[1] = us[1]; w.rec[c].den[2] = us[2]; w.rec[c].den[3] = us[3]; }
+      }
     }
   });
   GSYNC();
+  real csl = 0;
   c0 = 0; c1 = 0;
   grad = Mr;
   qf = 0; ql = 0;
@@ -1326,6 +1341,11 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
     if (cr.fl > 0) { real f; co += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
     if (cr.sg != 0) { real f; co += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
     if (sub < NL) c0 = co; else if (sub < NV) c1 = co;
+    if (cs) {                                   // (the Gauss term vanishes at a_s)
+      real f; int qd;
+      if (cr.fl > 0) csl += row_eval(0, a_s - cr.areff, cr.Rf, cr.Df, cr.fl, f, qd);
+      if (cr.sg != 0) csl += row_eval(1, cr.sg * a_s - cr.arefl, cr.Rl, cr.Dl, 0.0, f, qd);
+    }
   }
   constexpr int NEQ = (6 * NC + G - 1) / G;
   real lf[NEQ];                             // forces of this lane's edges (one-row groups exchange them by DPP, not LDS)
@@ -1338,9 +1358,11 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
       const ConRec& rc = w.rec[c];
       const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
       real f; int quad;
-      const real ce = row_eval(1, rc.inv[0] + sm * rc.inv[k] - rc.aref[e], rc.R, rc.D, 0.0, f, quad);
+      const real aref = rc.aref[e], R = rc.R, Dn = rc.D;
+      const real ce = row_eval(1, rc.inv[0] + sm * rc.inv[k] - aref, R, Dn, 0.0, f, quad);
       if constexpr (G == 16) lf[q] = f; else w.rec[c].f[e] = f;
       if (kind == 0) c1 += ce; else c0 += ce;
+      if (cs) { real fs; int qd; csl += row_eval(1, rc.den[0] + sm * rc.den[k] - aref, R, Dn, 0.0, fs, qd); }
     }
   }
   if constexpr (G != 16) GSYNC();
@@ -1360,6 +1382,7 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
       grad -= cr.jb[c][0] * F0 + cr.jb[c][1] * F1 + cr.jb[c][2] * F2 + cr.jb[c][3] * F3;
     }
   });
+  if (cs) *cs = csl;
 }
 
 // The same evaluation after a line-search step, without touching the projections: the contact edges this lane owns
@@ -1601,12 +1624,11 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   real grad; int qf, ql; uint32_t qm[NC];
   // ---- warm start: the better of qacc_warmstart and qacc_smooth (primal costs of the WHOLE problem, as MuJoCo compares
   // them).  qacc_smooth first, so that in the usual case (the warm start wins) the state left behind is already the start.
-  real c0, c1;
-  newton_eval<NL, G>(w, sub, cr, a_s, a_s, 0.0, grad, qf, ql, qm, c0, c1);
-  const real cs = gsum<G>(c0) + gsum<G>(c1);
+  real c0, c1, csl;
   real a = warm;
   real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
-  newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1);
+  newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1, &csl);
+  const real cs = gsum<G>(csl);
   real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
   if (!(cost0 + cost1 < cs)) {
     a = a_s; Mr = 0;
