@@ -359,6 +359,94 @@ __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int
     }
   }
 }
+// One-row groups (NL <= 10, G = 16): composite inertias and subtree wrenches WITHOUT the LDS round trips.  Lane b builds link
+// b's own ten composite numbers in registers, takes its bias wrench, and every lane sums over its descendants with
+// broadcast-FMAs (acc_k += bcast_j(own_k) * [j in subtree(sub)], runs of four behind one pair of wait states): 160 LDS reads,
+// 32 LDS writes and two synchronisations become 40 four-instruction runs.  Then the lane projects ITS composite's unit-
+// acceleration wrench onto its ancestors' joints (column `sub` of M, rows through LDS for the row-per-lane inversion) and its
+// subtree wrench onto its own joint (bias).
+template <int NL, int G>
+__device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+  static_assert(G == 16 && NL <= 16, "one DPP row per env");
+  const bool on = sub < NL;
+  const int b = on ? sub : 0;
+  real own[16];
+  {
+    const real mb = on ? lm.mass[b] : 0.0;
+    const real c[3] = {w.k.cpos[b][0], w.k.cpos[b][1], w.k.cpos[b][2]};
+    const real* R = w.k.xmat[b];
+    const real I0 = lm.inertia[b][0], I1 = lm.inertia[b][1], I2 = lm.inertia[b][2];
+    const real cc = dot3(c, c);
+    own[0] = mb; own[1] = mb * c[0]; own[2] = mb * c[1]; own[3] = mb * c[2];
+    // R diag(I) R^T + m (|c|^2 1 - c c^T), packed xx xy xz yy yz zz
+    own[4] = R[0] * R[0] * I0 + R[1] * R[1] * I1 + R[2] * R[2] * I2 + mb * (cc - c[0] * c[0]);
+    own[5] = R[0] * R[3] * I0 + R[1] * R[4] * I1 + R[2] * R[5] * I2 - mb * c[0] * c[1];
+    own[6] = R[0] * R[6] * I0 + R[1] * R[7] * I1 + R[2] * R[8] * I2 - mb * c[0] * c[2];
+    own[7] = R[3] * R[3] * I0 + R[4] * R[4] * I1 + R[5] * R[5] * I2 + mb * (cc - c[1] * c[1]);
+    own[8] = R[3] * R[6] * I0 + R[4] * R[7] * I1 + R[5] * R[8] * I2 - mb * c[1] * c[2];
+    own[9] = R[6] * R[6] * I0 + R[7] * R[7] * I1 + R[8] * R[8] * I2 + mb * (cc - c[2] * c[2]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) own[10 + k] = w.f.FN[b][k];
+    if (!on) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) own[k] = 0;
+    }
+  }
+  real acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc[k] = 0;
+  const uint32_t dm = on ? lm.desc[sub] : 0u;          // (bit `sub` is set: the link's own contribution)
+  static_for<0, NL>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const real take = ((dm >> j) & 1u) ? 1.0 : 0.0;
+    dppfma4<false, j, j, j, j>(acc[0], own[0], take, acc[1], own[1], take, acc[2], own[2], take, acc[3], own[3], take);
+    dppfma4<false, j, j, j, j>(acc[4], own[4], take, acc[5], own[5], take, acc[6], own[6], take, acc[7], own[7], take);
+    dppfma4<false, j, j, j, j>(acc[8], own[8], take, acc[9], own[9], take, acc[10], own[10], take, acc[11], own[11], take);
+    dppfma4<false, j, j, j, j>(acc[12], own[12], take, acc[13], own[13], take, acc[14], own[14], take, acc[15], own[15], take);
+  });
+  if (on) {
+    const int j = sub;
+    const real* o = acc;
+    const real ax[3] = {w.k.axis[j][0], w.k.axis[j][1], w.k.axis[j][2]};
+    const real oj[3] = {w.k.xpos[j][0], w.k.xpos[j][1], w.k.xpos[j][2]};
+    const real h[3] = {o[1], o[2], o[3]};
+    real F[3], N[3], t[3];
+    const bool slide = lm.jtype[j] == KM_JNT_SLIDE;
+    if (slide) {
+      F[0] = o[0] * ax[0]; F[1] = o[0] * ax[1]; F[2] = o[0] * ax[2];
+      cross3(N, h, ax);
+    } else {
+      real aO[3];
+      cross3(aO, oj, ax);
+      cross3(t, ax, h);
+      F[0] = o[0] * aO[0] + t[0]; F[1] = o[0] * aO[1] + t[1]; F[2] = o[0] * aO[2] + t[2];
+      N[0] = o[4] * ax[0] + o[5] * ax[1] + o[6] * ax[2];
+      N[1] = o[5] * ax[0] + o[7] * ax[1] + o[8] * ax[2];
+      N[2] = o[6] * ax[0] + o[8] * ax[1] + o[9] * ax[2];
+      cross3(t, h, aO);
+      N[0] += t[0]; N[1] += t[1]; N[2] += t[2];
+    }
+    const uint32_t am = lm.anc[j];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const real ai[3] = {w.k.axis[i][0], w.k.axis[i][1], w.k.axis[i][2]};
+      const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
+      cross3(t, oi, F);
+      const real mo[3] = {N[0] - t[0], N[1] - t[1], N[2] - t[2]};
+      const real val = lm.jtype[i] == KM_JNT_SLIDE ? dot3(ai, F) : dot3(ai, mo);
+      w.Minv[i][j] = ((am >> i) & 1u) ? val : 0.0;
+    }
+    // bias_j = axis_j . (subtree wrench about the joint)
+    const real Fb[3] = {acc[10], acc[11], acc[12]};
+    if (slide) w.bias[j] = dot3(ax, Fb);
+    else {
+      cross3(t, oj, Fb);
+      const real mo[3] = {acc[13] - t[0], acc[14] - t[1], acc[15] - t[2]};
+      w.bias[j] = dot3(ax, mo);
+    }
+  }
+}
+
 // lower triangle from the upper one (column j only wrote rows i <= j along its ancestor path)
 template <int NL, int G>
 __device__ __forceinline__ void mass_symmetrize(Ws<NL>& w, int sub) {
@@ -1658,12 +1746,16 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   if constexpr (SOLVER != KM_SOLVER_NEWTON) { if (sub == 0) scalar_rows_serial<NL>(w, lm); }
   GSYNC();
   pf.ph(2);
-  composite_own<NL, G>(w, lm, sub);      // (comp aliases the bias scratch: its last reader is before the barrier above)
-  GSYNC();
-  composite_accumulate<NL, G>(w, lm, sub);
-  GSYNC();
-  mass_matrix<NL, G>(w, lm, sub);
-  bias_project<NL, G>(w, lm, sub);
+  if constexpr (G == 16) {
+    composite_mass_bias_rows<NL, G>(w, lm, sub);
+  } else {
+    composite_own<NL, G>(w, lm, sub);      // (comp aliases the bias scratch: its last reader is before the barrier above)
+    GSYNC();
+    composite_accumulate<NL, G>(w, lm, sub);
+    GSYNC();
+    mass_matrix<NL, G>(w, lm, sub);
+    bias_project<NL, G>(w, lm, sub);
+  }
   GSYNC();
   pf.ph(3);
   invert_mass<NL, G>(w, sub, cr);
