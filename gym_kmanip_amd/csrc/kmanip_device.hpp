@@ -238,6 +238,15 @@ __device__ __forceinline__ void dppfma4(real& a0, real x0, real t0, real& a1, re
     asm("s_nop 1\n\t" KM_DPPF("", 0, 4, 8, 12) KM_DPPF("", 1, 5, 9, 13) KM_DPPF("", 2, 6, 10, 14) KM_DPPF("", 3, 7, 11, 15)
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
 }
+template <bool NEG, int K0, int K1, int K2>
+__device__ __forceinline__ void dppfma3(real& a0, real x0, real t0, real& a1, real x1, real t1, real& a2, real x2, real t2) {
+  if constexpr (NEG)
+    asm("s_nop 1\n\t" KM_DPPF("-", 0, 3, 6, 9) KM_DPPF("-", 1, 4, 7, 10) KM_DPPF("-", 2, 5, 8, 11)
+        : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
+  else
+    asm("s_nop 1\n\t" KM_DPPF("", 0, 3, 6, 9) KM_DPPF("", 1, 4, 7, 10) KM_DPPF("", 2, 5, 8, 11)
+        : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
+}
 template <bool NEG, int K0, int K1>
 __device__ __forceinline__ void dppfma2(real& a0, real x0, real t0, real& a1, real x1, real t1) {
   if constexpr (NEG)

@@ -366,7 +366,7 @@ __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int
 // acceleration wrench onto its ancestors' joints (column `sub` of M, rows through LDS for the row-per-lane inversion) and its
 // subtree wrench onto its own joint (bias).
 template <int NL, int G>
-__device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel<NL>& lm, int sub) {
+__device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel<NL>& lm, int sub, const real (&FN)[6]) {
   static_assert(G == 16 && NL <= 16, "one DPP row per env");
   const bool on = sub < NL;
   const int b = on ? sub : 0;
@@ -386,7 +386,7 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
     own[8] = R[3] * R[6] * I0 + R[4] * R[7] * I1 + R[5] * R[8] * I2 - mb * c[1] * c[2];
     own[9] = R[6] * R[6] * I0 + R[7] * R[7] * I1 + R[8] * R[8] * I2 + mb * (cc - c[2] * c[2]);
 #pragma unroll
-    for (int k = 0; k < 6; k++) own[10 + k] = w.f.FN[b][k];
+    for (int k = 0; k < 6; k++) own[10 + k] = FN[k];
     if (!on) {
 #pragma unroll
       for (int k = 0; k < 16; k++) own[k] = 0;
@@ -545,6 +545,79 @@ __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>
     cross3(t, wv, Iw);
 #pragma unroll
     for (int c = 0; c < 3; c++) { w.bias[NL + c] = -m->cube_mass * m->gravity[c]; w.bias[NL + 3 + c] = t[c]; }
+  }
+}
+
+// One-row groups: the bias-wrench pass with the three ancestor sums as broadcast-FMAs (s += bcast_j(v) * [j in mask], link
+// order = root-to-leaf order) instead of LDS publish / synchronise / read rounds; the link's wrench stays in registers (FN).
+template <int NL, int G>
+__device__ __forceinline__ void anc_sum3(uint32_t mask, const real* v, real* s) {
+  static_for<0, NL>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const real take = ((mask >> j) & 1u) ? 1.0 : 0.0;
+    dppfma3<false, j, j, j>(s[0], v[0], take, s[1], v[1], take, s[2], v[2], take);
+  });
+}
+template <int NL, int G>
+__device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, real (&FN)[6]) {
+  static_assert(G == 16 && NL <= 16, "one DPP row per env");
+  const bool on = sub < NL;
+  const int i = on ? sub : 0;
+  const bool slide = on && lm.jtype[i] == KM_JNT_SLIDE;
+  const uint32_t am = on ? lm.anc[i] : 0u, up = am & ~(1u << i);       // ancestors incl. self / proper ancestors
+  const real qv = on ? w.qvel[i] : 0.0;
+  const real ax[3] = {w.k.axis[i][0] * qv, w.k.axis[i][1] * qv, w.k.axis[i][2] * qv};
+  const real wv[3] = {(slide || !on) ? 0.0 : ax[0], (slide || !on) ? 0.0 : ax[1], (slide || !on) ? 0.0 : ax[2]};
+  real wp[3] = {0, 0, 0}, cz[3], alp[3] = {0, 0, 0};
+  anc_sum3<NL, G>(up, wv, wp);
+  cross3(cz, wp, ax);
+  const real czv[3] = {(slide || !on) ? 0.0 : cz[0], (slide || !on) ? 0.0 : cz[1], (slide || !on) ? 0.0 : cz[2]};
+  anc_sum3<NL, G>(up, czv, alp);
+  const int p = lm.parent[i];
+  real op[3] = {0, 0, 0};
+  if (on && p >= 0) { op[0] = w.k.xpos[p][0]; op[1] = w.k.xpos[p][1]; op[2] = w.k.xpos[p][2]; }
+  const real xo[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
+  real r[3] = {xo[0] - op[0], xo[1] - op[1], xo[2] - op[2]}, t1[3], t2[3], db[3];
+  cross3(t1, alp, r);
+  cross3(t2, wp, r); cross3(t2, wp, t2);
+#pragma unroll
+  for (int c = 0; c < 3; c++) db[c] = on ? t1[c] + t2[c] + (slide ? 2 * cz[c] : 0.0) : 0.0;
+  real ai[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]};
+  anc_sum3<NL, G>(am, db, ai);
+  if (on) {
+    real wi[3] = {wp[0], wp[1], wp[2]}, ali[3] = {alp[0], alp[1], alp[2]};
+    if (!slide) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) { wi[c] += ax[c]; ali[c] += cz[c]; }
+    }
+    const real cpi[3] = {w.k.cpos[i][0], w.k.cpos[i][1], w.k.cpos[i][2]};
+    real cr[3] = {cpi[0] - xo[0], cpi[1] - xo[1], cpi[2] - xo[2]};
+    cross3(t1, ali, cr);
+    cross3(t2, wi, cr); cross3(t2, wi, t2);
+    real wl[3], all[3], Iw[3], nl3[3], nw[3];
+    matT_vec3(wl, w.k.xmat[i], wi);
+    matT_vec3(all, w.k.xmat[i], ali);
+#pragma unroll
+    for (int c = 0; c < 3; c++) Iw[c] = lm.inertia[i][c] * wl[c];
+    cross3(nl3, wl, Iw);
+#pragma unroll
+    for (int c = 0; c < 3; c++) nl3[c] += lm.inertia[i][c] * all[c];
+    mat_vec3(nw, w.k.xmat[i], nl3);
+    real Fi[3] = {lm.mass[i] * (ai[0] + t1[0] + t2[0]), lm.mass[i] * (ai[1] + t1[1] + t2[1]), lm.mass[i] * (ai[2] + t1[2] + t2[2])}, sh[3];
+    cross3(sh, cpi, Fi);                       // shift the moment from the com to the world origin
+#pragma unroll
+    for (int c = 0; c < 3; c++) { FN[c] = Fi[c]; FN[3 + c] = nw[c] + sh[c]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 6; c++) FN[c] = 0;
+    if (sub == NL) {
+      // cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
+      real wc[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
+      real Iw[3] = {m->cube_inertia[0] * wc[0], m->cube_inertia[1] * wc[1], m->cube_inertia[2] * wc[2]}, t[3];
+      cross3(t, wc, Iw);
+#pragma unroll
+      for (int c = 0; c < 3; c++) { w.bias[NL + c] = -m->cube_mass * m->gravity[c]; w.bias[NL + 3 + c] = t[c]; }
+    }
   }
 }
 
@@ -1740,14 +1813,16 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
                                                CReg<NL>& cr, real invm, Prof& pf) {
   fk_parallel<NL, G>(w, lm, sub);
   pf.ph(0);
-  bias_bodies_parallel<NL, G>(w, lm, m, sub);
+  real FN[6];
+  if constexpr (G == 16) bias_bodies_rows<NL, G>(w, lm, m, sub, FN);
+  else bias_bodies_parallel<NL, G>(w, lm, m, sub);
   pf.ph(1);
   collide_parallel<NL, G>(w, m, sub);
   if constexpr (SOLVER != KM_SOLVER_NEWTON) { if (sub == 0) scalar_rows_serial<NL>(w, lm); }
   GSYNC();
   pf.ph(2);
   if constexpr (G == 16) {
-    composite_mass_bias_rows<NL, G>(w, lm, sub);
+    composite_mass_bias_rows<NL, G>(w, lm, sub, FN);
   } else {
     composite_own<NL, G>(w, lm, sub);      // (comp aliases the bias scratch: its last reader is before the barrier above)
     GSYNC();
