@@ -70,6 +70,12 @@ struct LModel {
   struct Imp { real d0, dw, iw, mid, imid, i1mid; int mode; } imp[2];
 };
 
+// friction coefficient k (0, 1: tangential, 2: torsional) of contact slot kind `kind`: pairs with the cube use the mixed cube
+// parameters, finger-table pairs MuJoCo's defaults -- wave-uniform model scalars, not worth a slot in the LDS records
+__device__ __forceinline__ real slot_mu(const KModelDesc* m, int kind, int k) {
+  const real* fr = kind != 2 ? m->con_cube_friction : m->con_def_friction;
+  return k < 2 ? fr[0] : fr[1];
+}
 // Solver view of one pyramidal contact (group-uniform scalars).  Basis index 0 = normal, 1..2 = tangents,
 // 3 = torsion.  Edge e = 2*(k-1) + s uses J_0 + sm J_k with sm = (s ? -mu[k-1] : mu[k-1]).
 struct ConRec {
@@ -1357,9 +1363,10 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
         ConRec& rc = w.rec[c];
         rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad);
         rc.D = frcp(rc.R);
-        rc.mu[0] = mu[0]; rc.mu[1] = mu[1]; rc.mu[2] = mu[2];
+        if constexpr (G != 16) {                       // (one-row groups exchange the edge forces by DPP, not through f[])
 #pragma unroll
-        for (int e = 0; e < 6; e++) rc.f[e] = 0;       // edge forces (the unused edges of a condim-3 pair stay 0)
+          for (int e = 0; e < 6; e++) rc.f[e] = 0;     // edge forces (the unused edges of a condim-3 pair stay 0)
+        }
 #pragma unroll
         for (int e = 0; e < 6; e++) {
           const int k = e / 2 + 1;
@@ -1386,7 +1393,7 @@ __device__ __forceinline__ real mass_mul(const CReg<NL>& cr, int sub, real mdiag
 // rows, plus J^T W J per contact of the subset (active edges from the masks the last evaluation produced).  Lanes outside
 // the subset get a zero row (inert in the factorisation).
 template <int NL, int G, int S>
-__device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const CReg<NL>& cr, real mdiag, int qf, int ql,
+__device__ __forceinline__ void newton_hessian(const Ws<NL>& w, const KModelDesc* m, int sub, const CReg<NL>& cr, real mdiag, int qf, int ql,
                                                const uint32_t (&qm)[Dim<NL>::NC], real (&h)[Dim<NL>::NV]) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   using SS = SubSet<NL, S>;
@@ -1410,7 +1417,8 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, int sub, const C
 #pragma unroll
         for (int e = 0; e < 6; e++) {
           const int k = e / 2 + 1;
-          const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+          const real muk = slot_mu(m, SS::kind(c), k - 1);
+          const real sm = (e & 1) ? -muk : muk;
           const real d = ((qm[c] >> e) & 1u) ? Dn : 0.0;
           W[0][0] += d; W[0][k] += d * sm; W[k][k] += d * sm * sm;
         }
@@ -1460,7 +1468,7 @@ __device__ __forceinline__ void edge_forces(const ConRec& rc, const real (&lf)[N
 // c0 / c1: this lane's share of the cost of the arm part (arm dofs, finger contacts) / the cube part (cube dofs, table-cube
 // contacts); callers sum them over the lanes (total = both).
 template <int NL, int G>
-__device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
+__device__ __forceinline__ void newton_eval(Ws<NL>& w, const KModelDesc* m, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
                                             real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC], real& c0, real& c1, real* cs = nullptr) {
   // cs != nullptr: ALSO the cost of the smooth point a_s (this lane's share), in the same pass -- MuJoCo's warm start compares
   // the two costs; sharing the contact tables' loads, the synchronisations and the slot loop makes the second evaluation
@@ -1517,7 +1525,8 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
     lf[q] = 0;
     if (c < NC && ((act >> c) & 1u) && !(kind == 2 && e >= 4)) {
       const ConRec& rc = w.rec[c];
-      const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+      const real muk = slot_mu(m, kind, k - 1);
+      const real sm = (e & 1) ? -muk : muk;
       real f; int quad;
       const real aref = rc.aref[e], R = rc.R, Dn = rc.D;
       const real ce = row_eval(1, rc.inv[0] + sm * rc.inv[k] - aref, R, Dn, 0.0, f, quad);
@@ -1539,7 +1548,8 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
       for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
       qm[c] = q;
       const real F0 = ((f[0] + f[1]) + (f[2] + f[3])) + (f[4] + f[5]);
-      const real F1 = rc.mu[0] * (f[0] - f[1]), F2 = rc.mu[1] * (f[2] - f[3]), F3 = rc.mu[2] * (f[4] - f[5]);
+      const real F1 = slot_mu(m, slot_kind<NL>(c), 0) * (f[0] - f[1]), F2 = slot_mu(m, slot_kind<NL>(c), 1) * (f[2] - f[3]);
+      const real F3 = slot_mu(m, slot_kind<NL>(c), 2) * (f[4] - f[5]);
       grad -= cr.jb[c][0] * F0 + cr.jb[c][1] * F1 + cr.jb[c][2] * F2 + cr.jb[c][3] * F3;
     }
   });
@@ -1551,7 +1561,7 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, int sub, const CReg<NL>& 
 // records (f[] slots), after which every lane needs only 6 forces + 3 friction coefficients per contact for its
 // gradient component and the active-edge mask.  Restricted to the subset's dofs, rows and slots; returns its cost.
 template <int NL, int G, int S, int NEQ>
-__device__ __forceinline__ real newton_eval_step(Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
+__device__ __forceinline__ real newton_eval_step(Ws<NL>& w, const KModelDesc* m, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
                                                  const real (&lx)[NEQ], const real (&ly)[NEQ], const real (&lR)[NEQ],
                                                  const real (&lD)[NEQ], real alpha, real& grad, int& qf, int& ql,
                                                  uint32_t (&qm)[Dim<NL>::NC]) {
@@ -1593,7 +1603,8 @@ __device__ __forceinline__ real newton_eval_step(Ws<NL>& w, int sub, const CReg<
         for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
         qm[c] = q;
         const real F0 = ((f[0] + f[1]) + (f[2] + f[3])) + (f[4] + f[5]);
-        const real F1 = rc.mu[0] * (f[0] - f[1]), F2 = rc.mu[1] * (f[2] - f[3]), F3 = rc.mu[2] * (f[4] - f[5]);
+        const real F1 = slot_mu(m, slot_kind<NL>(c), 0) * (f[0] - f[1]), F2 = slot_mu(m, slot_kind<NL>(c), 1) * (f[2] - f[3]);
+        const real F3 = slot_mu(m, slot_kind<NL>(c), 2) * (f[4] - f[5]);
         if (in) grad -= cr.jb[c][0] * F0 + cr.jb[c][1] * F1 + cr.jb[c][2] * F2 + cr.jb[c][3] * F3;
       }
     }
@@ -1631,7 +1642,8 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     const bool valid = c < NC && insub && ((act >> c) & 1u) && !(kind == 2 && e >= 4);
     if (valid) {
       const ConRec& rc = w.rec[c];
-      const real sm = (e & 1) ? -rc.mu[k - 1] : rc.mu[k - 1];
+      const real muk = slot_mu(m, kind, k - 1);
+      const real sm = (e & 1) ? -muk : muk;
       lx[q] = rc.inv[0] + sm * rc.inv[k] - rc.aref[e];
       lR[q] = rc.R; lD[q] = rc.D; lsm[q] = sm;
     }
@@ -1680,7 +1692,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
       pf.ph(11 + 6 * S);
     } else {
     real h[NV];
-    newton_hessian<NL, G, S>(w, sub, cr, mdiag, qf, ql, qm, h);
+    newton_hessian<NL, G, S>(w, m, sub, cr, mdiag, qf, ql, qm, h);
     pf.ph(9 + 6 * S);
     // ---- p = -H^-1 grad
     real invd = 1;
@@ -1748,7 +1760,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     // ---- advance the point and everything linear in it
     a += alpha * p;
     Mr += alpha * Mp;
-    const real cost_new = newton_eval_step<NL, G, S, NEQ>(w, sub, cr, a, a_s, Mr, lx, ly, lR, lD, alpha, grad, qf, ql, qm);
+    const real cost_new = newton_eval_step<NL, G, S, NEQ>(w, m, sub, cr, a, a_s, Mr, lx, ly, lR, lD, alpha, grad, qf, ql, qm);
 #pragma unroll
     for (int q = 0; q < NEQ; q++) lx[q] += alpha * ly[q];
     const real g1 = in ? grad : 0.0;
@@ -1788,12 +1800,12 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   real c0, c1, csl;
   real a = warm;
   real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
-  newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1, &csl);
+  newton_eval<NL, G>(w, m, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1, &csl);
   const real cs = gsum<G>(csl);
   real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
   if (!(cost0 + cost1 < cs)) {
     a = a_s; Mr = 0;
-    newton_eval<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1);
+    newton_eval<NL, G>(w, m, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1);
     cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
   }
   pf.ph(8);
