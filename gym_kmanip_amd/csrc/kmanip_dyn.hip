@@ -1341,7 +1341,6 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   cube_part<NL, G>(w, qv, qlin, qangw);
 #pragma unroll
   for (int c = 0; c < NC; c++) {
-    __builtin_amdgcn_sched_barrier(0);
     if ((act >> c) & 1u) {
       const int kind = slot_kind<NL>(c);
       const bool cube = kind != 2;
@@ -1409,7 +1408,6 @@ __device__ __forceinline__ void newton_hessian(const Ws<NL>& w, const KModelDesc
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if constexpr (SS::slot(c)) {
-      __builtin_amdgcn_sched_barrier(0);
       if ((act >> c) & 1u) {
         const ConRec& rc = w.rec[c];
         const real Dn = rc.D;
