@@ -40,8 +40,8 @@ template <int NL> struct Dim {
   static constexpr int NV = NL + 6;
   static constexpr int NQ = NL + 7;
   static constexpr int NS = 2 * NL;               // arm single-dof rows: friction loss (<= nl) + limits (<= nl)
-  static constexpr int NSPH = NL / 5;             // finger spheres (2 solo, 4 dual/torso)
-  static constexpr int NC = 4 + 2 * NSPH;         // contact SLOTS: 4 cube-table corners, NSPH finger-cube, NSPH finger-table
+  static constexpr int NSPH = 3 * (NL / 10);      // collision spheres: two fingers + one hand per arm (3 solo, 6 dual/torso)
+  static constexpr int NC = 4 + 2 * NSPH;         // contact SLOTS: 4 cube-table corners, NSPH sphere-cube, NSPH sphere-table
   static constexpr int NCF = 2 * NSPH;            // slots that involve arm dofs
 };
 // compile-time kind of contact slot c: 0 = table(plane) - cube corner, 1 = finger sphere - cube, 2 = table - finger sphere
@@ -797,7 +797,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
   act = (uint32_t)gor<G>((int)act);
   if (sub == 0) {
     w.cact = act; w.contact_mask = mask;
-    w.touch_fc = (mask & (0xFu << 8)) != 0; w.touch_ct = (mask & 0xFFu) != 0;
+    w.touch_fc = (mask & (0xFFu << 8)) != 0; w.touch_ct = (mask & 0xFFu) != 0;
   }
 }
 
@@ -1186,7 +1186,7 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
 enum { KM_SUB_ALL = 0, KM_SUB_ARM = 1, KM_SUB_CUBE = 2 };
 template <int NL, int S> struct SubSet {
   static constexpr int D0 = S == KM_SUB_CUBE ? NL : 0, D1 = S == KM_SUB_ARM ? NL : NL + 6;
-  static constexpr int kind(int c) { return c < 4 ? 0 : (c < 4 + NL / 5 ? 1 : 2); }
+  static constexpr int kind(int c) { return c < 4 ? 0 : (c < 4 + 3 * (NL / 10) ? 1 : 2); }
   static constexpr bool slot(int c) { return S == KM_SUB_ALL || (S == KM_SUB_ARM ? kind(c) == 2 : kind(c) == 0); }
   // columns of the Hessian a slot of this kind touches (its Jacobian is zero elsewhere), intersected with the subset
   static constexpr int c0(int c) { const int k = kind(c); const int lo = k == 0 ? NL : 0; return lo > D0 ? lo : D0; }

@@ -22,7 +22,7 @@ ASSETS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 KM_MAX_LINKS = 20
 KM_MAX_ARMS = 2
 KM_MAX_IK = 7
-KM_MAX_SPHERES = 4
+KM_MAX_SPHERES = 6
 KM_MAX_CAMS = 4
 KM_CAM_INDEX = {"grip_r": 0, "grip_l": 1, "top": 2, "head": 3}
 

@@ -31,7 +31,7 @@ extern "C" {
 #define KM_MAX_LINKS   20   /* 1-DoF robot links == robot dofs == nu == q_len (10 solo, 20 dual/torso) */
 #define KM_MAX_ARMS    2    /* arm 0 = right ("eer"), arm 1 = left ("eel")                         */
 #define KM_MAX_IK      7    /* IK unknowns per arm (7 solo/dual, 6 torso)                          */
-#define KM_MAX_SPHERES 4    /* finger sphere colliders                                             */
+#define KM_MAX_SPHERES 6    /* sphere colliders: two fingers + one hand (palm) sphere per arm      */
 #define KM_MAX_CAMS    4    /* cameras: 0 = grip_r, 1 = grip_l, 2 = top, 3 = head (__init__.py:157-161) */
 enum { KM_CAM_GRIP_R = 0, KM_CAM_GRIP_L = 1, KM_CAM_TOP = 2, KM_CAM_HEAD = 3 };
 #define KM_NQ_CUBE     7
@@ -53,8 +53,8 @@ enum { KM_SOLVER_PGS = 0, KM_SOLVER_NEWTON = 1 };
 
 /* contact-mask bits (uint32 per env), bit-exact parity target */
 #define KM_CON_CUBE_TABLE(c)   (1u << (c))          /* c = 0..7 cube corner vs table plane (<=4 kept) */
-#define KM_CON_FINGER_CUBE(s)  (1u << (8 + (s)))    /* s = sphere index                               */
-#define KM_CON_FINGER_TABLE(s) (1u << (12 + (s)))
+#define KM_CON_FINGER_CUBE(s)  (1u << (8 + (s)))    /* s = sphere index (fingers first, then hands): sphere vs cube  */
+#define KM_CON_FINGER_TABLE(s) (1u << (16 + (s)))   /* sphere vs table plane                                         */
 
 typedef struct KModelDesc {
   /* ---- sizes */

@@ -99,8 +99,10 @@ def test_reset_matches_initialize_episode():
     # shard-independent: env 44 of a differently sharded oracle == env 4 here
     o2 = Oracle(cm, 1, seed=3, env_id_offset=44); o2.reset()
     assert np.array_equal(o2.get_state()[0][0], qpos[4])
-    # warmstart = unactuated forward acceleration; cube in free fall
-    assert np.allclose(warm[:, nl:nl + 3], [0, 0, -9.81], atol=0.25)
+    # warmstart = unactuated forward acceleration; cube in free fall (the spawn box overlaps the home-pose gripper,
+    # env_sim.py:31-37, so a spawn may start in contact with a finger or hand sphere: those rows are skipped)
+    free = ~np.any(warm[:, nl:nl + 2], axis=1)     # no contact <=> no horizontal acceleration
+    assert free.sum() >= 4 and np.allclose(warm[free, nl:nl + 3], [0, 0, -9.81], atol=0.25)
 
 
 @pytest.mark.parametrize("env", ENVS3)
@@ -200,6 +202,7 @@ def test_oracle_depth_render_geometry():
     for k in range(3):
         d.sphere_pos[0][k] = loc[k]
     d.sphere_radius[0] = 0.004
+    d.nsphere = 2                                                # the hand (palm) sphere sits on the camera -> target line
     cm2 = type(cm)(**{**cm.__dict__, "desc": d})
     img = Oracle(cm2, 1).render_depth(qpos, 0, 65, 65)
     centre = img[32, 32]
@@ -309,7 +312,9 @@ def test_cube_free_fall_and_rest():
         orc.step(act)
     qpos, qvel = orc.get_state()[:2]
     pen = d.table_z + d.cube_half[2] - qpos[:, nl + 2]
+    alone = (orc.get_diag()[0] & 0xFF00) == 0                               # no finger / hand sphere on the cube
+    assert alone.sum() >= 2
     assert (pen > 0).all() and (pen < 1e-3).all()                           # resting: sub-millimetre soft penetration
-    assert np.abs(qvel[:, nl:nl + 6]).max() < 1e-4
+    assert np.abs(qvel[alone, nl:nl + 6]).max() < 1e-4
     straight = np.abs(qpos[:, nl:nl + 2] - qpos0[:, nl:nl + 2]).max(axis=1) < 1e-6
-    assert straight.sum() >= 3                                             # it fell straight down (one spawn may brush the home-pose gripper)
+    assert straight.sum() >= 2                                             # it fell straight down (a spawn may brush the home-pose gripper)

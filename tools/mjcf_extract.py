@@ -121,6 +121,8 @@ MIN_LINK_LEN = 0.04
 HINGE_EXTRA_INERTIA = 0.01
 FINGER_RADIUS = 0.010       # one sphere collider per gripper finger
 FINGER_OPEN_OFFSET = 0.035  # finger centre sits this far (along +slide axis) from the EE site at q=0
+HAND_RADIUS = 0.030         # one sphere collider per hand (the link that carries the finger sliders): the palm, half way
+                            # between that link's origin and the EE site -- the reference's hand meshes collide with table and cube
 TABLE_TOP_Z = 0.5           # table body origin z (scene.xml:14); surrogate = plane z = 0.5
 
 
@@ -290,6 +292,22 @@ def build(env_xml, name):
                         "link": i, "pos": centre.tolist(), "radius": FINGER_RADIUS,
                         "site": sname})
 
+    # ---- surrogate hand colliders: one sphere per hand link (the parent of a pair of finger sliders), after the fingers
+    hands = []
+    for s in list(spheres):
+        par = links[s["link"]]["parent"]
+        if par in hands:
+            continue
+        hands.append(par)
+        st = sites[s["site"]]
+        lk, sp = st["link"], np.array(st["pos"])
+        while lk != par and lk >= 0:                      # EE site in the hand link's frame at zero configuration
+            sp = np.array(links[lk]["pos"]) + qrot(np.array(links[lk]["quat"]), sp)
+            lk = links[lk]["parent"]
+        assert lk == par
+        spheres.append({"name": "hand_" + ("r" if s["name"].endswith("_r") else "l"), "link": par, "pos": (0.5 * sp).tolist(),
+                        "radius": HAND_RADIUS, "site": s["site"]})
+
     spec = {
         "name": name,
         "source": env_xml,
@@ -302,7 +320,7 @@ def build(env_xml, name):
         "table": {"pos": table["pos"], "plane_z": TABLE_TOP_Z},
         "spheres": spheres,
         "option": {"timestep": 0.002, "gravity": [0, 0, -9.81]},
-        "surrogate_note": "link inertials, finger spheres and the table plane are build-owned "
+        "surrogate_note": "link inertials, finger / hand spheres and the table plane are build-owned "
                           "surrogates (reference meshes absent); see tools/mjcf_extract.py",
     }
     return spec
