@@ -69,7 +69,9 @@ struct DevBuf {
 
 static int validate(const KModelDesc* d, std::string& err) {
   if (d->nlink != 10 && d->nlink != 20) { err = "nlink must be 10 or 20 (KManipSoloArm / DualArm / Torso)"; return -1; }
-  if (d->nsphere < 0 || d->nsphere > KM_MAX_SPHERES || d->nsphere > 3 * (d->nlink / 10)) { err = "too many collision spheres (two fingers + one hand per arm)"; return -1; }
+  if (d->nsphere < 0 || d->nsphere > KM_MAX_SPHERES || d->nsphere > 6 * (d->nlink / 10)) { err = "too many collision spheres (at most 6 per 10 links: one collision lane each)"; return -1; }
+  for (int s = 0; s < d->nsphere; s++)
+    if (d->sphere_link[s] < 0 || d->sphere_link[s] >= d->nlink || !(d->sphere_radius[s] > 0)) { err = "collision sphere on a missing link or with radius <= 0"; return -1; }
   if (d->obs_dim != 2 * d->nlink + 7) { err = "obs_dim != 2*nlink+7"; return -1; }
   if (d->n_sub_steps < 1 || d->solver_iterations < 0) { err = "bad n_sub_steps / solver_iterations"; return -1; }
   for (const double* si : {d->con_def_solimp, d->con_cube_solimp}) {

@@ -40,13 +40,14 @@ template <int NL> struct Dim {
   static constexpr int NV = NL + 6;
   static constexpr int NQ = NL + 7;
   static constexpr int NS = 2 * NL;               // arm single-dof rows: friction loss (<= nl) + limits (<= nl)
-  static constexpr int NSPH = 3 * (NL / 10);      // collision spheres: two fingers + one hand per arm (3 solo, 6 dual/torso)
-  static constexpr int NC = 4 + 2 * NSPH;         // contact SLOTS: 4 cube-table corners, NSPH sphere-cube, NSPH sphere-table
-  static constexpr int NCF = 2 * NSPH;            // slots that involve arm dofs
+  static constexpr int NSPH = 6 * (NL / 10);      // collision-sphere CANDIDATES, one lane each: per arm two fingers, palm, three joint housings
+  static constexpr int NSS = KM_SPHERE_SLOTS(NL); // sphere contacts KEPT per kind and sub-step (the first penetrating ones in sphere order)
+  static constexpr int NC = 4 + 2 * NSS;          // contact SLOTS: 4 cube-table corners, NSS sphere-cube, NSS sphere-table
+  static constexpr int NCF = 2 * NSS;             // slots that involve arm dofs
 };
-// compile-time kind of contact slot c: 0 = table(plane) - cube corner, 1 = finger sphere - cube, 2 = table - finger sphere
-template <int NL> __device__ __forceinline__ constexpr int slot_kind(int c) { return c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2); }
-template <int NL> __device__ __forceinline__ constexpr int slot_sphere(int c) { return c < 4 ? -1 : (c < 4 + Dim<NL>::NSPH ? c - 4 : c - 4 - Dim<NL>::NSPH); }
+// compile-time kind of contact slot c: 0 = table(plane) - cube corner, 1 = sphere - cube, 2 = table - sphere.  WHICH sphere sits
+// in a sphere slot is decided per sub-step by collide_parallel (Ws::slot_sph).
+template <int NL> __device__ __forceinline__ constexpr int slot_kind(int c) { return c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2); }
 
 // Per-link model constants staged in LDS once per workgroup (lane-indexed reads stay on-chip); scalars
 // and small fixed arrays are read straight from the global KModelDesc with wave-uniform (scalar) loads.
@@ -62,9 +63,10 @@ struct LModel {
   // stiffness k, damping b (mj_makeImpedance / solref), impedance at zero distance
   real kb[2][2], imp0[2];
   // MuJoCo's qpos0-time constants (mj_setConst): efc_diagApprox of this link's single-dof rows (dof_invweight0), of the
-  // FIRST pyramid edge of every contact slot (tran + mu^2 tran, tran = summed body_invweight0 of the pair), of the cube's
+  // FIRST pyramid edge of every contact pair (tran + mu^2 tran, tran = summed body_invweight0 of the pair: cornerA for a
+  // cube corner on the table, sphA[0][s] for sphere s on the cube, sphA[1][s] for sphere s on the table), of the cube's
   // friction-loss rows (linear, angular), and the solvers' termination scale 1 / (meaninertia * nv)
-  real dofw[NL], slotA[Dim<NL>::NC], cubew[2], scale;
+  real dofw[NL], sphA[2][Dim<NL>::NSPH], cornerA, cubew[2], scale;
   // solimp of the two parameter sets, clamped like mj_makeImpedance clamps it, with the reciprocals the spline divides by
   // (mode 0: constant (d0 + dw) / 2; 1: linear; 2: MuJoCo's default quadratic spline)
   struct Imp { real d0, dw, iw, mid, imid, i1mid; int mode; } imp[2];
@@ -125,6 +127,7 @@ struct Ws {
 #endif
   // contact geometry per slot
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
+  int slot_sph[NC];        // sphere index held by each active sphere slot (4..NC-1)
 };
 
 // this lane's column of every contact basis: J (jb) and M^-1 J^T (bb); compile-time indexed only
@@ -710,12 +713,12 @@ __device__ __forceinline__ void make_frame(real* fr) {
 // contact frame of every contact whose normal is the table normal (+z): mju_makeFrame((0,0,1)) = rows n, t1, t2
 #define KM_PLANE_FRAME {0, 0, 1, 0, 1, 0, -1, 0, 0}
 // narrow phase for the fixed candidate set, written into fixed slots: plane-box (first 4 corners below the
-// table -> slots 0..3 in corner order), sphere-box (slot 4 + s), plane-sphere (slot 4 + NSPH + s).
+// table -> slots 0..3 in corner order), sphere-box (slots 4.., the first NSS penetrating spheres), plane-sphere (slots 4 + NSS..).
 // One candidate per lane: lanes 0..7 test the cube corners (slot = rank among the penetrating corners, from the
-// group's ballot bits), lanes 8..8+NSPH-1 their finger sphere against cube and table.
+// group's ballot bits), lanes 8..8+NSPH-1 their collision sphere against cube and table.
 template <int NL, int G>
 __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub) {
-  constexpr int NSPH = Dim<NL>::NSPH;
+  constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS;
   static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
   const real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
@@ -742,20 +745,21 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     }
   }
   const int nsph = m->nsphere < NSPH ? m->nsphere : NSPH;
+  const int s = sub - 8;
+  bool hitc = false, hitt = false;
+  real ctr[3] = {0, 0, 0}, nloc[3] = {0, 0, 0}, d1 = 0, d2 = 0, rad = 0;
   if (sub >= 8 && sub < 8 + nsph) {
-    const int s = sub - 8;
     const int l = m->sphere_link[s];
-    real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, ctr[3], rel[3], loc[3], cl[3];
+    real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, rel[3], loc[3], cl[3];
     mat_vec3(ctr, w.k.xmat[l], sl);
 #pragma unroll
     for (int a = 0; a < 3; a++) { ctr[a] += w.k.xpos[l][a]; rel[a] = ctr[a] - cp[a]; }
-    const real rad = m->sphere_radius[s];
+    rad = m->sphere_radius[s];
     // sphere (geom1) - cube box (geom2)
     matT_vec3(loc, w.k.cube_mat, rel);
     bool inside = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) { cl[a] = fmin(fmax(loc[a], -m->cube_half[a]), m->cube_half[a]); if (cl[a] != loc[a]) inside = false; }
-    real nloc[3], d1;
     if (!inside) {
       nloc[0] = cl[0] - loc[0]; nloc[1] = cl[1] - loc[1]; nloc[2] = cl[2] - loc[2];
       real dn = normalize3_fast(nloc);
@@ -764,40 +768,47 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
       int best = 0; real bd = INFINITY;
 #pragma unroll
       for (int a = 0; a < 3; a++) { real dd = m->cube_half[a] - fabs(loc[a]); if (dd < bd) { bd = dd; best = a; } }
-      nloc[0] = 0; nloc[1] = 0; nloc[2] = 0;
       real sg = (best == 0 ? loc[0] : (best == 1 ? loc[1] : loc[2])) >= 0 ? -1.0 : 1.0;
       if (best == 0) nloc[0] = sg; else if (best == 1) nloc[1] = sg; else nloc[2] = sg;
       d1 = -bd - rad;
     }
-    if (d1 < 0) {
-      const int n = 4 + s;
-      real fr[9];
-      mat_vec3(fr, w.k.cube_mat, nloc);
-      make_frame(fr);
-#pragma unroll
-      for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
-      w.c_dist[n] = d1;
-#pragma unroll
-      for (int a = 0; a < 3; a++) w.c_pos[n][a] = ctr[a] + fr[a] * (rad + 0.5 * d1);
-      mask |= KM_CON_FINGER_CUBE(s); act |= 1u << n;
-    }
+    hitc = d1 < 0;
     // table plane (geom1) - sphere (geom2)
-    const real d2 = ctr[2] - m->table_z - rad;
-    if (d2 < 0) {
-      const int n = 4 + NSPH + s;
-      const real fr[9] = KM_PLANE_FRAME;
+    d2 = ctr[2] - m->table_z - rad;
+    hitt = d2 < 0;
+  }
+  // the first NSS penetrating spheres of each kind (sphere order) get the slots: rank = penetrating spheres on lower lanes
+  const uint32_t below_me = (1u << sub) - 1u;
+  const uint32_t mc = (uint32_t)(__ballot(hitc) >> ((threadIdx.x & 63) - sub)) & below_me;
+  const uint32_t mt = (uint32_t)(__ballot(hitt) >> ((threadIdx.x & 63) - sub)) & below_me;
+  if (hitc && __popc(mc) < NSS) {
+    const int n = 4 + __popc(mc);
+    real fr[9];
+    mat_vec3(fr, w.k.cube_mat, nloc);
+    make_frame(fr);
 #pragma unroll
-      for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
-      w.c_dist[n] = d2;
-      w.c_pos[n][0] = ctr[0]; w.c_pos[n][1] = ctr[1]; w.c_pos[n][2] = ctr[2] - (rad + 0.5 * d2);
-      mask |= KM_CON_FINGER_TABLE(s); act |= 1u << n;
-    }
+    for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
+    w.c_dist[n] = d1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) w.c_pos[n][a] = ctr[a] + fr[a] * (rad + 0.5 * d1);
+    w.slot_sph[n] = s;
+    mask |= KM_CON_SPHERE_CUBE(s); act |= 1u << n;
+  }
+  if (hitt && __popc(mt) < NSS) {
+    const int n = 4 + NSS + __popc(mt);
+    const real fr[9] = KM_PLANE_FRAME;
+#pragma unroll
+    for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
+    w.c_dist[n] = d2;
+    w.c_pos[n][0] = ctr[0]; w.c_pos[n][1] = ctr[1]; w.c_pos[n][2] = ctr[2] - (rad + 0.5 * d2);
+    w.slot_sph[n] = s;
+    mask |= KM_CON_SPHERE_TABLE(s); act |= 1u << n;
   }
   mask = (uint32_t)gor<G>((int)mask);
   act = (uint32_t)gor<G>((int)act);
   if (sub == 0) {
     w.cact = act; w.contact_mask = mask;
-    w.touch_fc = (mask & (0xFFu << 8)) != 0; w.touch_ct = (mask & 0xFFu) != 0;
+    w.touch_fc = (mask & KM_CON_ANY_SPHERE_CUBE) != 0; w.touch_ct = (mask & KM_CON_ANY_CUBE_TABLE) != 0;
   }
 }
 
@@ -907,7 +918,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
     cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
     if (((act >> c) & 1u) && sub < NV) {
       const int kind = slot_kind<NL>(c);
-      const int link = kind == 0 ? -1 : m->sphere_link[slot_sphere<NL>(c) < 0 ? 0 : slot_sphere<NL>(c)];
+      const int link = kind == 0 ? -1 : m->sphere_link[w.slot_sph[c]];
       const int b1 = kind == 1 ? link : -1, b2 = kind == 2 ? link : NL;   // geom1 / geom2 bodies
       real pt[3] = {w.c_pos[c][0], w.c_pos[c][1], w.c_pos[c][2]};
       real p1[3], r1[3], p2[3], r2[3];
@@ -983,7 +994,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
 #pragma unroll
         for (int l = 0; l < 4; l++) Ge[l] = Gm[l][0] + sm * Gm[l][k];        // J_l . M^-1 (J_0 + sm J_k)^T
         const real Ad = Ge[0] + sm * Ge[k];
-        if (e == 0) R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * lm.slotA[c]);
+        if (e == 0) R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * (kind == 0 ? lm.cornerA : lm.sphA[kind == 2][w.slot_sph[c]]));
         const real vel = vb[0] + sm * vb[k];
         if (sub == 0) {
           rc.den[e] = Ad + R;
@@ -1186,7 +1197,7 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
 enum { KM_SUB_ALL = 0, KM_SUB_ARM = 1, KM_SUB_CUBE = 2 };
 template <int NL, int S> struct SubSet {
   static constexpr int D0 = S == KM_SUB_CUBE ? NL : 0, D1 = S == KM_SUB_ARM ? NL : NL + 6;
-  static constexpr int kind(int c) { return c < 4 ? 0 : (c < 4 + 3 * (NL / 10) ? 1 : 2); }
+  static constexpr int kind(int c) { return slot_kind<NL>(c); }
   static constexpr bool slot(int c) { return S == KM_SUB_ALL || (S == KM_SUB_ARM ? kind(c) == 2 : kind(c) == 0); }
   // columns of the Hessian a slot of this kind touches (its Jacobian is zero elsewhere), intersected with the subset
   static constexpr int c0(int c) { const int k = kind(c); const int lo = k == 0 ? NL : 0; return lo > D0 ? lo : D0; }
@@ -1321,7 +1332,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
           cr.jb[c][0] = dl[2]; cr.jb[c][1] = dl[1]; cr.jb[c][2] = -dl[0]; cr.jb[c][3] = drz;
         }
       } else {
-      const int link = m->sphere_link[slot_sphere<NL>(c) < 0 ? 0 : slot_sphere<NL>(c)];
+      const int link = m->sphere_link[w.slot_sph[c]];
       const int b1 = kind == 1 ? link : -1, b2 = kind == 2 ? link : NL;
       real pt[3] = {w.c_pos[c][0], w.c_pos[c][1], w.c_pos[c][2]};
       real p1[3], r1[3], p2[3], r2[3];
@@ -1348,7 +1359,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       const real* sr = cube ? m->con_cube_solref : m->con_def_solref;
       const real* si = cube ? m->con_cube_solimp : m->con_def_solimp;
       real mu[3] = {fr[0], fr[0], fr[1]};
-      const real Ad = lm.slotA[c];         // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
+      const real Ad = kind == 0 ? lm.cornerA : lm.sphA[kind == 2][w.slot_sph[c]];   // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
       real vb[4];
       if (kind == 0) plane_proj<NL>(w, c, qlin, qangw, vb);
       else {
@@ -1519,7 +1530,7 @@ __device__ __forceinline__ void newton_eval(Ws<NL>& w, const KModelDesc* m, int 
 #pragma unroll
   for (int q = 0; q < NEQ; q++) {
     const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
-    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2);
+    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
     lf[q] = 0;
     if (c < NC && ((act >> c) & 1u) && !(kind == 2 && e >= 4)) {
       const ConRec& rc = w.rec[c];
@@ -1635,7 +1646,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
   for (int q = 0; q < NEQ; q++) {
     const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
     lx[q] = 0; ly[q] = 0; lR[q] = 0; lD[q] = 0; lsm[q] = 0;
-    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSPH ? 1 : 2);
+    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
     const bool insub = S == KM_SUB_ALL || (S == KM_SUB_ARM ? kind == 2 : kind == 0);
     const bool valid = c < NC && insub && ((act >> c) & 1u) && !(kind == 2 && e >= 4);
     if (valid) {
@@ -1807,7 +1818,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
     cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
   }
   pf.ph(8);
-  constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSPH) - 1u) << 4;          // finger-cube slots couple arm and cube
+  constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
   if (act & FC_MASK) {
     newton_loop<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, qm, pf);
   } else {
@@ -1987,12 +1998,12 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
       stage_imp(lm.imp[0], m->con_def_solimp); stage_imp(lm.imp[1], m->con_cube_solimp);
       lm.cubew[0] = m->cube_invweight0[0]; lm.cubew[1] = m->cube_invweight0[1];
       lm.scale = 1.0 / (m->meaninertia * (NL + 6));
-      for (int c = 0; c < Dim<NL>::NC; c++) {
-        const int kind = slot_kind<NL>(c), sp = slot_sphere<NL>(c);
-        const real lw = (kind != 0 && sp < m->nsphere) ? m->body_invweight0[m->sphere_link[sp]][0] : 0.0;
-        const real tran = (kind != 2 ? m->cube_invweight0[0] : 0.0) + lw;
-        const real mu = kind != 2 ? m->con_cube_friction[0] : m->con_def_friction[0];
-        lm.slotA[c] = tran + mu * mu * tran;
+      const real muc = m->con_cube_friction[0], mud = m->con_def_friction[0], cw = m->cube_invweight0[0];
+      lm.cornerA = cw + muc * muc * cw;
+      for (int sp = 0; sp < Dim<NL>::NSPH; sp++) {
+        const real lw = sp < m->nsphere ? m->body_invweight0[m->sphere_link[sp]][0] : 0.0;
+        lm.sphA[0][sp] = (cw + lw) + muc * muc * (cw + lw);
+        lm.sphA[1][sp] = lw + mud * mud * lw;
       }
     }
     lm.dofw[i] = m->dof_invweight0[i];

@@ -158,8 +158,9 @@ __device__ __forceinline__ real cast_ray(const KModelDesc* m, const RenderScene&
       }
     }
   }
-  // finger spheres
+  // finger spheres (the link spheres are collision-only surrogates: they would wall in the wrist cameras)
   for (int s = 0; s < m->nsphere; s++) {
+    if (!m->sphere_visible[s]) continue;
     real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
     const real a = dot3(d, d), b = dot3(d, oc), cc = dot3(oc, oc) - m->sphere_radius[s] * m->sphere_radius[s];
     const real disc = b * b - a * cc;

@@ -22,7 +22,7 @@ ASSETS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 KM_MAX_LINKS = 20
 KM_MAX_ARMS = 2
 KM_MAX_IK = 7
-KM_MAX_SPHERES = 6
+KM_MAX_SPHERES = 12
 KM_MAX_CAMS = 4
 KM_CAM_INDEX = {"grip_r": 0, "grip_l": 1, "top": 2, "head": 3}
 
@@ -147,7 +147,7 @@ class KModelDesc(C.Structure):
         ("arm_site_link", C.c_int32 * KM_MAX_ARMS), ("arm_mode", C.c_int32 * KM_MAX_ARMS),
         ("arm_has_grip", C.c_int32 * KM_MAX_ARMS), ("pad2_", C.c_int32 * 2),
         ("arm_site_pos", (C.c_double * 3) * KM_MAX_ARMS), ("arm_site_quat", (C.c_double * 4) * KM_MAX_ARMS),
-        ("sphere_link", C.c_int32 * KM_MAX_SPHERES), ("sphere_pos", (C.c_double * 3) * KM_MAX_SPHERES),
+        ("sphere_link", C.c_int32 * KM_MAX_SPHERES), ("sphere_visible", C.c_int32 * KM_MAX_SPHERES), ("sphere_pos", (C.c_double * 3) * KM_MAX_SPHERES),
         ("sphere_radius", C.c_double * KM_MAX_SPHERES), ("table_z", C.c_double),
         ("cube_mass", C.c_double), ("cube_inertia", C.c_double * 3), ("cube_half", C.c_double * 3),
         ("cube_frictionloss", C.c_double), ("cube_quat0", C.c_double * 4),
@@ -355,6 +355,7 @@ def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool
     d.nsphere = len(sph)
     for i, s in enumerate(sph):
         d.sphere_link[i] = s["link"]
+        d.sphere_visible[i] = s.get("visible", 1)
         d.sphere_radius[i] = s["radius"]
         for k in range(3):
             d.sphere_pos[i][k] = s["pos"][k]

@@ -31,7 +31,11 @@ extern "C" {
 #define KM_MAX_LINKS   20   /* 1-DoF robot links == robot dofs == nu == q_len (10 solo, 20 dual/torso) */
 #define KM_MAX_ARMS    2    /* arm 0 = right ("eer"), arm 1 = left ("eel")                         */
 #define KM_MAX_IK      7    /* IK unknowns per arm (7 solo/dual, 6 torso)                          */
-#define KM_MAX_SPHERES 6    /* sphere colliders: two fingers + one hand (palm) sphere per arm      */
+#define KM_MAX_SPHERES 12   /* sphere colliders per model: per arm two fingers, the palm and three joint housings */
+/* Contact slots the solver keeps per step: 4 cube corners on the table, plus KM_SPHERE_SLOTS sphere-cube and
+ * KM_SPHERE_SLOTS sphere-table contacts -- the first penetrating spheres in sphere-index order (fingers come first);
+ * a further penetrating sphere is dropped for that sub-step (its mask bit stays clear), like the 5th+ cube corner. */
+#define KM_SPHERE_SLOTS(nlink) (2 * ((nlink) / 10))
 #define KM_MAX_CAMS    4    /* cameras: 0 = grip_r, 1 = grip_l, 2 = top, 3 = head (__init__.py:157-161) */
 enum { KM_CAM_GRIP_R = 0, KM_CAM_GRIP_L = 1, KM_CAM_TOP = 2, KM_CAM_HEAD = 3 };
 #define KM_NQ_CUBE     7
@@ -53,8 +57,11 @@ enum { KM_SOLVER_PGS = 0, KM_SOLVER_NEWTON = 1 };
 
 /* contact-mask bits (uint32 per env), bit-exact parity target */
 #define KM_CON_CUBE_TABLE(c)   (1u << (c))          /* c = 0..7 cube corner vs table plane (<=4 kept) */
-#define KM_CON_FINGER_CUBE(s)  (1u << (8 + (s)))    /* s = sphere index (fingers first, then hands): sphere vs cube  */
-#define KM_CON_FINGER_TABLE(s) (1u << (16 + (s)))   /* sphere vs table plane                                         */
+#define KM_CON_SPHERE_CUBE(s)  (1u << (8 + (s)))    /* s = sphere index 0..11 (fingers first, then link spheres): sphere vs cube */
+#define KM_CON_SPHERE_TABLE(s) (1u << (20 + (s)))   /* sphere vs table plane                                         */
+#define KM_CON_ANY_CUBE_TABLE   0x000000FFu
+#define KM_CON_ANY_SPHERE_CUBE  0x000FFF00u
+#define KM_CON_ANY_SPHERE_TABLE 0xFFF00000u
 
 typedef struct KModelDesc {
   /* ---- sizes */
@@ -101,8 +108,9 @@ typedef struct KModelDesc {
   double  arm_site_pos[KM_MAX_ARMS][3];         /* site pose in its link frame                     */
   double  arm_site_quat[KM_MAX_ARMS][4];
 
-  /* ---- colliders (surrogates): finger spheres, table plane z, cube box */
+  /* ---- colliders (surrogates): finger + link spheres, table plane z, cube box */
   int32_t sphere_link[KM_MAX_SPHERES];
+  int32_t sphere_visible[KM_MAX_SPHERES];       /* 1: drawn by the camera renders (fingers); 0: collision only    */
   double  sphere_pos[KM_MAX_SPHERES][3];
   double  sphere_radius[KM_MAX_SPHERES];
   double  table_z;

@@ -121,8 +121,8 @@ MIN_LINK_LEN = 0.04
 HINGE_EXTRA_INERTIA = 0.01
 FINGER_RADIUS = 0.010       # one sphere collider per gripper finger
 FINGER_OPEN_OFFSET = 0.035  # finger centre sits this far (along +slide axis) from the EE site at q=0
-HAND_RADIUS = 0.030         # one sphere collider per hand (the link that carries the finger sliders): the palm, half way
-                            # between that link's origin and the EE site -- the reference's hand meshes collide with table and cube
+PALM_RADIUS = 0.030         # link colliders (see build()): the palm sphere; the joint-housing spheres use LINK_RADIUS -- the
+                            # reference's link meshes all collide with table and cube (contype = conaffinity = 1)
 TABLE_TOP_Z = 0.5           # table body origin z (scene.xml:14); surrogate = plane z = 0.5
 
 
@@ -292,21 +292,37 @@ def build(env_xml, name):
                         "link": i, "pos": centre.tolist(), "radius": FINGER_RADIUS,
                         "site": sname})
 
-    # ---- surrogate hand colliders: one sphere per hand link (the parent of a pair of finger sliders), after the fingers
+    # ---- surrogate link colliders, after the fingers (sphere order = priority for the solver's contact slots, so the
+    # distal ones come first): per hand link H (the parent of a pair of finger sliders) the palm, half way between H's
+    # origin and the EE site, then the joint housings at the origins of H and of its two ancestors (wrist, forearm,
+    # elbow).  Links nearer the shoulder stay collider-free: the surrogate table is an infinite plane at the table-top
+    # height and the arms are mounted at (solo / dual) or next to (torso) that height.  Collision only (visible = 0):
+    # the wrist cameras sit inside / behind these spheres, where the reference's camera sees past its gripper mesh.
+    for s in spheres:
+        s["visible"] = 1
     hands = []
     for s in list(spheres):
         par = links[s["link"]]["parent"]
-        if par in hands:
+        if par in [h[0] for h in hands]:
             continue
-        hands.append(par)
         st = sites[s["site"]]
         lk, sp = st["link"], np.array(st["pos"])
         while lk != par and lk >= 0:                      # EE site in the hand link's frame at zero configuration
             sp = np.array(links[lk]["pos"]) + qrot(np.array(links[lk]["quat"]), sp)
             lk = links[lk]["parent"]
         assert lk == par
-        spheres.append({"name": "hand_" + ("r" if s["name"].endswith("_r") else "l"), "link": par, "pos": (0.5 * sp).tolist(),
-                        "radius": HAND_RADIUS, "site": s["site"]})
+        hands.append((par, "r" if s["name"].endswith("_r") else "l", sp, s["site"]))
+    for par, side, sp, site in hands:
+        spheres.append({"name": "palm_" + side, "link": par, "pos": (0.5 * sp).tolist(), "radius": PALM_RADIUS,
+                        "site": site, "visible": 0})
+    for tier, tname in enumerate(["wrist", "forearm", "elbow"]):
+        for par, side, sp, site in hands:
+            lk = par
+            for _ in range(tier):
+                lk = links[lk]["parent"]
+                assert lk >= 0
+            spheres.append({"name": tname + "_" + side, "link": lk, "pos": [0.0, 0.0, 0.0], "radius": LINK_RADIUS,
+                            "site": site, "visible": 0})
 
     spec = {
         "name": name,
@@ -320,7 +336,7 @@ def build(env_xml, name):
         "table": {"pos": table["pos"], "plane_z": TABLE_TOP_Z},
         "spheres": spheres,
         "option": {"timestep": 0.002, "gravity": [0, 0, -9.81]},
-        "surrogate_note": "link inertials, finger / hand spheres and the table plane are build-owned "
+        "surrogate_note": "link inertials, finger / link spheres and the table plane are build-owned "
                           "surrogates (reference meshes absent); see tools/mjcf_extract.py",
     }
     return spec
