@@ -146,6 +146,79 @@ def test_step_parity_vs_oracle(env, n, steps, solver):
     dev.k_close()
 
 
+def test_forearm_on_table_gpu():
+    """The link-collider scenario of tests/test_oracle_dynamics.py on the device: same mask bit, same trajectory."""
+    _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    from test_oracle_dynamics import forearm_on_table
+    cm = compile_model("KManipSoloArmQPos", auto_reset=False)
+    dev = forearm_on_table(cm, cm.desc.nsphere, lambda c: env_hip.KManipEnvHip(c, num_envs=1, seed=0))
+    orc = forearm_on_table(cm, cm.desc.nsphere, lambda c: Oracle(c, 1, seed=0))
+    torch = _torch()
+    for k in range(3):
+        act = np.zeros((1, cm.act_dim), dtype=np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda()); orc.step(act)
+        _cmp_state(dev, orc, k)
+        assert int(dev.get_diag()[0][0]) == int(orc.get_diag()[0][0]) == 1 << (20 + 4)
+    dev.k_close()
+
+
+def _crowded(cm):
+    """A descriptor whose link spheres crowd the contact slots: on the 10-link model they are moved onto the two finger
+    links (so a finger on the table brings three candidates down at once), on the 20-link models they are doubled in size."""
+    from gym_kmanip_amd.model import KModelDesc
+    d = KModelDesc.from_buffer_copy(cm.desc)
+    nf = 2 * (cm.nlink // 10)
+    for s in range(nf, d.nsphere):
+        if cm.nlink == 10:
+            d.sphere_link[s] = d.sphere_link[s % nf]
+            for k in range(3):
+                d.sphere_pos[s][k] = d.sphere_pos[s % nf][k] + 0.004 * (s - nf + 1) * (1 if k == s % 3 else 0)
+            d.sphere_radius[s] = 0.012
+        else:
+            d.sphere_radius[s] *= 2.0
+    return type(cm)(**{**cm.__dict__, "desc": d})
+
+
+@pytest.mark.parametrize("env,n", [("KManipSoloArm", 32), ("KManipTorso", 16)])
+def test_sphere_slot_overflow_parity(env, n):
+    """KM_SPHERE_SLOTS: with more penetrating spheres than slots, device and oracle keep the same ones (the first in sphere
+    order) -- contact masks bit-exact, states within tolerance -- on a model rigged so that this happens often."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    from oracle import ik_scipy as S
+    cm = _crowded(compile_model(env, auto_reset=True))
+    d = cm.desc
+    dev = env_hip.KManipEnvHip(cm, num_envs=n, seed=5, env_id_offset=7); orc = Oracle(cm, n, seed=5, env_id_offset=7)
+    dev.k_reset(); orc.reset()
+    rng = np.random.default_rng(43)
+    nss = 2 * (cm.nlink // 10)
+    full = over = 0
+    resync = [0]
+    for k in range(40):
+        act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda())
+        oo, ro, do = orc.step(act)
+        _cmp_state(dev, orc, k, resync)
+        mg = dev.get_diag()[0]; mo = orc.get_diag()[0]
+        assert np.array_equal(mg, mo), (k, mg, mo)
+        assert np.array_equal(dev.done.cpu().numpy(), do), k
+        tab = np.array([bin(int(m) >> 20).count("1") for m in mg]); cub = np.array([bin((int(m) >> 8) & 0xFFF).count("1") for m in mg])
+        assert tab.max() <= nss and cub.max() <= nss
+        full += int((tab == nss).sum())
+        qpos = orc.get_state()[0]
+        for e in np.where(tab == nss)[0]:                       # slots full: were more spheres down than were kept?
+            xpos, xquat, _, _ = orc.fk(qpos[e])
+            down = sum((xpos[d.sphere_link[s]] + S.quat2mat(xquat[d.sphere_link[s]]) @ np.array(d.sphere_pos[s]))[2]
+                       - d.sphere_radius[s] < d.table_z for s in range(d.nsphere))
+            over += int(down > nss)
+    assert full > 0 and over > 0, (full, over)
+    assert resync[0] <= 1, resync
+    dev.k_close()
+
+
 @pytest.mark.parametrize("env", ENVS3)
 def test_golden_trajectory_gpu(env):
     torch = _torch()

@@ -318,3 +318,40 @@ def test_cube_free_fall_and_rest():
     assert np.abs(qvel[alone, nl:nl + 6]).max() < 1e-4
     straight = np.abs(qpos[:, nl:nl + 2] - qpos0[:, nl:nl + 2]).max(axis=1) < 1e-6
     assert straight.sum() >= 2                                             # it fell straight down (a spawn may brush the home-pose gripper)
+
+
+FOREARM_DOWN = [-1.003, 1.609, 2.408, 0.15, -0.821, 0.563, 0.223, 2.946, -0.002, -0.005]   # only the forearm sphere is below the table (5 mm)
+
+
+def forearm_on_table(cm, nsphere, make):
+    """Solo arm held (joint-delta actions of zero) in FOREARM_DOWN with the cube out of the way; returns per control step
+    the contact mask and the height of the forearm sphere's lowest point over the table."""
+    from gym_kmanip_amd.model import KModelDesc
+    d = KModelDesc.from_buffer_copy(cm.desc); d.nsphere = nsphere
+    o = make(type(cm)(**{**cm.__dict__, "desc": d}))
+    o.reset() if hasattr(o, "reset") else o.k_reset()
+    qpos, qvel, ctrl, warm, step = o.get_state()
+    nl = cm.nlink
+    qpos[0, :nl] = FOREARM_DOWN; ctrl[0, :] = np.asarray(FOREARM_DOWN, dtype=np.float32); qpos[0, nl:nl + 3] = [0.2, 0.6, 3.0]
+    o.set_state(qpos, qvel, ctrl, warm, step)
+    return o
+
+
+def test_link_sphere_keeps_the_forearm_on_the_table():
+    """arm links collide.  With the link spheres the forearm's joint housing, started 5 mm inside the table,
+    is pushed back out (soft contact) and its mask bit is set; with finger spheres only it keeps sinking."""
+    cm = compile_model("KManipSoloArmQPos", auto_reset=False)
+    d = cm.desc
+    s = [i for i in range(d.nsphere) if d.sphere_link[i] == 5][0]
+    assert s == 4 and not d.sphere_visible[s] and d.sphere_visible[0]
+    zs = {}
+    for nsph in (d.nsphere, 2):
+        o = forearm_on_table(cm, nsph, lambda c: Oracle(c, 1, seed=0))
+        zs[nsph] = []
+        for _ in range(3):
+            o.step(np.zeros((1, cm.act_dim), dtype=np.float32))
+            xpos = o.fk(o.get_state()[0][0])[0]
+            zs[nsph].append(xpos[5][2] - d.sphere_radius[s] - d.table_z)
+            assert int(o.get_diag()[0][0]) == ((1 << (20 + s)) if nsph > 2 else 0)
+    assert zs[d.nsphere][0] > -0.005 and zs[d.nsphere][2] > -0.001 and zs[d.nsphere][2] < 0        # resting: sub-millimetre penetration
+    assert zs[2][2] < -0.01                                                                        # no collider: through the table

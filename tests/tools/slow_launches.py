@@ -12,12 +12,23 @@ args = bench.parse_args(["--no-variants", "--no-cpu-baseline"])
 w = bench.Workload(torch, "KManipSoloArm", 4096, 0, 0, 0, "newton", 100, 1234)
 env = w.env
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rows = []
 for k in range(steps):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); w.step(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     mask, nfev, st = env.get_diag()
+    rows.append((ms, int(nfev[:, 0].max()), int(((mask & 0xFFF00) != 0).sum())))
     if ms > 2.0 or k < 3:
         j = int(nfev[:, 0].argmax())
         print("step %3d  %.3f ms  max nfev %d (env %d, status %d)  nfev>100: %d envs  contact mask of that env %s" % (
             k, ms, nfev[j, 0], j, st[j, 0], int((nfev[:, 0] > 100).sum()), hex(int(mask[j]))))
+
+r = np.array(rows, dtype=np.float64)
+print("launch ms: mean %.3f  p50 %.3f  p90 %.3f  p99 %.3f  max %.3f" % (r[:, 0].mean(), *np.percentile(r[:, 0], [50, 90, 99]), r[:, 0].max()))
+print("  (end-of-step state) max IK nfev per launch: p50 %d p90 %d max %d; envs with a sphere-cube contact: mean %.1f" % (
+    *np.percentile(r[:, 1], [50, 90]), r[:, 1].max(), r[:, 2].mean()))
+for lo, hi in [(0, 100), (100, 200), (200, 400), (400, 10000)]:
+    sel = (r[:, 1] >= lo) & (r[:, 1] < hi)
+    if sel.any():
+        print("  launches with max nfev in [%d, %d): %4d  mean %.3f ms" % (lo, hi, sel.sum(), r[sel, 0].mean()))

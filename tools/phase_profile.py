@@ -42,6 +42,8 @@ nb = n // 4
 blk = (C.c_ulonglong * (NPH * 4 * nb))()
 if hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) == 0:
     B = np.array(list(blk), dtype=np.float64).reshape(nb, 4, NPH)
+    if os.environ.get("KM_PHASE_DUMP"):
+        np.save(os.environ["KM_PHASE_DUMP"], B)
     tot_b = B[:, 0, :].sum(1)                       # wave lifetime as seen by lane group 0
     order = np.argsort(tot_b)
     print("last launch: wave totals  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
