@@ -116,7 +116,7 @@ struct Ws {
 #if KM_VAR_SOLVER == KM_SOLVER_PGS
   real as[NV], tmp2[NV], tmp3[NV];
 #endif
-  int ns, bad, touch_fc, touch_ct;
+  int ns, bad, touch_ct;
   uint32_t contact_mask;   // KM_CON_* bits (which candidate pairs touch)
   uint32_t cact;           // active contact slots
   // single-dof constraint rows on ARM dofs (friction loss, then limits); the cube's friction-loss rows are
@@ -808,7 +808,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
   act = (uint32_t)gor<G>((int)act);
   if (sub == 0) {
     w.cact = act; w.contact_mask = mask;
-    w.touch_fc = (mask & KM_CON_ANY_SPHERE_CUBE) != 0; w.touch_ct = (mask & KM_CON_ANY_CUBE_TABLE) != 0;
+    w.touch_ct = (mask & KM_CON_ANY_CUBE_TABLE) != 0;
   }
 }
 
@@ -2109,7 +2109,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
       real df[3] = {w.qpos[NL] - (sp[0] + w.k.xpos[l][0]), w.qpos[NL + 1] - (sp[1] + w.k.xpos[l][1]), w.qpos[NL + 2] - (sp[2] + w.k.xpos[l][2])};
       rew += m->reward_grip_dist * (1.0 / (sqrt(dot3(df, df)) + m->epsilon));
     }
-    if (m->touch_reward_enabled && w.touch_fc) {
+    if (m->touch_reward_enabled && (w.contact_mask & KM_CON_FINGERS_CUBE(NL))) {      // a FINGER on the cube (palm / link spheres do not count)
       rew += m->reward_touch_cube;
       if (!w.touch_ct) rew += m->reward_lift_cube;
     }

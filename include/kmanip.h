@@ -62,6 +62,8 @@ enum { KM_SOLVER_PGS = 0, KM_SOLVER_NEWTON = 1 };
 #define KM_CON_ANY_CUBE_TABLE   0x000000FFu
 #define KM_CON_ANY_SPHERE_CUBE  0x000FFF00u
 #define KM_CON_ANY_SPHERE_TABLE 0xFFF00000u
+/* the finger spheres come first in the sphere list, two per arm: "cube touches a gripper finger" (env_sim.py:164-175) */
+#define KM_CON_FINGERS_CUBE(nlink) (((1u << (2 * ((nlink) / 10))) - 1u) << 8)
 
 typedef struct KModelDesc {
   /* ---- sizes */

@@ -146,6 +146,34 @@ def test_step_parity_vs_oracle(env, n, steps, solver):
     dev.k_close()
 
 
+def test_touch_reward_parity():
+    """touch_reward=True (the reference's unreachable touch / lift terms switched on): reward parity incl. the bonuses, which
+    only a FINGER sphere on the cube earns (+1, and +1 more with no cube corner on the table)."""
+    torch = _torch()
+    from oracle.oracle import Oracle
+    import gym_kmanip_amd.model as K
+    n = 256
+    cm, dev, orc = _mk("KManipSoloArm", n, seed=3, touch_reward=True)
+    plain = Oracle(compile_model("KManipSoloArm"), n, seed=3)          # same physics, reward without the touch terms
+    dev.k_reset(); orc.reset(); plain.reset()
+    rng = np.random.default_rng(1)
+    seen = np.zeros(3, dtype=int)
+    for k in range(64):
+        act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda()); ro = orc.step(act)[1]; r0 = plain.step(act)[1]
+        mg = dev.get_diag()[0]
+        assert np.array_equal(mg, orc.get_diag()[0]), k
+        rg = dev.reward.cpu().numpy()
+        assert np.abs(rg - ro).max() < TOL_R, (k, np.abs(rg - ro).max())
+        finger = (mg & 0x300) != 0; other = ((mg & 0xFFF00) != 0) & ~finger; table = (mg & 0xFF) != 0
+        bonus = np.where(finger, K.REWARD_TOUCH_CUBE + np.where(table, 0.0, K.REWARD_LIFT_CUBE), 0.0)
+        assert np.abs(rg - r0 - bonus).max() < TOL_R, k
+        seen += [int((finger & table).sum()), int((finger & ~table).sum()), int(other.sum())]
+        sg = dev.get_state(); orc.set_state(*sg); plain.set_state(*sg)
+    assert (seen > 0).all(), seen
+    dev.k_close()
+
+
 def test_forearm_on_table_gpu():
     """The link-collider scenario of tests/test_oracle_dynamics.py on the device: same mask bit, same trajectory."""
     _torch()

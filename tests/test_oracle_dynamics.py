@@ -355,3 +355,23 @@ def test_link_sphere_keeps_the_forearm_on_the_table():
             assert int(o.get_diag()[0][0]) == ((1 << (20 + s)) if nsph > 2 else 0)
     assert zs[d.nsphere][0] > -0.005 and zs[d.nsphere][2] > -0.001 and zs[d.nsphere][2] < 0        # resting: sub-millimetre penetration
     assert zs[2][2] < -0.01                                                                        # no collider: through the table
+
+
+def test_touch_reward_counts_fingers_only():
+    """env_sim.py:164-179 with the touch terms made reachable (touch_reward=True; dead in the reference, SURVEY finding 4):
+    +1 when the cube touches a gripper FINGER, +1 more when it then has no contact with the table.  The palm and the link
+    spheres touch the cube too (they couple arm and cube in the solver) but earn nothing."""
+    n = 256
+    a = Oracle(compile_model("KManipSoloArm", touch_reward=True), n, seed=3); b = Oracle(compile_model("KManipSoloArm"), n, seed=3)
+    a.reset(); b.reset()
+    rng = np.random.default_rng(1)
+    seen = np.zeros(3, dtype=int)
+    for _ in range(64):
+        act = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        ra = a.step(act)[1]; rb = b.step(act)[1]
+        m = a.get_diag()[0]
+        finger = (m & 0x300) != 0; other = ((m & 0xFFF00) != 0) & ~finger; table = (m & 0xFF) != 0
+        bonus = np.where(finger, K.REWARD_TOUCH_CUBE + np.where(table, 0.0, K.REWARD_LIFT_CUBE), 0.0)
+        assert np.abs((ra - rb) - bonus).max() < 1e-12
+        seen += [int((finger & table).sum()), int((finger & ~table).sum()), int(other.sum())]
+    assert (seen > 0).all(), seen
