@@ -168,6 +168,7 @@ class KManipEnvHip:
         (get_termination -> None); the TimeLimit truncation and the divergence flag are in `self.done`."""
         torch = _torch()
         act = self.pack_action(action)
+        self.last_act = act                      # the flat float32 row this step ran on (episode loggers read it)
         self.step_flat(act)
         # sim_time = data.time of each env (env_sim.py:194,200) = steps since its last reset x control_timestep: the step
         # kernel itself fills the bound device buffer -- no extra launch, no host synchronisation

@@ -9,11 +9,16 @@ gymnasium is not installed in the build image, so spaces degrade to duck-typed s
 With num_envs == 1 and squeeze=True the return values have the reference's single-env shapes.
 With device_outputs=True nothing crosses PCIe: observations, reward, terminated, truncated are device tensors and the
 step never synchronises (the drop-in path at full speed); the default returns host NumPy like the reference.
+log_h5py=True / log_prefix reproduce env_base.py:82-101,231-263: a fresh `<log_prefix>.<uuid6>.<date>` directory under DATA_DIR
+and one episode file per reset (episode_log.EpisodeLogger: device-resident rings, written out at the next reset / close).
 """
 from __future__ import annotations
 
+import os
 import time
+import uuid
 from collections import OrderedDict
+from datetime import datetime
 from typing import Any, Dict
 
 import numpy as np
@@ -23,6 +28,8 @@ from .model import (CAMERAS, ENV_SPECS, MAX_EPISODE_STEPS, REWARD_SUCCESS_THRESH
 
 OBS_DTYPE = np.float64   # __init__.py:50
 ACT_DTYPE = np.float32   # __init__.py:51
+DATA_DIR = os.environ.get("KMANIP_DATA_DIR", os.path.join(os.getcwd(), "data"))   # __init__.py:12 (theirs sits inside the package)
+DATE_FORMAT = "%mm%dd%Yy_%Hh%Mm"                                                    # __init__.py:15
 
 try:  # pragma: no cover - gymnasium is absent in the build image
     from gymnasium import spaces as _spaces
@@ -80,7 +87,8 @@ class KManipEnv:
     metadata = {"render_modes": ["rgb_array"], "render_fps": 30}
 
     def __init__(self, env_id: str = "KManipSoloArm", num_envs: int = 1, device: int = 0, seed: int = 0,
-                 squeeze: bool = False, env_id_offset: int = 0, device_outputs: bool = False, **overrides):
+                 squeeze: bool = False, env_id_offset: int = 0, device_outputs: bool = False,
+                 log_h5py: bool = False, log_prefix: str = "test", log_env_ids=None, log_backend=None, **overrides):
         spec: EnvSpec = ENV_SPECS[env_id]
         self.env_id = env_id
         self.seed = seed
@@ -138,6 +146,29 @@ class KManipEnv:
             "a_len": self.action_len, "obs_list": self.obs_list, "act_list": self.act_list,
             "cameras": self.cameras, "sim": self.sim,
         }
+        # optional episode logging, env_base.py:82-101 (rerun is a viewer, not on the path: not offered)
+        self.log_h5py = log_h5py
+        self.logger = None
+        if log_h5py:
+            self.log_dir = os.path.join(DATA_DIR, "{}.{}.{}".format(log_prefix, str(uuid.uuid4())[:6], datetime.now().strftime(DATE_FORMAT)))
+            os.makedirs(self.log_dir, exist_ok=True)
+            from .episode_log import EpisodeLogger
+            meta = {k: v for k, v in self.info.items() if k not in ("cameras",)}
+            self.logger = EpisodeLogger(self.log_dir, num_envs, self.q_len, self.env.cm.act_dim, device=self.env.obs.device,
+                                        env_ids=[0] if log_env_ids is None else log_env_ids, info=meta, backend=log_backend)
+            for cam in self.cameras:                                                 # env_base.py:233-234
+                self.logger.cam(cam)
+
+    def _log_step(self, action, obs_dev):
+        """env_base.py:255-257: append this step's action / q_pos / q_vel (and camera frames) to the episode's rings."""
+        act = self.env.last_act                                                 # the flat row k_step packed and ran on
+        q = self.q_len
+        frames = {cam.name: obs_dev[cam.log_name] for cam in self.cameras} or None
+        self.logger.step(act, self.env.obs[:, :q], self.env.obs[:, q:2 * q], images=frames)
+
+    def _log_flush(self):
+        if self.logger is not None and self.logger.t > 0:
+            self.log_paths = self.logger.end_episode()
 
     # ------------------------------------------------------------------ observations
     def _observation(self, state_obs):
@@ -145,6 +176,7 @@ class KManipEnv:
         obs = OrderedDict((k, v) for k, v in state_obs.items() if k in self.obs_list)
         for cam in self.cameras:
             obs[cam.log_name] = self.env.k_render(cam)
+        self._obs_dev = obs
         if self.device_outputs:
             return obs
         out = OrderedDict()
@@ -163,6 +195,7 @@ class KManipEnv:
         if seed is not None:
             self.seed = int(seed)
             self.env.set_seed(self.seed, restart_episodes=True)
+        self._log_flush()                                                       # env_base.py:231-232: one file per episode
         terminated, reward, _, observation, sim_time = self.env.k_reset()
         self.step_idx = 0
         self.episode_idx += 1
@@ -177,13 +210,16 @@ class KManipEnv:
         terminated, reward, _, observation, sim_time = self.env.k_step(action)
         self.step_idx += 1
         trunc_now = self.step_idx >= MAX_EPISODE_STEPS                              # TimeLimit wrapper
+        obs_out = self._observation(observation)
+        if self.logger is not None:
+            self._log_step(action, self._obs_dev)
         if self.device_outputs:
             torch = env_hip._torch()
             trunc = torch.full((self.num_envs,), trunc_now, dtype=torch.bool, device=reward.device)
             self.info.update(step=self.step_idx, episode=self.episode_idx, sim_time=sim_time, cpu_time=time.time(),
                              reward=reward, is_success=reward > REWARD_SUCCESS_THRESHOLD, terminated=terminated,
                              diverged=(self.env.done & KM_DONE_DIVERGED) != 0)
-            return self._observation(observation), reward, terminated, trunc, self.info
+            return obs_out, reward, terminated, trunc, self.info
         r = reward.detach().cpu().numpy()
         term = terminated.cpu().numpy()
         trunc = np.full(self.num_envs, trunc_now)
@@ -191,8 +227,8 @@ class KManipEnv:
                          reward=r, is_success=r > REWARD_SUCCESS_THRESHOLD, terminated=term,
                          diverged=(self.env.done.cpu().numpy() & KM_DONE_DIVERGED) != 0)
         if self.squeeze:
-            return self._observation(observation), float(r[0]), bool(term[0]), bool(trunc[0]), self.info
-        return self._observation(observation), r, term, trunc, self.info
+            return obs_out, float(r[0]), bool(term[0]), bool(trunc[0]), self.info
+        return obs_out, r, term, trunc, self.info
 
     def render(self):
         """env_base.py:215-217: the `top` camera as uint8 RGB [h, w, 3] ([num_envs, h, w, 3] for a batch)."""
@@ -203,4 +239,5 @@ class KManipEnv:
         return img[0] if self.squeeze else img
 
     def close(self):
+        self._log_flush()                                                       # env_base.py:262-263
         self.env.k_close()

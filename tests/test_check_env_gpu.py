@@ -3,6 +3,8 @@ installed here (or on the GPU box), so this file restates what check_env pins --
 membership in observation_space (keys / order / shape / dtype / bounds), action sampling, the step 5-tuple's types, render --
 on real HIP outputs for all 8 ids, single-env (squeeze) shapes like the reference's, plus the batched and device-resident
 variants of the same shell and the TimeLimit(64) truncation gym.make adds (__init__.py:28,247)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -168,3 +170,39 @@ def test_episode_logger_with_camera_frames_from_device(tmp_path):
     assert got.shape == (MAX_EPISODE_STEPS, cam.h, cam.w, 3) and got.dtype == np.uint8
     assert np.array_equal(got, np.stack(frames)) and np.unique(got).size > 3
     e.k_close()
+
+
+def test_shell_log_h5py_kwargs_and_examples(tmp_path, monkeypatch):
+    """env_base.py:82-101,231-263 through the shell: KManipEnv(log_h5py=True, log_prefix=...) makes a fresh log directory,
+    writes one episode file per reset for the logged envs (camera frames included for a *Vision id) and flushes on close();
+    the two example scripts (the reference's 2_log_with_h5py.py / 2_synthetic_data.py, batched) run end to end."""
+    import gym_kmanip_amd.gym_shell as gs
+    monkeypatch.setattr(gs, "DATA_DIR", str(tmp_path / "data"))
+    env = gs.KManipEnv("KManipSoloArmVision", num_envs=4, log_h5py=True, log_prefix="unit", log_env_ids=[1, 3], log_backend="npz")
+    assert os.path.isdir(env.log_dir) and os.path.basename(env.log_dir).startswith("unit.")
+    env.action_space.seed(1)
+    acts = []
+    for ep in range(2):
+        env.reset()
+        for k in range(5):
+            a = {key: np.stack([sp.sample() for _ in range(4)]) for key, sp in env.action_space.spaces.items()}
+            acts.append(np.concatenate([a[key].reshape(4, -1) for key in env.action_space.spaces], axis=1))
+            obs, rew, term, trunc, info = env.step(a)
+    env.close()
+    files = sorted(os.listdir(env.log_dir))
+    assert files == ["episode_1_env1.npz", "episode_1_env3.npz", "episode_2_env1.npz", "episode_2_env3.npz"], files
+    f = np.load(os.path.join(env.log_dir, "episode_2_env3.npz"))
+    assert f["observations/qpos"].shape == (64, 10) and f["action"].shape == (64, 7)
+    assert np.array_equal(f["action"][:5], np.stack([a[3] for a in acts[5:]]).astype(np.float32))
+    assert not f["action"][5:].any()
+    assert np.abs(f["observations/qpos"][4] - obs["q_pos"][3].astype(np.float32)).max() == 0
+    cam = [c for c in env.cameras if c.name == "grip_r"][0]
+    frames = f["observations/images/grip_r"]
+    assert frames.shape == (64, cam.h, cam.w, 3) and frames.dtype == np.uint8
+    assert np.array_equal(frames[4], obs[cam.log_name][3]) and frames[:5].any() and not frames[5:].any()
+    # the examples
+    from gym_kmanip_amd.examples import log_episodes, synthetic_data
+    d = log_episodes.main(["--env", "KManipSoloArm", "--num-envs", "8", "--episodes", "1", "--log-envs", "0", "2"])
+    assert len(os.listdir(d)) == 2
+    d = synthetic_data.main(["--num-envs", "64", "--episodes", "1", "--log-envs", "0", "--log-dir", str(tmp_path / "synth")])
+    assert len(os.listdir(d)) == 1
