@@ -1812,12 +1812,13 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   newton_eval<NL, G>(w, m, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1, &csl);
   const real cs = gsum<G>(csl);
   real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
+  pf.ph(8);
   if (!(cost0 + cost1 < cs)) {
     a = a_s; Mr = 0;
     newton_eval<NL, G>(w, m, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1);
     cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
+    pf.ph(38);
   }
-  pf.ph(8);
   constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
   if (act & FC_MASK) {
     newton_loop<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, qm, pf);
