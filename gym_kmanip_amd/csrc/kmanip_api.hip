@@ -124,6 +124,17 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
   if (depth > 16) { err = "kinematic tree deeper than 16 links"; return -1; }
   x->fk_rounds = 0;
   while ((1 << x->fk_rounds) < depth) x->fk_rounds++;
+  // block split of the joint-space inertia: the most balanced s such that no link >= s has an ancestor < s
+  x->split = 0;
+  if (!getenv("KMANIP_NO_BLOCK_SPLIT")) {
+    int best = d->nlink + 1;
+    for (int s = 1; s < d->nlink; s++) {
+      bool ok = true;
+      for (int i = s; i < d->nlink && ok; i++) ok = (x->anc_mask[i] & ((1u << s) - 1u)) == 0;
+      const int big = s > d->nlink - s ? s : d->nlink - s;
+      if (ok && big <= KM_BLOCK_MAX && big < best) { best = big; x->split = s; }
+    }
+  }
   for (int a = 0; a < KM_MAX_ARMS; a++) {
     if (!d->arm_present[a]) continue;
     int chain[KM_MAX_LINKS], n = 0;

@@ -9,6 +9,7 @@
 #include "../../include/kmanip.h"
 
 #define KM_MAX_CHAIN 8
+#define KM_BLOCK_MAX 11
 #define MJ_MINVAL 1e-15
 #define MJ_MINIMP 0.0001
 #define MJ_MAXIMP 0.9999
@@ -19,6 +20,8 @@ struct KModelAux {
   uint32_t desc_mask[KM_MAX_LINKS];          // bit j set <=> link j is link i or one of its descendants
   int32_t jump[4][KM_MAX_LINKS];             // jump[k][i] = the 2^k-th ancestor of link i (-1: none) -- FK pointer jumping
   int32_t fk_rounds;                         // ceil(log2(tree depth)) <= 4
+  int32_t split;                             // links [0, split) and [split, nlink) share no kinematic tree (two-arm models: the joint-space
+                                             // inertia is two diagonal blocks of <= KM_BLOCK_MAX dofs); 0 = no such split
   int32_t chain_len[KM_MAX_ARMS];            // IK kinematic chain root -> site link
   int32_t chain_link[KM_MAX_ARMS][KM_MAX_CHAIN];
   int32_t chain_xidx[KM_MAX_ARMS][KM_MAX_CHAIN];  // index into the IK unknowns, -1 = fixed at current qpos

@@ -55,7 +55,7 @@ template <int NL>
 struct LModel {
   int parent[NL], jtype[NL], forcelimited[NL];
   uint32_t anc[NL], desc[NL];
-  int jump[4][NL], fk_rounds;
+  int jump[4][NL], fk_rounds, split;
   real pos[NL][3], quat[NL][4], jaxis[NL][3], range[NL][2], floss[NL], kp[NL], ctrlrange[NL][2], forcerange[NL][2];
   real mass[NL], com[NL][3], inertia[NL][3], q_home[NL];
   real R[NL][9];        // constant rotation of each link in its parent (from link_quat)
@@ -152,6 +152,13 @@ extern "C" int kmanip_dbg_prof(unsigned long long* out, int reset) {
 extern "C" int kmanip_dbg_prof_blocks(unsigned long long* out, int nblocks) {
   if (nblocks > KM_PROF_BLOCKS) return -1;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_blk), sizeof(unsigned long long) * KM_NPH * 4 * nblocks) == hipSuccess ? 0 : -1;
+}
+#endif
+#if KM_VAR_NL == 20 && KM_VAR_SOLVER == 1
+extern "C" int kmanip_dbg_prof20(unsigned long long* out, int reset) {          // the DualArm / Torso Newton object's accumulators
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * KM_NPH) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[KM_NPH] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1; }
+  return 0;
 }
 #endif
 #endif
@@ -663,8 +670,58 @@ __device__ __forceinline__ void gj_cols(real (&upd)[N], const real (&a)[N], real
 // group runs an in-place Gauss-Jordan sweep (no pivoting: every pivot of an SPD matrix is a positive Schur
 // complement); row k reaches the other lanes through DPP row broadcasts, so there is no LDS traffic and no
 // synchronisation inside the n^2 loop.
+// Two-arm models: the trees [0, split) and [split, NL) share no dof, so the inertia is two diagonal blocks and both are
+// eliminated at once -- step t takes pivot t of EACH block (lanes of a block read their own pivot row: a wave shuffle with a
+// per-lane source instead of the broadcast of one row to everybody).  Each lane keeps only its block's columns, in
+// block-local order (compile-time register indices): <= KM_BLOCK_MAX steps of <= KM_BLOCK_MAX columns instead of NL x NL, and
+// the same operations per block in the same order as the full sweep does them (the off-block entries it carries are exact
+// zeros), so the result is bitwise the same.
 template <int NL, int G>
-__device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr) {
+__device__ __forceinline__ void invert_mass_blocks(Ws<NL>& w, int sub, CReg<NL>& cr, int split) {
+  constexpr int NB = KM_BLOCK_MAX;
+  const bool arm = sub < NL;
+  const int base = sub < split ? 0 : split, nb = sub < split ? split : NL - split, mine = sub - base;
+  real loc[NB];
+#pragma unroll
+  for (int j = 0; j < NL; j++) cr.mrow[j] = arm ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
+#pragma unroll
+  for (int c = 0; c < NB; c++) {
+    const int j = base + c;
+    loc[c] = (arm && c < nb) ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;
+  }
+  GSYNC();
+  int bad = 0;
+  const int lane0 = (threadIdx.x & 63) & ~(G - 1);
+  static_for<0, NB>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    const bool act = arm && t < nb;
+    const int src = lane0 + base + (t < nb ? t : 0);
+    real prow[NB];
+#pragma unroll
+    for (int c = 0; c < NB; c++) prow[c] = __shfl(loc[c], src, 64);
+    real pk = prow[t];
+    if (!(pk > 0)) { if (act) bad = 1; pk = 1; }
+    const real d = frcp(pk), aik = loc[t], f = aik * d;
+    const bool me = mine == t;
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < NB; c++) if (c != t) loc[c] = me ? loc[c] * d : fma(-prow[c], f, loc[c]);
+      loc[t] = me ? d : -aik * d;
+    }
+  });
+  if (__any(bad)) { const int gb = gor<G>(bad); if (gb && sub == 0) w.bad = 1; }      // (wave-uniform branch; never taken on sane models)
+  if (arm) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) w.Minv[sub][j] = 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) if (c < nb) w.Minv[sub][base + c] = loc[c];
+  }
+  GSYNC();
+}
+
+template <int NL, int G>
+__device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr, int split = 0) {
+  if constexpr (G == 32) { if (split) { invert_mass_blocks<NL, G>(w, sub, cr, split); return; } }
   real a[NL];
 #pragma unroll
   for (int j = 0; j < NL; j++) a[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
@@ -1855,7 +1912,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   }
   GSYNC();
   pf.ph(3);
-  invert_mass<NL, G>(w, sub, cr);
+  invert_mass<NL, G>(w, sub, cr, lm.split);
   pf.ph(4);
   if constexpr (SOLVER == KM_SOLVER_NEWTON) build_constraints_newton<NL, G>(w, lm, m, sub, cr, invm);
   else build_constraints<NL, G>(w, lm, m, sub, cr, invm);
@@ -1991,7 +2048,7 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
     lm.anc[i] = dm->x.anc_mask[i]; lm.desc[i] = dm->x.desc_mask[i];
     for (int k = 0; k < 4; k++) lm.jump[k][i] = dm->x.jump[k][i];
     if (i == 0) {
-      lm.fk_rounds = dm->x.fk_rounds;
+      lm.fk_rounds = dm->x.fk_rounds; lm.split = dm->x.split;
       get_kb(m, m->con_def_solref, m->con_def_solimp, lm.kb[0][0], lm.kb[0][1]);
       get_kb(m, m->con_cube_solref, m->con_cube_solimp, lm.kb[1][0], lm.kb[1][1]);
       lm.imp0[0] = impedance(m->con_def_solimp, 0.0);

@@ -14,23 +14,26 @@ names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mas
          "newton: start eval at qacc_smooth (when it beats the warm start)"]
 names += ["-"] * (NPH - len(names))
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
+env_id = sys.argv[2] if len(sys.argv) > 2 else "KManipSoloArm"          # 20-link ids: totals only (no per-workgroup view)
 n = 4096
-env = env_hip.make("KManipSoloArm", num_envs=n, seed=0, solver=solver)
+env = env_hip.make(env_id, num_envs=n, seed=0, solver=solver)
 import numpy as _np
 env.k_reset(); env.set_state(step=(_np.arange(n) % 64).astype(_np.int32))   # desynchronised episode phases (as bench.py)
 L = env.L
 gen = torch.Generator(device="cuda"); gen.manual_seed(0)
-acts = [(torch.rand((n, 7), generator=gen, device="cuda") * 2 - 1) for _ in range(8)]
+acts = [(torch.rand((n, env.cm.act_dim), generator=gen, device="cuda") * 2 - 1) for _ in range(8)]
 for k in range(80): env.step_flat(acts[k % 8])
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * NPH)()
-L.kmanip_dbg_prof(buf, 1)
+prof = L.kmanip_dbg_prof if env.cm.nlink == 10 else L.kmanip_dbg_prof20
+epb = 4 if env.cm.nlink == 10 else 2
+prof(buf, 1)
 steps = 32
 for k in range(steps): env.step_flat(acts[k % 8])
 torch.cuda.synchronize()
-L.kmanip_dbg_prof(buf, 0)
+prof(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
-nblocks = n // 4
+nblocks = n // epb
 per = v / nblocks / steps            # cycles (100 MHz memtime ticks?) per block per control step
 tot = per.sum()
 print("solver", solver, "total ticks per block per step %.0f" % tot)
@@ -41,7 +44,7 @@ for nm, x in zip(names, per):
 # slow as its slowest env in every phase.  Slot 13 ("integrate") of a group also holds its wait for the sibling envs.
 nb = n // 4
 blk = (C.c_ulonglong * (NPH * 4 * nb))()
-if hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) == 0:
+if env.cm.nlink == 10 and hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_prof_blocks(blk, nb) == 0:
     B = np.array(list(blk), dtype=np.float64).reshape(nb, 4, NPH)
     if os.environ.get("KM_PHASE_DUMP"):
         np.save(os.environ["KM_PHASE_DUMP"], B)
