@@ -381,11 +381,11 @@ __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int
 // 32 LDS writes and two synchronisations become 40 four-instruction runs.  Then the lane projects ITS composite's unit-
 // acceleration wrench onto its ancestors' joints (column `sub` of M, rows through LDS for the row-per-lane inversion) and its
 // subtree wrench onto its own joint (bias).
-template <int NL, int G>
-__device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel<NL>& lm, int sub, const real (&FN)[6]) {
-  static_assert(G == 16 && NL <= 16, "one DPP row per env");
-  const bool on = sub < NL;
-  const int b = on ? sub : 0;
+template <int NL, int W>
+__device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel<NL>& lm, int li, int base, const real (&FN)[6]) {
+  static_assert(W <= 16, "one DPP row per block");
+  const bool on = li >= 0;
+  const int b = on ? li : 0;
   real own[16];
   {
     const real mb = on ? lm.mass[b] : 0.0;
@@ -411,8 +411,8 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
   real acc[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) acc[k] = 0;
-  const uint32_t dm = on ? lm.desc[sub] : 0u;          // (bit `sub` is set: the link's own contribution)
-  static_for<0, NL>([&](auto jc) {
+  const uint32_t dm = on ? lm.desc[li] >> base : 0u;   // row-local bits (the link's own bit is set: its own contribution)
+  static_for<0, W>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const real take = ((dm >> j) & 1u) ? 1.0 : 0.0;
     dppfma4<false, j, j, j, j>(acc[0], own[0], take, acc[1], own[1], take, acc[2], own[2], take, acc[3], own[3], take);
@@ -421,7 +421,7 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
     dppfma4<false, j, j, j, j>(acc[12], own[12], take, acc[13], own[13], take, acc[14], own[14], take, acc[15], own[15], take);
   });
   if (on) {
-    const int j = sub;
+    const int j = li;
     const real* o = acc;
     const real ax[3] = {w.k.axis[j][0], w.k.axis[j][1], w.k.axis[j][2]};
     const real oj[3] = {w.k.xpos[j][0], w.k.xpos[j][1], w.k.xpos[j][2]};
@@ -444,7 +444,9 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
     }
     const uint32_t am = lm.anc[j];
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
+    for (int c = 0; c < W; c++) {
+      const int i = base + c;                  // rows of the block only: M has no entries between blocks
+      if (W != NL && i >= NL) continue;
       const real ai[3] = {w.k.axis[i][0], w.k.axis[i][1], w.k.axis[i][2]};
       const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
       cross3(t, oi, F);
@@ -567,28 +569,41 @@ __device__ __forceinline__ void bias_bodies_parallel(Ws<NL>& w, const LModel<NL>
 // One-row groups: the bias-wrench pass with the three ancestor sums as broadcast-FMAs (s += bcast_j(v) * [j in mask], link
 // order = root-to-leaf order) instead of LDS publish / synchronise / read rounds; the link's wrench stays in registers (FN).
 template <int NL, int G>
-__device__ __forceinline__ void anc_sum3(uint32_t mask, const real* v, real* s) {
+__device__ __forceinline__ void anc_sum3(uint32_t mask, const real* v, real* s) {      // (NL here = the row's width)
   static_for<0, NL>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const real take = ((mask >> j) & 1u) ? 1.0 : 0.0;
     dppfma3<false, j, j, j>(s[0], v[0], take, s[1], v[1], take, s[2], v[2], take);
   });
 }
-template <int NL, int G>
-__device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, real (&FN)[6]) {
-  static_assert(G == 16 && NL <= 16, "one DPP row per env");
-  const bool on = sub < NL;
-  const int i = on ? sub : 0;
+// cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
+template <int NL>
+__device__ __forceinline__ void cube_bias(Ws<NL>& w, const KModelDesc* m) {
+  real wc[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
+  real Iw[3] = {m->cube_inertia[0] * wc[0], m->cube_inertia[1] * wc[1], m->cube_inertia[2] * wc[2]}, t[3];
+  cross3(t, wc, Iw);
+#pragma unroll
+  for (int c = 0; c < 3; c++) { w.bias[NL + c] = -m->cube_mass * m->gravity[c]; w.bias[NL + 3 + c] = t[c]; }
+}
+// W = links per DPP row.  One-row groups: the row holds the whole robot (li = sub, base = 0, W = NL).  Two-row groups with a
+// block split (two-arm models): each row holds one block of the robot -- lane c of a row works on link li = base + c of ITS
+// block, masks are taken relative to the block's first link, and both blocks go through the same instructions at once.
+template <int NL, int W>
+__device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int li, int base, bool cube_lane, real (&FN)[6]) {
+  static_assert(W <= 16, "one DPP row per block");
+  constexpr int G = 16;
+  const bool on = li >= 0;
+  const int i = on ? li : 0;
   const bool slide = on && lm.jtype[i] == KM_JNT_SLIDE;
-  const uint32_t am = on ? lm.anc[i] : 0u, up = am & ~(1u << i);       // ancestors incl. self / proper ancestors
+  const uint32_t am = on ? lm.anc[i] >> base : 0u, up = am & ~(1u << (i - base));       // ancestors incl. self / proper ancestors (row-local bits)
   const real qv = on ? w.qvel[i] : 0.0;
   const real ax[3] = {w.k.axis[i][0] * qv, w.k.axis[i][1] * qv, w.k.axis[i][2] * qv};
   const real wv[3] = {(slide || !on) ? 0.0 : ax[0], (slide || !on) ? 0.0 : ax[1], (slide || !on) ? 0.0 : ax[2]};
   real wp[3] = {0, 0, 0}, cz[3], alp[3] = {0, 0, 0};
-  anc_sum3<NL, G>(up, wv, wp);
+  anc_sum3<W, G>(up, wv, wp);
   cross3(cz, wp, ax);
   const real czv[3] = {(slide || !on) ? 0.0 : cz[0], (slide || !on) ? 0.0 : cz[1], (slide || !on) ? 0.0 : cz[2]};
-  anc_sum3<NL, G>(up, czv, alp);
+  anc_sum3<W, G>(up, czv, alp);
   const int p = lm.parent[i];
   real op[3] = {0, 0, 0};
   if (on && p >= 0) { op[0] = w.k.xpos[p][0]; op[1] = w.k.xpos[p][1]; op[2] = w.k.xpos[p][2]; }
@@ -599,7 +614,7 @@ __device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm
 #pragma unroll
   for (int c = 0; c < 3; c++) db[c] = on ? t1[c] + t2[c] + (slide ? 2 * cz[c] : 0.0) : 0.0;
   real ai[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]};
-  anc_sum3<NL, G>(am, db, ai);
+  anc_sum3<W, G>(am, db, ai);
   if (on) {
     real wi[3] = {wp[0], wp[1], wp[2]}, ali[3] = {alp[0], alp[1], alp[2]};
     if (!slide) {
@@ -626,14 +641,7 @@ __device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm
   } else {
 #pragma unroll
     for (int c = 0; c < 6; c++) FN[c] = 0;
-    if (sub == NL) {
-      // cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
-      real wc[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
-      real Iw[3] = {m->cube_inertia[0] * wc[0], m->cube_inertia[1] * wc[1], m->cube_inertia[2] * wc[2]}, t[3];
-      cross3(t, wc, Iw);
-#pragma unroll
-      for (int c = 0; c < 3; c++) { w.bias[NL + c] = -m->cube_mass * m->gravity[c]; w.bias[NL + 3 + c] = t[c]; }
-    }
+    if (cube_lane) cube_bias<NL>(w, m);
   }
 }
 
@@ -1893,7 +1901,23 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   fk_parallel<NL, G>(w, lm, sub);
   pf.ph(0);
   real FN[6];
-  if constexpr (G == 16) bias_bodies_rows<NL, G>(w, lm, m, sub, FN);
+  // two-row groups with a block split: row r of the group = block r of the robot (lane c <-> link base + c) for the two tree
+  // passes; everything else keeps lane = dof
+  const int split = G == 32 ? lm.split : 0;
+  int bli = -1, bbase = 0;
+  if constexpr (G == 32) {
+    const int row = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+    bbase = row ? split : 0;
+    bli = (split && c < (row ? NL - split : split)) ? bbase + c : -1;
+    if (split) {                                 // entries between the blocks: never written below, read as part of the rows
+      for (int e = sub; e < NL * NL; e += G) (&w.Minv[0][0])[e] = 0.0;
+    }
+  }
+  if constexpr (G == 16) bias_bodies_rows<NL, NL>(w, lm, m, sub < NL ? sub : -1, 0, sub == NL, FN);
+  else if (split) {
+    bias_bodies_rows<NL, KM_BLOCK_MAX>(w, lm, m, bli, bbase, false, FN);
+    if (sub == NL) cube_bias<NL>(w, m);          // (lane NL also works on a link of the second block above)
+  }
   else bias_bodies_parallel<NL, G>(w, lm, m, sub);
   pf.ph(1);
   collide_parallel<NL, G>(w, m, sub);
@@ -1901,7 +1925,9 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   GSYNC();
   pf.ph(2);
   if constexpr (G == 16) {
-    composite_mass_bias_rows<NL, G>(w, lm, sub, FN);
+    composite_mass_bias_rows<NL, NL>(w, lm, sub < NL ? sub : -1, 0, FN);
+  } else if (split) {
+    composite_mass_bias_rows<NL, KM_BLOCK_MAX>(w, lm, bli, bbase, FN);
   } else {
     composite_own<NL, G>(w, lm, sub);      // (comp aliases the bias scratch: its last reader is before the barrier above)
     GSYNC();
