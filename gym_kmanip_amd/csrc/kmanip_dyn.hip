@@ -678,51 +678,61 @@ __device__ __forceinline__ void gj_cols(real (&upd)[N], const real (&a)[N], real
 // group runs an in-place Gauss-Jordan sweep (no pivoting: every pivot of an SPD matrix is a positive Schur
 // complement); row k reaches the other lanes through DPP row broadcasts, so there is no LDS traffic and no
 // synchronisation inside the n^2 loop.
-// Two-arm models: the trees [0, split) and [split, NL) share no dof, so the inertia is two diagonal blocks and both are
-// eliminated at once -- step t takes pivot t of EACH block (lanes of a block read their own pivot row: a wave shuffle with a
-// per-lane source instead of the broadcast of one row to everybody).  Each lane keeps only its block's columns, in
-// block-local order (compile-time register indices): <= KM_BLOCK_MAX steps of <= KM_BLOCK_MAX columns instead of NL x NL, and
-// the same operations per block in the same order as the full sweep does them (the off-block entries it carries are exact
+// In-place Gauss-Jordan sweep of the SPD matrix whose row `me` this lane holds in a[0..N) (one matrix per DPP row; no
+// pivoting: every pivot of an SPD matrix is a positive Schur complement).  Row k reaches the other lanes through DPP row
+// broadcasts, so there is no LDS traffic and no synchronisation inside the n^2 loop.
+template <int G, int N>
+__device__ __forceinline__ void gj_invert_rows(real (&a)[N], int me_idx, int& bad) {
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    real pk = gbcast<G, k>(a[k]);
+    if (!(pk > 0)) { bad = 1; pk = 1; }
+    const real d = frcp(pk);
+    const real aik = a[k];
+    const bool me = me_idx == k;
+    // a_ij - (a_ik / p) a_kj for every column j != k, row k arriving by DPP: all columns of a pivot are independent, so
+    // they go in runs of four behind one pair of wait states
+    real upd[N];
+    const real f = aik * d;
+#pragma unroll
+    for (int j = 0; j < N; j++) upd[j] = a[j];
+    gj_cols<G, k, 0, N>(upd, a, f);
+#pragma unroll
+    for (int j = 0; j < N; j++) if (j != k) a[j] = me ? a[j] * d : upd[j];
+    a[k] = me ? d : -aik * d;
+  });
+}
+
+// Two-arm models: the trees [0, split) and [split, NL) share no dof, so the inertia is two diagonal blocks.  Row r of the
+// group inverts block r (lane c <-> link base + c, the mapping of the tree passes; M comes from and goes back to LDS by link
+// index, so nothing has to be moved between lanes): two <= KM_BLOCK_MAX-pivot sweeps side by side with the one-row
+// broadcasts, instead of one NL-pivot sweep across two rows.  Lanes and columns beyond a block's size carry identity rows.
+// The same operations per block in the same order as the full sweep does them (the off-block entries it carries are exact
 // zeros), so the result is bitwise the same.
 template <int NL, int G>
 __device__ __forceinline__ void invert_mass_blocks(Ws<NL>& w, int sub, CReg<NL>& cr, int split) {
   constexpr int NB = KM_BLOCK_MAX;
-  const bool arm = sub < NL;
-  const int base = sub < split ? 0 : split, nb = sub < split ? split : NL - split, mine = sub - base;
+  const int row = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+  const int base = row ? split : 0, nb = row ? NL - split : split;
+  const bool on = c < nb;
+  const int li = base + c;
   real loc[NB];
 #pragma unroll
-  for (int j = 0; j < NL; j++) cr.mrow[j] = arm ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
+  for (int j = 0; j < NL; j++) cr.mrow[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
 #pragma unroll
-  for (int c = 0; c < NB; c++) {
-    const int j = base + c;
-    loc[c] = (arm && c < nb) ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;
+  for (int k = 0; k < NB; k++) {
+    const int j = base + k;
+    loc[k] = (on && k < nb) ? (j >= li ? w.Minv[li][j] : w.Minv[j][li]) : ((!on && k == c) ? 1.0 : 0.0);
   }
   GSYNC();
   int bad = 0;
-  const int lane0 = (threadIdx.x & 63) & ~(G - 1);
-  static_for<0, NB>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    const bool act = arm && t < nb;
-    const int src = lane0 + base + (t < nb ? t : 0);
-    real prow[NB];
-#pragma unroll
-    for (int c = 0; c < NB; c++) prow[c] = __shfl(loc[c], src, 64);
-    real pk = prow[t];
-    if (!(pk > 0)) { if (act) bad = 1; pk = 1; }
-    const real d = frcp(pk), aik = loc[t], f = aik * d;
-    const bool me = mine == t;
-    if (act) {
-#pragma unroll
-      for (int c = 0; c < NB; c++) if (c != t) loc[c] = me ? loc[c] * d : fma(-prow[c], f, loc[c]);
-      loc[t] = me ? d : -aik * d;
-    }
-  });
+  gj_invert_rows<16, NB>(loc, c, bad);
   if (__any(bad)) { const int gb = gor<G>(bad); if (gb && sub == 0) w.bad = 1; }      // (wave-uniform branch; never taken on sane models)
-  if (arm) {
+  if (on) {
 #pragma unroll
-    for (int j = 0; j < NL; j++) w.Minv[sub][j] = 0.0;
+    for (int j = 0; j < NL; j++) w.Minv[li][j] = 0.0;
 #pragma unroll
-    for (int c = 0; c < NB; c++) if (c < nb) w.Minv[sub][base + c] = loc[c];
+    for (int k = 0; k < NB; k++) if (k < nb) w.Minv[li][base + k] = loc[k];
   }
   GSYNC();
 }
@@ -737,24 +747,7 @@ __device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr, in
 #pragma unroll
   for (int j = 0; j < NL; j++) cr.mrow[j] = a[j];
   int bad = 0;
-  static_for<0, NL>([&](auto kc) {
-    constexpr int k = decltype(kc)::value;
-    real pk = gbcast<G, k>(a[k]);
-    if (!(pk > 0)) { bad = 1; pk = 1; }
-    const real d = frcp(pk);
-    const real aik = a[k];
-    const bool me = sub == k;
-    // a_ij - (a_ik / p) a_kj for every column j != k, row k arriving by DPP: all columns of a pivot are independent, so
-    // they go in runs of four behind one pair of wait states
-    real upd[NL];
-    const real f = aik * d;
-#pragma unroll
-    for (int j = 0; j < NL; j++) upd[j] = a[j];
-    gj_cols<G, k, 0, NL>(upd, a, f);
-#pragma unroll
-    for (int j = 0; j < NL; j++) if (j != k) a[j] = me ? a[j] * d : upd[j];
-    a[k] = me ? d : -aik * d;
-  });
+  gj_invert_rows<G, NL>(a, sub, bad);
   if (bad && sub == 0) w.bad = 1;
   if (sub < NL) {
 #pragma unroll
