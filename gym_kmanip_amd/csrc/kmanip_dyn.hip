@@ -1732,7 +1732,13 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
       });
       const unsigned long long bal = __ballot(in && (qf | ql));
       rows = (uint32_t)(bal >> ((threadIdx.x & 63) - sub)) & ((G == 32) ? 0xFFFFFFFFu : 0xFFFFu);
-      plain = !cq && __popc(rows) <= 2;
+      if constexpr (G == 32) {
+        // two-arm models: M^-1 is block diagonal, so the identity holds per block -- up to two quadratic rows in EACH block,
+        // every lane correcting with the rows of its own block
+        const uint32_t lowm = lm.split ? (1u << lm.split) - 1u : 0xFFFFFFFFu;
+        plain = !cq && __popc(rows & lowm) <= 2 && __popc(rows & ~lowm) <= 2;
+        rows &= (sub < lm.split || !lm.split) ? lowm : ~lowm;
+      } else plain = !cq && __popc(rows) <= 2;
     }
     if (plain) {
       real y = 0;

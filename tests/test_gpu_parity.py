@@ -147,25 +147,29 @@ def test_step_parity_vs_oracle(env, n, steps, solver):
 
 
 @pytest.mark.parametrize("env", ["KManipDualArm", "KManipTorso"])
-def test_block_inertia_inversion_is_bitwise_the_full_sweep(env, monkeypatch):
-    """Two-arm models: the joint-space inertia is two diagonal blocks (KModelAux.split) and the step inverts both at once;
-    KMANIP_NO_BLOCK_SPLIT=1 keeps the full 20 x 20 Gauss-Jordan sweep.  Same operations per block in the same order =>
-    bit-identical trajectories."""
+def test_block_structure_paths_agree_with_the_full_sweep(env, monkeypatch):
+    """Two-arm models: the joint-space inertia is two diagonal blocks (KModelAux.split).  The step then runs the tree passes
+    and the inversion one block per DPP row and applies the arm solve's Woodbury shortcut per block; KMANIP_NO_BLOCK_SPLIT=1
+    keeps the 20-dof code.  Same mathematics, different operation order: one-step agreement to roundoff on the same states."""
     torch = _torch()
     from gym_kmanip_amd import env_hip
-    n = 64
+    n = 256
     a = env_hip.make(env, num_envs=n, seed=4)
     monkeypatch.setenv("KMANIP_NO_BLOCK_SPLIT", "1")
     b = env_hip.make(env, num_envs=n, seed=4)
     monkeypatch.delenv("KMANIP_NO_BLOCK_SPLIT")
     a.k_reset(); b.k_reset()
     gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+    worst = 0.0
     for k in range(70):
         act = torch.rand((n, a.cm.act_dim), generator=gen, device="cuda") * 2 - 1
         a.step_flat(act); b.step_flat(act)
-    for x, y in zip(a.get_state(), b.get_state()):
-        assert np.array_equal(x, y)
-    assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
+        sa, sb = a.get_state(), b.get_state()
+        same_ctrl = ~(sa[2] != sb[2]).any(axis=1)                 # (a float32 ctrl flip legitimately moves an env by ~1e-5)
+        worst = max(worst, float(np.abs(sa[0] - sb[0])[same_ctrl].max()))
+        assert np.abs(sa[0] - sb[0])[same_ctrl].max() < 1e-9 and np.abs(sa[1] - sb[1])[same_ctrl].max() < 1e-7, k
+        assert np.array_equal(a.get_diag()[0], b.get_diag()[0]) and torch.equal(a.done, b.done), k
+        b.set_state(*sa)                                           # one-step samples
     a.k_close(); b.k_close()
 
 
