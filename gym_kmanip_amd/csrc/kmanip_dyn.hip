@@ -452,7 +452,11 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
       cross3(t, oi, F);
       const real mo[3] = {N[0] - t[0], N[1] - t[1], N[2] - t[2]};
       const real val = lm.jtype[i] == KM_JNT_SLIDE ? dot3(ai, F) : dot3(ai, mo);
-      w.Minv[i][j] = ((am >> i) & 1u) ? val : 0.0;
+      const real mij = ((am >> i) & 1u) ? val : 0.0;
+      if (i <= j) {                            // both triangles: the inversion then reads plain rows; entry (a, b) is written
+        w.Minv[i][j] = mij;                    // by the lane of link max(a, b) only
+        w.Minv[j][i] = mij;
+      }
     }
     // bias_j = axis_j . (subtree wrench about the joint)
     const real Fb[3] = {acc[10], acc[11], acc[12]};
@@ -710,21 +714,28 @@ __device__ __forceinline__ void gj_invert_rows(real (&a)[N], int me_idx, int& ba
 // The same operations per block in the same order as the full sweep does them (the off-block entries it carries are exact
 // zeros), so the result is bitwise the same.
 template <int NL, int G>
-__device__ __forceinline__ void invert_mass_blocks(Ws<NL>& w, int sub, CReg<NL>& cr, int split) {
+__device__ __forceinline__ void invert_mass_blocks(Ws<NL>& w, int sub, CReg<NL>& cr, int split, Prof& pf) {
   constexpr int NB = KM_BLOCK_MAX;
   const int row = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
   const int base = row ? split : 0, nb = row ? NL - split : split;
   const bool on = c < nb;
   const int li = base + c;
   real loc[NB];
+  {
+    // unconditional loads at clamped addresses, then selects on the values (conditional loads would each become a branch)
+    const int rs = sub < NL ? sub : NL - 1, rl = on ? li : NL - 1;
+    real full[NL], blk[NB];
 #pragma unroll
-  for (int j = 0; j < NL; j++) cr.mrow[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
+    for (int j = 0; j < NL; j++) full[j] = w.Minv[rs][j];
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
-    const int j = base + k;
-    loc[k] = (on && k < nb) ? (j >= li ? w.Minv[li][j] : w.Minv[j][li]) : ((!on && k == c) ? 1.0 : 0.0);
+    for (int k = 0; k < NB; k++) blk[k] = w.Minv[rl][base + k < NL ? base + k : NL - 1];
+#pragma unroll
+    for (int j = 0; j < NL; j++) cr.mrow[j] = sub < NL ? full[j] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) loc[k] = (on && k < nb) ? blk[k] : ((!on && k == c) ? 1.0 : 0.0);
   }
   GSYNC();
+  pf.ph(39);
   int bad = 0;
   gj_invert_rows<16, NB>(loc, c, bad);
   if (__any(bad)) { const int gb = gor<G>(bad); if (gb && sub == 0) w.bad = 1; }      // (wave-uniform branch; never taken on sane models)
@@ -738,11 +749,19 @@ __device__ __forceinline__ void invert_mass_blocks(Ws<NL>& w, int sub, CReg<NL>&
 }
 
 template <int NL, int G>
-__device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr, int split = 0) {
-  if constexpr (G == 32) { if (split) { invert_mass_blocks<NL, G>(w, sub, cr, split); return; } }
+__device__ __forceinline__ void invert_mass(Ws<NL>& w, int sub, CReg<NL>& cr, int split, Prof& pf) {
+  if constexpr (G == 32) { if (split) { invert_mass_blocks<NL, G>(w, sub, cr, split, pf); return; } }
   real a[NL];
+  if constexpr (G == 16) {                      // (composite_mass_bias_rows wrote both triangles: plain rows, unconditional loads)
+    const int rs = sub < NL ? sub : NL - 1;
 #pragma unroll
-  for (int j = 0; j < NL; j++) a[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
+    for (int j = 0; j < NL; j++) a[j] = w.Minv[rs][j];
+#pragma unroll
+    for (int j = 0; j < NL; j++) a[j] = sub < NL ? a[j] : 0.0;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NL; j++) a[j] = sub < NL ? (j >= sub ? w.Minv[sub][j] : w.Minv[j][sub]) : 0.0;   // columns hold the upper triangle
+  }
   GSYNC();
 #pragma unroll
   for (int j = 0; j < NL; j++) cr.mrow[j] = a[j];
@@ -1937,7 +1956,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   }
   GSYNC();
   pf.ph(3);
-  invert_mass<NL, G>(w, sub, cr, lm.split);
+  invert_mass<NL, G>(w, sub, cr, lm.split, pf);
   pf.ph(4);
   if constexpr (SOLVER == KM_SOLVER_NEWTON) build_constraints_newton<NL, G>(w, lm, m, sub, cr, invm);
   else build_constraints<NL, G>(w, lm, m, sub, cr, invm);

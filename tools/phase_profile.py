@@ -11,7 +11,7 @@ names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mas
          "newton: start evals"] + ["newton %s: %s" % (sb, ph) for sb in ("ALL", "ARM", "CUBE") for ph in ("H build", "chol", "tri-solve", "ls setup", "ls loop", "eval")] + [
          "integrate", "post-solve (sibling wait)", "load state", "before_step (decode + IK)", "tail (reward/obs/store)", "auto-reset",
          "IK: residual + Jacobian", "IK: normal matrix", "IK: trust-region solve", "IK: select_step", "IK: ratio / radius / tests",
-         "newton: start eval at qacc_smooth (when it beats the warm start)"]
+         "newton: start eval at qacc_smooth (when it beats the warm start)", "invert_mass: row loads (two-arm block path)"]
 names += ["-"] * (NPH - len(names))
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 env_id = sys.argv[2] if len(sys.argv) > 2 else "KManipSoloArm"          # 20-link ids: totals only (no per-workgroup view)
@@ -67,7 +67,7 @@ if env.cm.nlink == 10 and hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_
 # ---- the slowest waves one by one: which phase classes make them slow (summed over the wave's 4 groups where it is the max)
 if "B" in dir():
     ik = [30, 33, 34, 35, 36, 37]; allp = list(range(9, 15)); armp = list(range(15, 21)); cubep = list(range(21, 27))
-    fixed = [0, 1, 2, 3, 4, 5, 7, 8, 27, 38]
+    fixed = [0, 1, 2, 3, 4, 5, 7, 8, 27, 38, 39]
     print("slowest waves: total | per-group max of: IK, ALL loop, ARM loop, CUBE loop, fixed per-sub-step work")
     for wv in order[-16:][::-1]:
         g = B[wv]
