@@ -1388,38 +1388,52 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
     }
   }
   const uint32_t act = w.cact;
+  // ---- this lane's column of every active contact's Jacobian basis.  What a dof does to a point depends on the dof only
+  // through a direction A and, for rotations, a point O on the axis (an arm hinge: joint axis and origin; an arm slider: its
+  // axis; the cube: a world axis, or a body axis through the cube centre) -- fetched ONCE, unconditionally, before the slot
+  // loop; per slot the column is then a cross product and selects, no branches and no loads under conditions.
+  const bool armlane = sub < NL, cubelane = sub >= NL && sub < NV;
+  const int jl = armlane ? sub : 0, ce = cubelane ? sub - NL : 0;
+  const bool rot = armlane ? lm.jtype[jl] != KM_JNT_SLIDE : ce >= 3;
+  real A[3], O[3];
+  {
+    const real ax[3] = {w.k.axis[jl][0], w.k.axis[jl][1], w.k.axis[jl][2]}, xo[3] = {w.k.xpos[jl][0], w.k.xpos[jl][1], w.k.xpos[jl][2]};
+    const int k = ce >= 3 ? ce - 3 : 0;
+    const real col[3] = {w.k.cube_mat[k], w.k.cube_mat[3 + k], w.k.cube_mat[6 + k]};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      A[d] = armlane ? ax[d] : (ce >= 3 ? col[d] : (ce == d ? 1.0 : 0.0));
+      O[d] = armlane ? xo[d] : w.qpos[NL + d];
+    }
+  }
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
-    if (((act >> c) & 1u) && sub < NV) {
+    if ((act >> c) & 1u) {                                 // (group-uniform)
+      constexpr int dummy = 0; (void)dummy;
       const int kind = slot_kind<NL>(c);
-      if (kind == 0) {
-        // table plane (world) - cube corner: only the cube's six dofs move the point and the frame is the constant plane
-        // frame (rows n = +z, t1 = +y, t2 = -x), so the basis entries are components of the point's velocity columns
-        if (sub >= NL) {
-          const int e = sub - NL;
-          real dl[3] = {e == 0 ? 1.0 : 0.0, e == 1 ? 1.0 : 0.0, e == 2 ? 1.0 : 0.0}, drz = 0;
-          if (e >= 3) {
-            const int k = e - 3;
-            const real col[3] = {w.k.cube_mat[k], w.k.cube_mat[3 + k], w.k.cube_mat[6 + k]};
-            const real r[3] = {w.c_pos[c][0] - w.qpos[NL], w.c_pos[c][1] - w.qpos[NL + 1], w.c_pos[c][2] - w.qpos[NL + 2]};
-            cross3(dl, col, r);
-            drz = col[2];
-          }
-          cr.jb[c][0] = dl[2]; cr.jb[c][1] = dl[1]; cr.jb[c][2] = -dl[0]; cr.jb[c][3] = drz;
-        }
+      // geom1 / geom2: kind 0 table (world) / cube, kind 1 sphere's link / cube, kind 2 table (world) / sphere's link.  A lane
+      // belongs to at most one of the two bodies; its column is +J for geom2's body, -J for geom1's.
+      real sgn = 0;
+      if (kind == 0) sgn = cubelane ? 1.0 : 0.0;
+      else {
+        const uint32_t am = lm.anc[m->sphere_link[w.slot_sph[c]]];
+        const bool mine = armlane && ((am >> jl) & 1u);
+        sgn = kind == 1 ? (mine ? -1.0 : (cubelane ? 1.0 : 0.0)) : (mine ? 1.0 : 0.0);
+      }
+      const real r[3] = {w.c_pos[c][0] - O[0], w.c_pos[c][1] - O[1], w.c_pos[c][2] - O[2]};
+      real jp[3];
+      cross3(jp, A, r);
+#pragma unroll
+      for (int d = 0; d < 3; d++) jp[d] = sgn * (rot ? jp[d] : A[d]);
+      const real jr[3] = {rot ? sgn * A[0] : 0.0, rot ? sgn * A[1] : 0.0, rot ? sgn * A[2] : 0.0};
+      if (kind == 0) {                                     // constant plane frame: rows n = +z, t1 = +y, t2 = -x
+        cr.jb[c][0] = jp[2]; cr.jb[c][1] = jp[1]; cr.jb[c][2] = -jp[0]; cr.jb[c][3] = jr[2];
       } else {
-      const int link = m->sphere_link[w.slot_sph[c]];
-      const int b1 = kind == 1 ? link : -1, b2 = kind == 2 ? link : NL;
-      real pt[3] = {w.c_pos[c][0], w.c_pos[c][1], w.c_pos[c][2]};
-      real p1[3], r1[3], p2[3], r2[3];
-      point_jac_col<NL>(w, lm, b1, sub, pt, p1, r1);
-      point_jac_col<NL>(w, lm, b2, sub, pt, p2, r2);
-      real dl[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, dr[3] = {r2[0] - r1[0], r2[1] - r1[1], r2[2] - r1[2]};
-      cr.jb[c][0] = dot3(w.c_frame[c], dl);
-      cr.jb[c][1] = dot3(w.c_frame[c] + 3, dl);
-      cr.jb[c][2] = dot3(w.c_frame[c] + 6, dl);
-      cr.jb[c][3] = dot3(w.c_frame[c], dr);
+        cr.jb[c][0] = dot3(w.c_frame[c], jp);
+        cr.jb[c][1] = dot3(w.c_frame[c] + 3, jp);
+        cr.jb[c][2] = dot3(w.c_frame[c] + 6, jp);
+        cr.jb[c][3] = dot3(w.c_frame[c], jr);
       }
     }
   }
