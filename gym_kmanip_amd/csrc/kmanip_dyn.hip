@@ -1441,40 +1441,44 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   const real qv = sub < NV ? w.qvel[sub] : 0.0;
   real qlin[3], qangw[3];
   cube_part<NL, G>(w, qv, qlin, qangw);
+  // velocity projections of every active slot (group sums: the same on every lane); lane c keeps slot c's
+  real vb[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     if ((act >> c) & 1u) {
-      const int kind = slot_kind<NL>(c);
-      const bool cube = kind != 2;
-      const real* fr = cube ? m->con_cube_friction : m->con_def_friction;
-      const real* sr = cube ? m->con_cube_solref : m->con_def_solref;
-      const real* si = cube ? m->con_cube_solimp : m->con_def_solimp;
-      real mu[3] = {fr[0], fr[0], fr[1]};
-      const real Ad = kind == 0 ? lm.cornerA : lm.sphA[kind == 2][w.slot_sph[c]];   // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
-      real vb[4];
-      if (kind == 0) plane_proj<NL>(w, c, qlin, qangw, vb);
+      real v[4];
+      if (slot_kind<NL>(c) == 0) plane_proj<NL>(w, c, qlin, qangw, v);
       else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) vb[k] = gsum<G>(cr.jb[c][k] * qv);
+        for (int k = 0; k < 4; k++) v[k] = gsum<G>(cr.jb[c][k] * qv);
       }
-      const real dist = w.c_dist[c];
-      const real imp = impedance_c(lm.imp[cube ? 1 : 0], dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
-      (void)sr; (void)si;
-      if (sub == 0) {
-        ConRec& rc = w.rec[c];
-        rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad);
-        rc.D = frcp(rc.R);
-        if constexpr (G != 16) {                       // (one-row groups exchange the edge forces by DPP, not through f[])
 #pragma unroll
-          for (int e = 0; e < 6; e++) rc.f[e] = 0;     // edge forces (the unused edges of a condim-3 pair stay 0)
-        }
+      for (int k = 0; k < 4; k++) vb[k] = sub == c ? v[k] : vb[k];
+    }
+  }
+  // the solver record of slot `sub`, one slot per lane (all slots through ONE pass of the impedance / regulariser / reference
+  // acceleration arithmetic instead of one unrolled copy per slot)
+  if (sub < NC && ((act >> sub) & 1u)) {
+    const int c = sub, kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
+    const bool cube = kind != 2;
+    const real* fr = cube ? m->con_cube_friction : m->con_def_friction;
+    const real mu[3] = {fr[0], fr[0], fr[1]};
+    const int sp = kind == 0 ? 0 : w.slot_sph[c];
+    const real Ad = kind == 0 ? lm.cornerA : lm.sphA[kind == 2][sp];   // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
+    const real dist = w.c_dist[c];
+    const real imp = impedance_c(lm.imp[cube ? 1 : 0], dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
+    ConRec& rc = w.rec[c];
+    rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad);
+    rc.D = frcp(rc.R);
+    if constexpr (G != 16) {                       // (one-row groups exchange the edge forces by DPP, not through f[])
 #pragma unroll
-        for (int e = 0; e < 6; e++) {
-          const int k = e / 2 + 1;
-          const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
-          rc.aref[e] = -bb * (vb[0] + sm * vb[k]) - kk * imp * dist;
-        }
-      }
+      for (int e = 0; e < 6; e++) rc.f[e] = 0;     // edge forces (the unused edges of a condim-3 pair stay 0)
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+      const int k = e / 2 + 1;
+      const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
+      rc.aref[e] = -bb * (vb[0] + sm * vb[k]) - kk * imp * dist;
     }
   }
   GSYNC();
