@@ -132,7 +132,7 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
       bool ok = true;
       for (int i = s; i < d->nlink && ok; i++) ok = (x->anc_mask[i] & ((1u << s) - 1u)) == 0;
       const int big = s > d->nlink - s ? s : d->nlink - s;
-      if (ok && big <= KM_BLOCK_MAX && big < best) { best = big; x->split = s; }
+      if (ok && big <= KM_BLOCK_MAX && big < best && (s == 10 || s == 11)) { best = big; x->split = s; }   // (the two layouts the device code selects between: DualArm 10 + 10, Torso 11 + 9)
     }
   }
   for (int a = 0; a < KM_MAX_ARMS; a++) {

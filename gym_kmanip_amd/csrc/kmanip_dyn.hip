@@ -1807,11 +1807,49 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     // ---- p = -H^-1 grad
     real invd = 1;
     int hbad = 0;
+    bool blocks = false;
+    if constexpr (S == KM_SUB_ARM && G == 32) blocks = lm.split != 0;
+    if (blocks) {
+      // Two-arm models: the arm problem's Hessian has the inertia's two diagonal blocks (a finger / link sphere on the table
+      // touches one arm only).  Each DPP row factorises and solves ONE block with the one-row code: lane c of row r takes over
+      // row base_r + c of H (block-local columns) and that dof's gradient from the lane that built them, and hands the
+      // direction back -- 13 wave shuffles around two 11-pivot solves side by side instead of one 20-pivot solve across rows.
+      if constexpr (S == KM_SUB_ARM && G == 32) {
+        constexpr int NB = KM_BLOCK_MAX;
+        const int split = lm.split, lane0 = (threadIdx.x & 63) & ~31;
+        const int row = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+        const int base = row ? split : 0, nb = row ? NL - split : split;
+        const bool on = c < nb;
+        const int src = lane0 + (on ? base + c : 0);
+        real mine[NB], loc[NB];                                  // my dof's row of H in ITS block's column order
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          const real lo = h[k], hi = split == 10 ? h[(10 + k) < NL ? 10 + k : NL - 1] : h[(11 + k) < NL ? 11 + k : NL - 1];
+          mine[k] = sub < split ? lo : hi;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+          const real v = __shfl(mine[k], src, 64);
+          loc[k] = (on && k < nb) ? v : ((!on && k == c) ? 1.0 : 0.0);
+        }
+        const real gsrc = __shfl(in ? -grad : 0.0, src, 64);
+        real invl = 1;
+        chol_rows<16, NB, 0, NB>(loc, invl, c, hbad);
+        if (__any(hbad)) { const int gb = gor<G>(hbad); if (gb && sub == 0) w.bad = 1; }
+        pf.ph(10 + 6 * S);
+        const real pl = chol_solve_rows<16, NB, 0, NB>(loc, invl, c, on ? gsrc : 0.0);
+        const int back = lane0 + (sub < split ? sub : 16 + (sub < NL ? sub - split : 0));
+        const real pb = __shfl(pl, back, 64);
+        p = in ? pb : 0.0;
+        pf.ph(11 + 6 * S);
+      }
+    } else {
     chol_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, hbad);
     if (hbad && sub == 0) w.bad = 1;
     pf.ph(10 + 6 * S);
     p = chol_solve_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, in ? -grad : 0.0);
     pf.ph(11 + 6 * S);
+    }
     }
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
     real Mp;
