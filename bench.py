@@ -116,9 +116,17 @@ def algorithmic_bytes_per_env_step(cm, depth=0):
     return 2 * state + cm.act_dim * 4 + cm.obs_dim * 8 + 8 + 1 + depth * depth * 4
 
 
-def _committed(name_glob):
+def _committed(name_glob, version=None):
+    """The committed counter summary measured on library `version` (the last such file by name); without one, the last file
+    by name (its `_meta.version` then tells the caller that it is stale)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", name_glob)))
+    for f in reversed(files):
+        try:
+            if json.load(open(f)).get("_meta", {}).get("version") == version:
+                return f
+        except (OSError, ValueError):
+            pass
     return files[-1] if files else None
 
 
@@ -128,7 +136,7 @@ def committed_counters(version, kernel_prefix):
     last committed measurement of this kernel -- and only if that measurement was taken on the same library version
     (`_meta.version` in the file == kmanip_version()): a stale file is refused (None + `stale`)."""
     out = {"traffic": None, "traffic_source": None, "valu": None, "flops": None}
-    f = _committed("*_pmc_hbm.json")
+    f = _committed("*_pmc_hbm.json", version)
     if f:
         d = json.load(open(f))
         if d.get("_meta", {}).get("version") != version:
@@ -140,7 +148,7 @@ def committed_counters(version, kernel_prefix):
                     # (uncalibrated width): reported as counted, see DESIGN.md
                     out["traffic"] = (v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024.0
                     out["traffic_source"] = os.path.basename(f)
-    f = _committed("*_sq_counters.json")
+    f = _committed("*_sq_counters.json", version)
     if f:
         d = json.load(open(f))
         if d.get("_meta", {}).get("version") != version:
