@@ -32,10 +32,13 @@ DATA_DIR = os.environ.get("KMANIP_DATA_DIR", os.path.join(os.getcwd(), "data")) 
 DATE_FORMAT = "%mm%dd%Yy_%Hh%Mm"                                                    # __init__.py:15
 
 try:  # pragma: no cover - gymnasium is absent in the build image
+    import gymnasium as _gym
     from gymnasium import spaces as _spaces
     _HAVE_GYM = True
+    _EnvBase = _gym.Env                     # env_base.py:16: KManipEnv(gym.Env) -- what gym.make's wrappers expect
 except Exception:  # noqa: BLE001
     _HAVE_GYM = False
+    _EnvBase = object
 
 
 class Box:
@@ -83,7 +86,7 @@ def _dict(d):
     return _spaces.Dict(d) if _HAVE_GYM else DictSpace(d)
 
 
-class KManipEnv:
+class KManipEnv(_EnvBase):
     metadata = {"render_modes": ["rgb_array"], "render_fps": 30}
 
     def __init__(self, env_id: str = "KManipSoloArm", num_envs: int = 1, device: int = 0, seed: int = 0,
@@ -192,6 +195,8 @@ class KManipEnv:
         """env_base.py:219-239.  reset(seed=s) re-keys the cube-spawn stream and restarts its episode counter, so two resets
         with the same seed give the same first observation (the reference ignores the seed: its spawn draws from the global
         NumPy RNG, env_sim.py:34, and its ids are registered nondeterministic=True)."""
+        if _HAVE_GYM:  # pragma: no cover
+            super().reset(seed=seed)                                            # env_base.py:220 (seeds gymnasium's np_random)
         if seed is not None:
             self.seed = int(seed)
             self.env.set_seed(self.seed, restart_episodes=True)

@@ -81,3 +81,20 @@ def test_flat_layout_is_dict_insertion_order(env_id, stub_backend):
         assert (sl.start, sl.stop) == (col, col + sp.shape[0]), k
         col = sl.stop
     assert col == cm.obs_dim
+
+
+def test_package_entry_points_and_gymnasium_registration():
+    """gym_kmanip/__init__.py:244-483 registers eight ids with max_episode_steps = 64; register_envs() does the same when a
+    gymnasium module is there (a stand-in here: gymnasium is absent from the image)."""
+    import types
+    import gym_kmanip_amd as k
+    calls = []
+    fake = types.SimpleNamespace(register=lambda **kw: calls.append(kw))
+    ids = k.register_envs(fake, suffix="-HIP")
+    assert ids == [i + "-HIP" for i in k.ENV_IDS] and len(ids) == 8
+    assert {c["id"] for c in calls} == set(ids)
+    for c in calls:
+        assert c["max_episode_steps"] == 64 and c["nondeterministic"] is True
+        assert c["entry_point"] == "gym_kmanip_amd.gym_shell:KManipEnv"
+        assert c["kwargs"]["env_id"] + "-HIP" == c["id"] and c["kwargs"]["squeeze"] is True
+    assert callable(k.make) and callable(k.make_backend)
