@@ -513,13 +513,16 @@ def test_fused_and_split_launches_agree(env, monkeypatch):
         e.k_close()
 
 
-@pytest.mark.parametrize("n,epb", [(1, None), (5, None), (37, "1"), (37, "2"), (300, None)])
-def test_small_batches_and_launch_shapes(n, epb, monkeypatch):
-    """Ragged / tiny batches and every envs-per-workgroup launch shape (KMANIP_EPB) against the oracle."""
+@pytest.mark.parametrize("env,n,epb", [("KManipSoloArm", 1, None), ("KManipSoloArm", 5, None), ("KManipSoloArm", 37, "1"),
+                                       ("KManipSoloArm", 37, "2"), ("KManipSoloArm", 300, None),
+                                       ("KManipDualArm", 3, None), ("KManipDualArm", 21, "1"), ("KManipTorso", 21, "1"), ("KManipTorso", 33, None)])
+def test_small_batches_and_launch_shapes(env, n, epb, monkeypatch):
+    """Ragged / tiny batches and every envs-per-workgroup launch shape (KMANIP_EPB) against the oracle; on the two-arm models
+    also the half-wave workgroup (one env per workgroup) of the block-per-row code."""
     torch = _torch()
     if epb:
         monkeypatch.setenv("KMANIP_EPB", epb)
-    cm, dev, orc = _mk("KManipSoloArm", n, seed=21, off=7)
+    cm, dev, orc = _mk(env, n, seed=21, off=7)
     dev.k_reset(); orc.reset()
     rng = np.random.default_rng(n)
     for k in range(20):
