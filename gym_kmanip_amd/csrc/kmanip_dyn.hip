@@ -42,8 +42,9 @@ template <int NL> struct Dim {
   static constexpr int NS = 2 * NL;               // arm single-dof rows: friction loss (<= nl) + limits (<= nl)
   static constexpr int NSPH = 6 * (NL / 10);      // collision-sphere CANDIDATES, one lane each: per arm two fingers, palm, three joint housings
   static constexpr int NSS = KM_SPHERE_SLOTS(NL); // sphere contacts KEPT per kind and sub-step (the first penetrating ones in sphere order)
-  static constexpr int NC = 4 + 2 * NSS;          // contact SLOTS: 4 cube-table corners, NSS sphere-cube, NSS sphere-table
-  static constexpr int NCF = 2 * NSS;             // slots that involve arm dofs
+  static constexpr int NST = KM_SPHERE_TABLE_SLOTS(NL);   // ... of the sphere-table kind
+  static constexpr int NC = 4 + NSS + NST;        // contact SLOTS: 4 cube-table corners, NSS sphere-cube, NST sphere-table
+  static constexpr int NCF = NSS + NST;           // slots that involve arm dofs
 };
 // compile-time kind of contact slot c: 0 = table(plane) - cube corner, 1 = sphere - cube, 2 = table - sphere.  WHICH sphere sits
 // in a sphere slot is decided per sub-step by collide_parallel (Ws::slot_sph).
@@ -795,7 +796,7 @@ __device__ __forceinline__ void make_frame(real* fr) {
 // group's ballot bits), lanes 8..8+NSPH-1 their collision sphere against cube and table.
 template <int NL, int G>
 __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub) {
-  constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS;
+  constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS, NST = Dim<NL>::NST;
   static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
   const real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
@@ -871,7 +872,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     w.slot_sph[n] = s;
     mask |= KM_CON_SPHERE_CUBE(s); act |= 1u << n;
   }
-  if (hitt && __popc(mt) < NSS) {
+  if (hitt && __popc(mt) < NST) {
     const int n = 4 + NSS + __popc(mt);
     const real fr[9] = KM_PLANE_FRAME;
 #pragma unroll

@@ -32,10 +32,13 @@ extern "C" {
 #define KM_MAX_ARMS    2    /* arm 0 = right ("eer"), arm 1 = left ("eel")                         */
 #define KM_MAX_IK      7    /* IK unknowns per arm (7 solo/dual, 6 torso)                          */
 #define KM_MAX_SPHERES 12   /* sphere colliders per model: per arm two fingers, the palm and three joint housings */
-/* Contact slots the solver keeps per step: 4 cube corners on the table, plus KM_SPHERE_SLOTS sphere-cube and
- * KM_SPHERE_SLOTS sphere-table contacts -- the first penetrating spheres in sphere-index order (fingers come first);
- * a further penetrating sphere is dropped for that sub-step (its mask bit stays clear), like the 5th+ cube corner. */
+/* Contact slots the solver keeps per step: 4 cube corners on the table, KM_SPHERE_SLOTS sphere-cube contacts and
+ * KM_SPHERE_TABLE_SLOTS sphere-table contacts -- the first penetrating spheres in sphere-index order (fingers come first); a
+ * further penetrating sphere is dropped for that sub-step (its mask bit stays clear), like the 5th+ cube corner.  Two per arm
+ * and kind, except three per arm on the table for the two-arm models, whose hands rest on it (measured under random actions:
+ * the single arm never has more than two spheres on the table, the Torso up to six). */
 #define KM_SPHERE_SLOTS(nlink) (2 * ((nlink) / 10))
+#define KM_SPHERE_TABLE_SLOTS(nlink) ((nlink) >= 20 ? 6 : 2)
 #define KM_MAX_CAMS    4    /* cameras: 0 = grip_r, 1 = grip_l, 2 = top, 3 = head (__init__.py:157-161) */
 enum { KM_CAM_GRIP_R = 0, KM_CAM_GRIP_L = 1, KM_CAM_TOP = 2, KM_CAM_HEAD = 3 };
 #define KM_NQ_CUBE     7

@@ -220,25 +220,22 @@ def test_forearm_on_table_gpu():
 
 
 def _crowded(cm):
-    """A descriptor whose link spheres crowd the contact slots: on the 10-link model they are moved onto the two finger
-    links (so a finger on the table brings three candidates down at once), on the 20-link models they are doubled in size."""
+    """A descriptor whose link spheres crowd the contact slots: they are moved onto the finger links (next to the finger
+    spheres), so every finger on the table brings three candidates down at once."""
     from gym_kmanip_amd.model import KModelDesc
     d = KModelDesc.from_buffer_copy(cm.desc)
     nf = 2 * (cm.nlink // 10)
     for s in range(nf, d.nsphere):
-        if cm.nlink == 10:
-            d.sphere_link[s] = d.sphere_link[s % nf]
-            for k in range(3):
-                d.sphere_pos[s][k] = d.sphere_pos[s % nf][k] + 0.004 * (s - nf + 1) * (1 if k == s % 3 else 0)
-            d.sphere_radius[s] = 0.012
-        else:
-            d.sphere_radius[s] *= 2.0
+        d.sphere_link[s] = d.sphere_link[s % nf]
+        for k in range(3):
+            d.sphere_pos[s][k] = d.sphere_pos[s % nf][k] + 0.004 * ((s - nf) // nf + 1) * (1 if k == s % 3 else 0)
+        d.sphere_radius[s] = 0.012
     return type(cm)(**{**cm.__dict__, "desc": d})
 
 
 @pytest.mark.parametrize("env,n", [("KManipSoloArm", 32), ("KManipTorso", 16)])
 def test_sphere_slot_overflow_parity(env, n):
-    """KM_SPHERE_SLOTS: with more penetrating spheres than slots, device and oracle keep the same ones (the first in sphere
+    """KM_SPHERE_SLOTS / KM_SPHERE_TABLE_SLOTS: with more penetrating spheres than slots, device and oracle keep the same ones (the first in sphere
     order) -- contact masks bit-exact, states within tolerance -- on a model rigged so that this happens often."""
     torch = _torch()
     from gym_kmanip_amd import env_hip
@@ -249,7 +246,8 @@ def test_sphere_slot_overflow_parity(env, n):
     dev = env_hip.KManipEnvHip(cm, num_envs=n, seed=5, env_id_offset=7); orc = Oracle(cm, n, seed=5, env_id_offset=7)
     dev.k_reset(); orc.reset()
     rng = np.random.default_rng(43)
-    nss = 2 * (cm.nlink // 10)
+    nss = 2 * (cm.nlink // 10)                                  # KM_SPHERE_SLOTS (sphere-cube)
+    nst = 2 if cm.nlink == 10 else 6                            # KM_SPHERE_TABLE_SLOTS
     full = over = 0
     resync = [0]
     for k in range(40):
@@ -261,14 +259,14 @@ def test_sphere_slot_overflow_parity(env, n):
         assert np.array_equal(mg, mo), (k, mg, mo)
         assert np.array_equal(dev.done.cpu().numpy(), do), k
         tab = np.array([bin(int(m) >> 20).count("1") for m in mg]); cub = np.array([bin((int(m) >> 8) & 0xFFF).count("1") for m in mg])
-        assert tab.max() <= nss and cub.max() <= nss
-        full += int((tab == nss).sum())
+        assert tab.max() <= nst and cub.max() <= nss
+        full += int((tab == nst).sum())
         qpos = orc.get_state()[0]
-        for e in np.where(tab == nss)[0]:                       # slots full: were more spheres down than were kept?
+        for e in np.where(tab == nst)[0]:                       # slots full: were more spheres down than were kept?
             xpos, xquat, _, _ = orc.fk(qpos[e])
             down = sum((xpos[d.sphere_link[s]] + S.quat2mat(xquat[d.sphere_link[s]]) @ np.array(d.sphere_pos[s]))[2]
                        - d.sphere_radius[s] < d.table_z for s in range(d.nsphere))
-            over += int(down > nss)
+            over += int(down > nst)
     assert full > 0 and over > 0, (full, over)
     assert resync[0] <= 1, resync
     dev.k_close()
