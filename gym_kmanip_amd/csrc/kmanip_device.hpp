@@ -36,6 +36,16 @@ struct KDeviceModel {
 
 typedef double real;
 
+// XCD-aware workgroup -> env-block mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), and
+// the state is stored field-major ([field][env]): a workgroup's few envs touch 32 B of every 64-128 B line, its neighbours in
+// env order the rest.  Giving each XCD a CONTIGUOUS range of env blocks keeps those neighbours behind the same L2, so a line is
+// fetched from HBM once instead of once per XCD (measured: FETCH_SIZE per k_step launch 5.6 MB -> see profiles/).  A bijection
+// of [0, nblocks) for any nblocks; the results do not depend on it (envs are independent).
+__device__ __forceinline__ int xcd_block(int b, int nblocks) {
+  const int x = b & 7, i = b >> 3, base = nblocks >> 3, rem = nblocks & 7;
+  return x * base + (x < rem ? x : rem) + i;
+}
+
 
 __device__ __forceinline__ real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(real* r, const real* a, const real* b) {

@@ -2188,7 +2188,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
-  const int env = blockIdx.x * EPB + grp;
+  const int env = xcd_block(blockIdx.x, gridDim.x) * EPB + grp;
   if (grp >= EPB || env >= st.num_envs) return;     // whole group exits together
   Ws<NL>& w = ws[grp];
   CReg<NL> cr;
@@ -2311,7 +2311,7 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
-  const int env = blockIdx.x * EPB + grp;
+  const int env = xcd_block(blockIdx.x, gridDim.x) * EPB + grp;
   if (grp >= EPB || env >= st.num_envs) return;
   if (mask && !mask[env]) return;
   Ws<NL>& w = ws[grp];
