@@ -39,7 +39,7 @@ typedef double real;
 // XCD-aware workgroup -> env-block mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), and
 // the state is stored field-major ([field][env]): a workgroup's few envs touch 32 B of every 64-128 B line, its neighbours in
 // env order the rest.  Giving each XCD a CONTIGUOUS range of env blocks keeps those neighbours behind the same L2, so a line is
-// fetched from HBM once instead of once per XCD (measured: FETCH_SIZE per k_step launch 5.6 MB -> see profiles/).  A bijection
+// fetched from HBM once instead of once per XCD (measured: FETCH_SIZE per k_step launch 5.6 MB -> 3.2 MB, profiles/r02f_pmc_hbm.json).  A bijection
 // of [0, nblocks) for any nblocks; the results do not depend on it (envs are independent).
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
   const int x = b & 7, i = b >> 3, base = nblocks >> 3, rem = nblocks & 7;
