@@ -992,7 +992,6 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
   // ---- J columns (needs kinematics, which the Gram tables will overwrite: finish all slots first)
 #pragma unroll
   for (int c = 0; c < NC; c++) {
-    constexpr int dummy = 0; (void)dummy;
     cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
     if (((act >> c) & 1u) && sub < NV) {
       const int kind = slot_kind<NL>(c);
@@ -1411,7 +1410,6 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   for (int c = 0; c < NC; c++) {
     cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
     if ((act >> c) & 1u) {                                 // (group-uniform)
-      constexpr int dummy = 0; (void)dummy;
       const int kind = slot_kind<NL>(c);
       // geom1 / geom2: kind 0 table (world) / cube, kind 1 sphere's link / cube, kind 2 table (world) / sphere's link.  A lane
       // belongs to at most one of the two bodies; its column is +J for geom2's body, -J for geom1's.
