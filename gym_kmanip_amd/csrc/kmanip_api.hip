@@ -311,6 +311,15 @@ int kmanip_scripted_action(KHandle h, float* act_dev, void* stream) {
   return 0;
 }
 
+int kmanip_sample_action(KHandle h, float* act_dev, int ahead, void* stream) {
+  if (!h || !act_dev || ahead < 0) { if (h) h->err = "kmanip_sample_action: null buffer / negative ahead"; return -1; }
+  if (h->desc.act_dim > 16) { h->err = "kmanip_sample_action: act_dim > 16"; return -1; }
+  KM_ENTER(h);
+  kmanip_launch_sample_action(h->dmodel, h->st, act_dev, ahead, (hipStream_t)stream);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 int kmanip_enable_timing(KHandle h, int enable) {
   if (!h) return -1;
   KM_ENTER(h);

@@ -174,8 +174,10 @@ __device__ __forceinline__ void normalize4_fast(real* q) {
 // cross-lane double move with a DPP control word (a DPP row is 16 lanes)
 template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  // (old = 0 with bound_ctrl: every control used here reads a lane of the row, so the old value never shows -- and the
+  // compiler need not copy the source into the destination first: 2 instead of 4 instructions per 64-bit move)
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // broadcast of lane K's value (K compile-time) to every lane of its G-lane group, registers only:
@@ -184,7 +186,7 @@ template <int CTRL> __device__ __forceinline__ real dpp_f64(real v) {
 template <int G, int K> __device__ __forceinline__ real gbcast(real v) {
   static_assert(G == 8 || G == 16 || G == 32, "group = half a DPP row, one row or two rows");
   if constexpr (G == 32) {
-    const real b = __builtin_amdgcn_update_dpp(v, v, 0x150 + (K & 15), 0xF, 0xF, false);
+    const real b = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + (K & 15), 0xF, 0xF, true);
     const unsigned lo = (unsigned)__double2loint(b), hi = (unsigned)__double2hiint(b);
     const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
     const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
@@ -192,7 +194,7 @@ template <int G, int K> __device__ __forceinline__ real gbcast(real v) {
     return __hiloint2double((int)rh[w], (int)rl[w]);
   } else {
     // one v_mov_b64_dpp: gfx90a+ DPP on 64-bit operands exists for exactly this control (row_newbcast)
-    return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false);      // G == 8 callers pass K already offset into the row
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true);      // G == 8 callers pass K already offset into the row
   }
 }
 // acc += bcast_K(x) * t in ONE instruction: v_fmac_f64 with the DPP row_newbcast modifier on its first source (the
@@ -246,44 +248,49 @@ template <bool NEG, int K0, int K1, int K2, int K3>
 __device__ __forceinline__ void dppfma4(real& a0, real x0, real t0, real& a1, real x1, real t1, real& a2, real x2, real t2, real& a3, real x3, real t3) {
   if constexpr (NEG)
     asm("s_nop 1\n\t" KM_DPPF("-", 0, 4, 8, 12) KM_DPPF("-", 1, 5, 9, 13) KM_DPPF("-", 2, 6, 10, 14) KM_DPPF("-", 3, 7, 11, 15)
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
   else
     asm("s_nop 1\n\t" KM_DPPF("", 0, 4, 8, 12) KM_DPPF("", 1, 5, 9, 13) KM_DPPF("", 2, 6, 10, 14) KM_DPPF("", 3, 7, 11, 15)
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
 }
 template <bool NEG, int K0, int K1, int K2>
 __device__ __forceinline__ void dppfma3(real& a0, real x0, real t0, real& a1, real x1, real t1, real& a2, real x2, real t2) {
   if constexpr (NEG)
     asm("s_nop 1\n\t" KM_DPPF("-", 0, 3, 6, 9) KM_DPPF("-", 1, 4, 7, 10) KM_DPPF("-", 2, 5, 8, 11)
-        : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
   else
     asm("s_nop 1\n\t" KM_DPPF("", 0, 3, 6, 9) KM_DPPF("", 1, 4, 7, 10) KM_DPPF("", 2, 5, 8, 11)
-        : "+v"(a0), "+v"(a1), "+v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
 }
 template <bool NEG, int K0, int K1>
 __device__ __forceinline__ void dppfma2(real& a0, real x0, real t0, real& a1, real x1, real t1) {
   if constexpr (NEG)
-    asm("s_nop 1\n\t" KM_DPPF("-", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 7) : "+v"(a0), "+v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+    asm("s_nop 1\n\t" KM_DPPF("-", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 7) : "+&v"(a0), "+&v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
   else
-    asm("s_nop 1\n\t" KM_DPPF("", 0, 2, 4, 6) KM_DPPF("", 1, 3, 5, 7) : "+v"(a0), "+v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+    asm("s_nop 1\n\t" KM_DPPF("", 0, 2, 4, 6) KM_DPPF("", 1, 3, 5, 7) : "+&v"(a0), "+&v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+}
+// ap += bcast_K(xp) * tp ; an -= bcast_K(xn) * tn (one run, two accumulators, one lane K)
+template <int K>
+__device__ __forceinline__ void dppfma_pn(real& ap, real xp, real tp, real& an, real xn, real tn) {
+  asm("s_nop 1\n\t" KM_DPPF("", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 6) : "+&v"(ap), "+&v"(an) : "v"(xp), "v"(xn), "v"(tp), "v"(tn), "n"(K));
 }
 // acc += sum_i bcast_K(x_i) * t_i, i = 0..NS-1 (one accumulator, NS = 3 or 4 sources, one lane K), in this order
 template <int K>
 __device__ __forceinline__ void dppfma_acc4(real& acc, real x0, real t0, real x1, real t1, real x2, real t2, real x3, real t3) {
   asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 9) KM_DPPF("", 0, 3, 7, 9) KM_DPPF("", 0, 4, 8, 9)
-      : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K));
+      : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K));
 }
 template <int K>
 __device__ __forceinline__ void dppfma_acc3(real& acc, real x0, real t0, real x1, real t1, real x2, real t2) {
   asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 4, 7) KM_DPPF("", 0, 2, 5, 7) KM_DPPF("", 0, 3, 6, 7)
-      : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K));
+      : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K));
 }
 // acc += sum_i bcast_{K_i}(x) * t_i, i = 0..3: four lanes of ONE distributed vector against four coefficients (a row-times-
 // vector product), in this order
 template <int K0, int K1, int K2, int K3>
 __device__ __forceinline__ void dppfma_row4(real& acc, real x0, real x1, real x2, real x3, real t0, real t1, real t2, real t3) {
   asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 10) KM_DPPF("", 0, 3, 7, 11) KM_DPPF("", 0, 4, 8, 12)
-      : "+v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+      : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
 }
 // acc += sum_{j in [J0, J1)} bcast_j(x) * row(j), row given as a callable (registers or LDS), runs of four then singles
 template <int G, int J0, int J1, class ROW>
@@ -362,6 +369,12 @@ __device__ __host__ inline double u53(uint32_t hi, uint32_t lo) {
   return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) / 9007199254740992.0;
 }
 
+// action_space.sample() of a Box(-1, 1, float32) component from 32 random bits: ((r >> 8) - 2^23) * 2^-23, exact in float32
+// (a 24-bit signed integer times a power of two), so the device and the CPU oracle produce identical bits
+__device__ __host__ inline float km_action_from_u32(uint32_t r) { return (float)((int32_t)(r >> 8) - 8388608) * (1.0f / 8388608.0f); }
+// counter word 3 of the action stream: the cube spawn uses 0 and 1 (reset_env), actions 0x10000 + 4 * step + block
+#define KM_ACT_CTR3(step, blk) (0x10000u + 4u * (uint32_t)(step) + (uint32_t)(blk))
+
 // Device state, struct-of-arrays over envs: element (k, env) of an [n_k, num_envs] array is at
 // k * num_envs + env, so a wave reading component k for consecutive envs is fully coalesced.
 struct KDeviceState {
@@ -405,3 +418,4 @@ void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, 
 void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, uint8_t* rgb,
                               hipStream_t stream);
 void kmanip_launch_scripted_action(const KDeviceModel* dm, const KDeviceState& st, float* act, hipStream_t stream);
+void kmanip_launch_sample_action(const KDeviceModel* dm, const KDeviceState& st, float* act, int ahead, hipStream_t stream);

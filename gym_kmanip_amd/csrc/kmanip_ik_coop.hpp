@@ -51,16 +51,14 @@ __device__ __forceinline__ bool gall8(bool pred) {
 }
 
 // value of lane K (0..7) of this lane's problem on every lane of the problem, registers only (one problem per DPP row)
-template <int K> __device__ __forceinline__ real bcast8(real v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, false); }
+template <int K> __device__ __forceinline__ real bcast8(real v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xF, 0xF, true); }
 // acc += bcast8<K>(x) * t with the broadcast folded into the FMA
 template <int K> __device__ __forceinline__ void fmac_bcast8(real& acc, real x, real t) { fmac_bcast16<K>(acc, x, t); }
 
-// per-problem LDS scratch
+// per-problem LDS scratch: the site link's world transform, published by the lane that ends the chain product
 template <int N>
 struct CoopLds {
-  real A[N][N];        // normal matrix J_h^T J_h + C (row c written by lane c)
-  real J[6][GI];       // all-gather of the task Jacobian (column c written by lane c)
-  real v0[GI], v1[GI], v2[GI];   // all-gather buffers for n-vectors
+  real pub[12];
 };
 
 template <int N>
@@ -91,16 +89,6 @@ __device__ __forceinline__ void coop_chain_setup(CoopCtx<N>& P) {
 }
 // value of lane (c - S) of the same 8-lane problem (garbage for c < S: callers mask); DPP row_shr
 template <int S> __device__ __forceinline__ real shr8(real v) { return dpp_f64<0x110 + S>(v); }
-
-// all-gather of one value per lane into out[0..N)
-template <int N>
-__device__ __forceinline__ void allgather(real* buf, int c, real v, real* out) {
-  buf[c] = v;
-  KM_GSYNC();
-#pragma unroll
-  for (int i = 0; i < N; i++) out[i] = buf[i];
-  KM_GSYNC();
-}
 
 // ik_res (+ ik_jac when JAC): residual task part ft[6] (uniform), this lane's Jacobian column Jc[6],
 // site position / rotation (uniform).  x = this lane's unknown.
@@ -153,7 +141,7 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
     }
   });
   // lane GI-1 holds the product over the whole chain (positions >= clen are identities)
-  real* pub = &P.L->J[0][0];
+  real* pub = P.L->pub;
   if (P.c == GI - 1) {
 #pragma unroll
     for (int i = 0; i < 9; i++) pub[i] = R[i];
@@ -238,98 +226,98 @@ __device__ __forceinline__ real coop_grad(const CoopCtx<N>& P, real x, const rea
   return s + P.m->ik_jac_reg * (P.m->ik_res_reg_prev * (x - P.q_prev) + P.m->ik_res_reg_home * (x - P.q_home));
 }
 
-// redundant-per-lane Cholesky of (A + alpha I) with A read from the problem's LDS copy; L in registers, the
-// diagonal stored INVERTED (L[j][j] = 1 / l_jj) so that the triangular solves multiply instead of divide
+// ---- trust-region subproblem, cooperative over the problem's 8 lanes (round 3; round 2 factorised the 7 x 7 redundantly in
+// every lane from an LDS copy: 77 doubles of registers per lane, and the reason k_step needed > 256 of them).
+// Lane c holds ROW c of the symmetric normal matrix (arow) and, after a factorisation, row c of L (h[j], j <= c), row c of
+// L^T (ut[j] = L[j][c], j > c) and 1 / L[c][c].  Column k of L reaches the other lanes by row broadcasts folded into the FMAs;
+// lane k picks its row of L^T up from the same broadcasts (ut[j] += bcast_j(l) * [c == k]), which makes BOTH triangular
+// solves column-oriented: one multiply and one broadcast-FMA per pivot, no lane reductions.  Lanes >= N carry zero rows and
+// stay inert.
+template <int N> struct TrFac { real h[N], hm[N], ut[N], invd; };
 template <int N>
-__device__ __forceinline__ bool chol_reg(const real (&A)[N][N], real alpha, real (*L)[N]) {
+__device__ __forceinline__ bool chol_coop(const real (&arow)[N], real alpha, int c, TrFac<N>& F) {
   bool ok = true;
 #pragma unroll
-  for (int j = 0; j < N; j++) {
-    // (two partial sums: the dependent chain of the inner products is what this redundant per-lane factorisation costs)
-    real s0 = A[j][j] + alpha, s1 = 0;
+  for (int j = 0; j < N; j++) { F.h[j] = arow[j] + (j == c ? alpha : 0.0); F.ut[j] = 0; }
+  F.invd = 0;
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    real dk = bcast8<k>(F.h[k]);
+    if (!(dk > 0)) { ok = false; dk = 1; }             // (uniform over the problem: dk is a broadcast)
+    const real inv = rsqrt_nr(dk);
+    const real lik = F.h[k] * inv;                     // lanes i >= k: L[i][k]
+    F.h[k] = lik;
+    const bool me = c == k;
+    F.invd = me ? inv : F.invd;
+    const real isk = me ? 1.0 : 0.0;
+    static_for<k + 1, N>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      dppfma_pn<j>(F.ut[j], lik, isk, F.h[j], lik, lik);             // ut[j] += L[j][k] [c == k];  h[j] -= L[j][k] L[c][k]
+    });
+  });
+  // the strictly-lower part of the lane's row, zero elsewhere: the forward substitution's multipliers need no lane tests
 #pragma unroll
-    for (int k = 0; k < j; k++) { if (k & 1) s1 -= L[j][k] * L[j][k]; else s0 -= L[j][k] * L[j][k]; }
-    real s = s0 + s1;
-    if (!(s > 0)) { ok = false; s = 1; }
-    const real inv = rsqrt_nr(s);
-    L[j][j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < N; i++) {
-      real t0 = A[i][j], t1 = 0;
-#pragma unroll
-      for (int k = 0; k < j; k++) { if (k & 1) t1 -= L[i][k] * L[j][k]; else t0 -= L[i][k] * L[j][k]; }
-      L[i][j] = (t0 + t1) * inv;
-    }
-  }
+  for (int j = 0; j < N; j++) F.hm[j] = c > j ? F.h[j] : 0.0;
   return ok;
 }
+// z = L^-1 b (b, z distributed one component per lane)
 template <int N>
-__device__ __forceinline__ void chol_solve_reg(const real (*L)[N], const real* b, real* x) {
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    real s = b[i];
-#pragma unroll
-    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
-    x[i] = s * L[i][i];
-  }
-#pragma unroll
-  for (int i = N - 1; i >= 0; i--) {
-    real s = x[i];
-#pragma unroll
-    for (int k = i + 1; k < N; k++) s -= L[k][i] * x[k];
-    x[i] = s * L[i][i];
-  }
+__device__ __forceinline__ real tr_fwd(const TrFac<N>& F, real b) {
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const real t = b * F.invd;                         // lane k's t is z_k (its b is final: hm[j] = 0 for j >= c)
+    fnmac_bcast16<k>(b, t, F.hm[k]);
+  });
+  return b * F.invd;
 }
-template <int N> __device__ __forceinline__ real vdotN(const real* a, const real* b) {
-  real s = 0;
-#pragma unroll
-  for (int i = 0; i < N; i++) s += a[i] * b[i];
-  return s;
+// x = L^-T z
+template <int N>
+__device__ __forceinline__ real tr_bwd(const TrFac<N>& F, real z) {
+  static_for<0, N>([&](auto kc) {
+    constexpr int k = N - 1 - decltype(kc)::value;
+    const real t = z * F.invd;                         // lane k's t is x_k (ut[j] = 0 for j <= c: later pivots leave it alone)
+    fnmac_bcast16<k>(z, t, F.ut[k]);
+  });
+  return z * F.invd;
 }
 
-// scipy common.py solve_lsq_trust_region on the normal matrix (redundant per lane; full vectors in registers)
+// scipy common.py solve_lsq_trust_region on the normal matrix: p = argmin of the model in the ball |p| <= Delta by More's
+// iteration on the secular equation, phi = |p(alpha)| - Delta, phi' = -|L^-1 p|^2 / |p| (SciPy evaluates the same two
+// numbers from its SVD).  g_h, p: this lane's components.
 template <int N>
-__device__ __forceinline__ void solve_tr_reg(const real (*Alds)[N], const real* g_h, real Delta, real& alpha, real* p) {
-  real L[N][N], ng[N], w[N];
-  // the normal matrix (lower triangle) once into registers: every factorisation below (up to twelve) reads it
-  real A[N][N];
-#pragma unroll
-  for (int i = 0; i < N; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++) A[i][j] = Alds[i][j];
-#pragma unroll
-  for (int i = 0; i < N; i++) ng[i] = -g_h[i];
-  bool full_rank = chol_reg<N>(A, 0.0, L);
+__device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], int c, real g_h, real Delta, real& alpha, real& p) {
+  TrFac<N> F;
+  const real ng = -g_h;
+  const bool full_rank = chol_coop<N>(arow, 0.0, c, F);
+  real pn = 0;
   if (full_rank) {
-    chol_solve_reg<N>(L, ng, p);
-    if (sqrt(vdotN<N>(p, p)) <= Delta) { alpha = 0.0; return; }
+    p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
+    pn = sqrt(gsum8(p * p));
+    if (pn <= Delta) { alpha = 0.0; return; }
   }
-  real alpha_upper = sqrt(vdotN<N>(g_h, g_h)) / Delta, alpha_lower = 0.0;
+  real alpha_upper = sqrt(gsum8(g_h * g_h)) / Delta, alpha_lower = 0.0;
   if (full_rank) {
-    real pn = sqrt(vdotN<N>(p, p));
-    chol_solve_reg<N>(L, p, w);
-    real phi = pn - Delta, phip = -vdotN<N>(p, w) / pn;
+    const real q = tr_fwd<N>(F, p);
+    const real phi = pn - Delta, phip = -gsum8(q * q) / pn;
     alpha_lower = -phi / phip;
   }
   if (!full_rank && alpha == 0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
   for (int it = 0; it < 10; it++) {
     if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-    chol_reg<N>(A, alpha, L);
-    chol_solve_reg<N>(L, ng, p);
-    real pn = sqrt(vdotN<N>(p, p));
-    chol_solve_reg<N>(L, p, w);
-    real phi = pn - Delta, phip = -vdotN<N>(p, w) / pn;
+    chol_coop<N>(arow, alpha, c, F);
+    p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
+    pn = sqrt(gsum8(p * p));
+    const real q = tr_fwd<N>(F, p);
+    const real phi = pn - Delta, phip = -gsum8(q * q) / pn;
     if (phi < 0) alpha_upper = alpha;
-    real ratio = phi / phip;
+    const real ratio = phi / phip;
     alpha_lower = fmax(alpha_lower, alpha - ratio);
     alpha -= (phi + Delta) * ratio / Delta;
     if (fabs(phi) < 0.01 * Delta) break;
   }
-  chol_reg<N>(A, alpha, L);
-  chol_solve_reg<N>(L, ng, p);
-  real sc = Delta / sqrt(vdotN<N>(p, p));
-#pragma unroll
-  for (int i = 0; i < N; i++) p[i] *= sc;
+  chol_coop<N>(arow, alpha, c, F);
+  p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
+  p *= Delta / sqrt(gsum8(p * p));
 }
 
 __device__ __forceinline__ void min_quad_1d_c(real a, real b, real lo, real hi, real c, real& t_out, real& y_out) {
@@ -343,13 +331,11 @@ __device__ __forceinline__ void min_quad_1d_c(real a, real b, real lo, real hi, 
   t_out = tb; y_out = yb;
 }
 
-// (A v)_c for this lane's row of A (A in LDS), v given as a full vector
+// (A v)_c = sum_j A[c][j] v_j: this lane's row of A (registers) against a vector distributed one component per lane
 template <int N>
-__device__ __forceinline__ real arow_dot(const CoopCtx<N>& P, const real* vfull) {
-  if (!P.on) return 0.0;
+__device__ __forceinline__ real arow_dot(const real (&arow)[N], real v) {
   real s = 0;
-#pragma unroll
-  for (int j = 0; j < N; j++) s += P.L->A[P.c][j] * vfull[j];
+  fmac_rowvec<16, 0, N>(s, bsrc<16>(v), [&](int j) { return arow[j]; });
   return s;
 }
 // step size to the bound along s for this lane (INF if none)
@@ -358,13 +344,12 @@ __device__ __forceinline__ real lane_step_to_bound(const CoopCtx<N>& P, real x, 
   return (P.on && s != 0) ? fmax((P.lb - x) / s, (P.ub - x) / s) : INFINITY;
 }
 
-// scipy trf.py select_step in per-lane form.  Inputs: this lane's x, d, p_h, g_h; full p_h / g_h vectors.
+// scipy trf.py select_step in per-lane form.  Inputs: this lane's x, d, p_h, g_h and its row of the normal matrix.
 // Output: this lane's step_h (step = d * step_h); returns the predicted reduction (uniform).
 template <int N>
-__device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, real x, real d, real ph, real gh, const real* ph_full,
-                                                 const real* gh_full, real Delta, real theta, real& step_h) {
-  real* buf = P.L->v2;
-  const real Aph = arow_dot<N>(P, ph_full);
+__device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, const real (&arow)[N], real x, real d, real ph, real gh,
+                                                 real Delta, real theta, real& step_h) {
+  const real Aph = arow_dot<N>(arow, ph);
   const real xp = x + d * ph;
   if (gall8(!P.on || (xp >= P.lb && xp <= P.ub))) {
     const real pv = 0.5 * gsum8(ph * Aph) + gsum8(gh * ph);
@@ -392,9 +377,7 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, real x, re
   real r_value = INFINITY;
   const real Aphs = Aph * p_stride;          // A (p_h * stride) row value
   if (rl <= ru) {
-    real rh_full[N];
-    allgather<N>(buf, P.c, rh, rh_full);
-    const real Arh = arow_dot<N>(P, rh_full);
+    const real Arh = arow_dot<N>(arow, rh);
     const real a = 0.5 * gsum8(rh * Arh);
     const real b = gsum8(gh * rh) + gsum8(phs * Arh);
     const real c = 0.5 * gsum8(phs * Aphs) + gsum8(gh * phs);
@@ -409,10 +392,7 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, real x, re
   real ag_stride = (to_bound2 < to_tr2) ? theta * to_bound2 : to_tr2;
   real ag_value;
   {
-    real ngh_full[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) ngh_full[i] = -gh_full[i];
-    const real Aag = arow_dot<N>(P, ngh_full);
+    const real Aag = arow_dot<N>(arow, agh);
     const real a = 0.5 * gsum8(agh * Aag), b = gsum8(gh * agh);
     min_quad_1d_c(a, b, 0, ag_stride, 0, ag_stride, ag_value);
   }
@@ -469,42 +449,29 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
     if (g_norm < gtol) status = 1;
     if (status != -1 || nfev == max_nfev) break;
     const real d = sqrt(v), diag_h = g * dv, g_h = d * g;
-    // ---- normal matrix row c: A[c][j] = d_c d_j (J_c . J_j + 2 reg^2 [c==j]) + diag_h [c==j].  The other lanes' Jacobian
-    // columns, scalings and gradient components arrive by half-row DPP broadcasts folded into the FMAs (no LDS all-gather,
-    // no synchronisation); only the finished row goes to LDS, from where every lane reads the whole matrix.
-    real d_full[N], gh_full[N], arow[N];
+    // ---- normal matrix row c: A[c][j] = d_c d_j (J_c . J_j + 2 reg^2 [c==j]) + diag_h [c==j], in registers.  The other lanes'
+    // Jacobian columns and scalings arrive by row broadcasts folded into the FMAs (no LDS, no synchronisation); the matrix is
+    // symmetric, so the lane's row is also its column -- all the trust-region solve and the step selection need.
+    real arow[N];
     static_for<0, N>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      d_full[j] = bcast8<j>(d);
-      gh_full[j] = bcast8<j>(g_h);
       real s = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++) fmac_bcast8<j>(s, Jc[r], Jc[r]);
-      arow[j] = s;
+      dppfma_acc3<j>(s, Jc[0], Jc[0], Jc[1], Jc[1], Jc[2], Jc[2]);
+      dppfma_acc3<j>(s, Jc[3], Jc[3], Jc[4], Jc[4], Jc[5], Jc[5]);
+      if (j == P.c) s += jreg2;
+      s *= d * bcast8<j>(d);
+      if (j == P.c) s += diag_h;
+      arow[j] = P.on ? s : 0.0;
     });
-    if (P.on) {
-#pragma unroll
-      for (int j = 0; j < N; j++) {
-        real s = arow[j];
-        if (j == P.c) s += jreg2;
-        s *= d * d_full[j];
-        if (j == P.c) s += diag_h;
-        P.L->A[P.c][j] = s;
-      }
-    }
-    KM_GSYNC();
     P.pf->ph(34);
     const real theta = fmax(0.995, 1 - g_norm);
     real actual = -1, x_new = x;
     while (actual <= 0 && nfev < max_nfev) {
-      real ph_full[N];
-      solve_tr_reg<N>(P.L->A, gh_full, Delta, alpha, ph_full);
-      P.pf->ph(35);
       real ph = 0;
-#pragma unroll
-      for (int i = 0; i < N; i++) if (P.c == i) ph = ph_full[i];
+      solve_tr_coop<N>(arow, P.c, g_h, Delta, alpha, ph);
+      P.pf->ph(35);
       real step_h;
-      const real predicted = coop_select_step<N>(P, x, d, ph, g_h, ph_full, gh_full, Delta, theta, step_h);
+      const real predicted = coop_select_step<N>(P, arow, x, d, ph, g_h, Delta, theta, step_h);
       if (!P.on) step_h = 0;
       P.pf->ph(36);
       const real step = d * step_h;

@@ -47,3 +47,35 @@ __global__ __launch_bounds__(64) void k_scripted_action(const KDeviceModel* __re
 void kmanip_launch_scripted_action(const KDeviceModel* dm, const KDeviceState& st, float* act, hipStream_t stream) {
   hipLaunchKernelGGL(k_scripted_action, dim3((st.num_envs + 63) / 64), dim3(64), 0, stream, dm, st, act);
 }
+
+// ---------------------------------------------------------------------------------------------
+// action_space.sample() for every env, on device: what the reference's rollout loops feed env.step with
+// (examples/2_log_with_h5py.py:22-26, 3_save_to_video.py:20-27: `action = env.action_space.sample()`, a Dict of Box(-1, 1,
+// float32) keys, env_base.py:151-188).  Counter-based: Philox4x32-10 keyed by the handle's seed, counter = (global env id,
+// episode, KM_ACT_CTR3(step, block)) -- SURVEY 8d's stream, so the CPU oracle (ko_sample_action) draws identical bits for
+// the same (seed, env, episode, step) and a run's actions do not depend on the shard layout.  `ahead` control steps into the
+// future under the TimeLimit-only episode structure (the reference never terminates early: every episode is exactly
+// max_episode_steps long), so a caller can lay out the actions of the next K steps before stepping (bench.py).
+// One lane per (env, block of 4 columns).
+__global__ __launch_bounds__(256) void k_sample_action(const KDeviceModel* __restrict__ dm, KDeviceState st, float* __restrict__ act, int ahead) {
+  const KModelDesc* m = &dm->d;
+  const int nblk = (m->act_dim + 3) / 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= st.num_envs * nblk) return;
+  const int env = i / nblk, blk = i - env * nblk;
+  const int T = m->max_episode_steps;
+  const int s0 = st.step_idx[env] + ahead;
+  const int step = s0 % T, episode = st.episode[env] + s0 / T;
+  const int64_t genv = st.env_id_offset + env;
+  const uint32_t key[2] = {(uint32_t)st.seed, (uint32_t)(st.seed >> 32)};
+  const uint32_t ctr[4] = {(uint32_t)genv, (uint32_t)((uint64_t)genv >> 32), (uint32_t)episode, KM_ACT_CTR3(step, blk)};
+  uint32_t o[4];
+  philox4x32_10(ctr, key, o);
+  float* a = act + (size_t)env * m->act_dim + 4 * blk;
+  for (int c = 0; c < 4 && 4 * blk + c < m->act_dim; c++) a[c] = km_action_from_u32(o[c]);
+}
+
+void kmanip_launch_sample_action(const KDeviceModel* dm, const KDeviceState& st, float* act, int ahead, hipStream_t stream) {
+  const int n = st.num_envs * 4;          // act_dim <= 16: at most 4 blocks per env (idle lanes return)
+  hipLaunchKernelGGL(k_sample_action, dim3((n + 255) / 256), dim3(256), 0, stream, dm, st, act, ahead);
+}

@@ -236,6 +236,17 @@ class KManipEnvHip:
         self._check(self.L.kmanip_scripted_action(self.h, C.c_void_p(act.data_ptr()), self._stream()), "kmanip_scripted_action")
         return act
 
+    def sample_action(self, act=None, ahead=0):
+        """action_space.sample() for every env on the device (examples/2_log_with_h5py.py:22-26): U[-1, 1) float32 from the
+        counter-based stream keyed (seed; global env id, episode, step) -- identical to the CPU oracle's.  `ahead`: the action
+        the env needs that many control steps from now (TimeLimit-only episodes).  Returns the [num_envs, act_dim] tensor."""
+        torch = _torch()
+        if act is None:
+            act = torch.empty((self.num_envs, self.cm.act_dim), dtype=torch.float32, device=self.device)
+        self._check_buf(act, (self.num_envs, self.cm.act_dim), torch.float32, "act")
+        self._check(self.L.kmanip_sample_action(self.h, C.c_void_p(act.data_ptr()), int(ahead), self._stream()), "kmanip_sample_action")
+        return act
+
     def k_render(self, cam):
         """KManipEnvSim.k_render (env_sim.py:187-188): physics.render(cam.h, cam.w, camera_id=cam.name) -> uint8 RGB,
         for every env ([num_envs, h, w, 3], device tensor).  `cam` is a Cam (model.CAMERAS) or a camera name."""

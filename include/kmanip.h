@@ -286,6 +286,15 @@ int kmanip_bind_step_depth(KHandle h, int cam, int height, int width, float* dep
  * Returns an error for env ids without an eer_pos action (the *QPos ids). */
 int kmanip_scripted_action(KHandle h, float* act_dev, void* stream);
 
+/* action_space.sample() for every env, on device -- what the reference's rollout loops feed env.step with
+ * (examples/2_log_with_h5py.py:22-26, 3_save_to_video.py:20-27; spaces env_base.py:151-188: every key a Box(-1, 1, float32)):
+ * act_dev float[num_envs, act_dim] is filled with U[-1, 1) float32 from a counter-based stream, Philox4x32-10 keyed by the
+ * handle's seed with counter (global env id, episode, step): the action of an env at a given (episode, step) does not depend
+ * on the shard layout or on what was drawn before, and the CPU oracle draws identical bits (SURVEY 8d's synthetic inputs).
+ * `ahead` >= 0 draws the action the env will need `ahead` control steps from now, assuming TimeLimit-only episodes (the
+ * reference never terminates early), so the next K actions can be laid out before stepping. */
+int kmanip_sample_action(KHandle h, float* act_dev, int ahead, void* stream);
+
 int kmanip_num_envs(KHandle h);
 const char* kmanip_last_error(KHandle h);   /* h may be NULL: error of the last failed create */
 const char* kmanip_version(void);

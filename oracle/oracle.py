@@ -93,6 +93,14 @@ class Oracle:
                              nthreads)
         return obs, rew, done
 
+    def sample_action(self, ahead: int = 0):
+        """action_space.sample() for every env from the counter-based stream (the device's kmanip_sample_action draws the
+        same bits)."""
+        act = np.zeros((self.n, self.cm.act_dim), dtype=np.float32)
+        self.L.ko_sample_action(C.byref(self.desc), C.c_uint64(self.seed), C.c_int64(self.env_id_offset), self.n,
+                                self.states, int(ahead), _p(act, C.c_float))
+        return act
+
     # ---- state access
     def get_state(self):
         nq, nv, nu = self.cm.nq, self.cm.nv, self.cm.nu
