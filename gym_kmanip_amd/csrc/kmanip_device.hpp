@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "../../include/kmanip.h"
+#include "kmanip_math.hpp"
 
 #define KM_MAX_CHAIN 8
 #define KM_BLOCK_MAX 11
@@ -92,37 +93,60 @@ __device__ __forceinline__ void matT_vec3(real* r, const real* m, const real* v)
 __device__ __forceinline__ void axis_angle2quat(real* q, const real* axis, real angle) {
   if (angle == 0) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
   real s, c;
-  sincos(angle * 0.5, &s, &c);
+  km_sincos(angle * 0.5, &s, &c);
   q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
-// mju_mat2Quat
+// 1/sqrt(s) to double precision: hardware estimate + two Newton steps (no IEEE sqrt / divide sequences)
+__device__ __forceinline__ real rsqrt_nr(real s) {
+  real y = __builtin_amdgcn_rsq(s);
+  y = y * (1.5 - 0.5 * s * y * y);
+  y = y * (1.5 - 0.5 * s * y * y);
+  return y;
+}
+
+// 1/x to double precision: hardware estimate + two Newton steps (6 instructions instead of the ~14 of an IEEE divide; last-bit
+// differences only).
+__device__ __forceinline__ real frcp(real x) {
+  real r = __builtin_amdgcn_rcp(x);
+  r = r + r * (1.0 - x * r);
+  r = r + r * (1.0 - x * r);
+  return r;
+}
+// mju_normalize3 / normalize4 without sqrt + divide sequences
+__device__ __forceinline__ real normalize3_fast(real* v) {
+  const real s = dot3(v, v);
+  if (s < MJ_MINVAL * MJ_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return km_sqrt(s); }
+  const real inv = rsqrt_nr(s);
+  v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  return s * inv;
+}
+__device__ __forceinline__ void normalize4_fast(real* q) {
+  const real s = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (s < MJ_MINVAL * MJ_MINVAL) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
+  const real inv = rsqrt_nr(s);
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+// mju_mat2Quat: ONE square root and one reciprocal whichever of the four cases applies (the case picks their argument)
 __device__ __forceinline__ void mat2quat(real* q, const real* m) {
-  if (m[0] + m[4] + m[8] > 0) {
-    q[0] = 0.5 * sqrt(1 + m[0] + m[4] + m[8]);
-    real s = 0.25 / q[0];
-    q[1] = s * (m[7] - m[5]); q[2] = s * (m[2] - m[6]); q[3] = s * (m[3] - m[1]);
-  } else if (m[0] > m[4] && m[0] > m[8]) {
-    q[1] = 0.5 * sqrt(1 + m[0] - m[4] - m[8]);
-    real s = 0.25 / q[1];
-    q[0] = s * (m[7] - m[5]); q[2] = s * (m[1] + m[3]); q[3] = s * (m[2] + m[6]);
-  } else if (m[4] > m[8]) {
-    q[2] = 0.5 * sqrt(1 - m[0] + m[4] - m[8]);
-    real s = 0.25 / q[2];
-    q[0] = s * (m[2] - m[6]); q[1] = s * (m[1] + m[3]); q[3] = s * (m[5] + m[7]);
-  } else {
-    q[3] = 0.5 * sqrt(1 - m[0] - m[4] + m[8]);
-    real s = 0.25 / q[3];
-    q[0] = s * (m[3] - m[1]); q[1] = s * (m[2] + m[6]); q[2] = s * (m[5] + m[7]);
-  }
-  normalize4(q);
+  const real tr = m[0] + m[4] + m[8];
+  const int cs = tr > 0 ? 0 : ((m[0] > m[4] && m[0] > m[8]) ? 1 : (m[4] > m[8] ? 2 : 3));
+  const real arg = cs == 0 ? 1 + tr : (cs == 1 ? 1 + m[0] - m[4] - m[8] : (cs == 2 ? 1 - m[0] + m[4] - m[8] : 1 - m[0] - m[4] + m[8]));
+  const real r = 0.5 * km_sqrt(arg), s = 0.25 * frcp(r);
+  const real d75 = s * (m[7] - m[5]), d26 = s * (m[2] - m[6]), d31 = s * (m[3] - m[1]);
+  const real s13 = s * (m[1] + m[3]), s26 = s * (m[2] + m[6]), s57 = s * (m[5] + m[7]);
+  q[0] = cs == 0 ? r : (cs == 1 ? d75 : (cs == 2 ? d26 : d31));
+  q[1] = cs == 0 ? d75 : (cs == 1 ? r : (cs == 2 ? s13 : s26));
+  q[2] = cs == 0 ? d26 : (cs == 1 ? s13 : (cs == 2 ? r : s57));
+  q[3] = cs == 0 ? d31 : (cs == 1 ? s26 : (cs == 2 ? s57 : r));
+  normalize4_fast(q);
 }
 // mju_subQuat(res, qa, qb)
 __device__ __forceinline__ void sub_quat(real* res, const real* qa, const real* qb) {
   real qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]}, qd[4];
   qmul(qd, qn, qa);
   real ax[3] = {qd[1], qd[2], qd[3]};
-  real sn = normalize3(ax);
-  real speed = 2 * atan2(sn, qd[0]);
+  real sn = normalize3_fast(ax);
+  real speed = 2 * km_atan2(sn, qd[0]);
   if (speed > M_PI) speed -= 2 * M_PI;
   res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
 }
@@ -133,42 +157,11 @@ __device__ __forceinline__ void sub_quat_sc(real* res, const real* qa, const rea
   real qn[4] = {qb[0], -qb[1], -qb[2], -qb[3]}, qd[4];
   qmul(qd, qn, qa);
   real ax[3] = {qd[1], qd[2], qd[3]};
-  real sn = normalize3(ax);
-  real speed = 2 * atan2(sn, qd[0]);
+  real sn = normalize3_fast(ax);
+  real speed = 2 * km_atan2(sn, qd[0]);
   if (speed > M_PI) speed -= 2 * M_PI;
   res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
   sn_out = sn; ac_out = fabs(qd[0]);
-}
-
-// 1/sqrt(s) to double precision: hardware estimate + two Newton steps (no IEEE sqrt / divide sequences)
-__device__ __forceinline__ real rsqrt_nr(real s) {
-  real y = __builtin_amdgcn_rsq(s);
-  y = y * (1.5 - 0.5 * s * y * y);
-  y = y * (1.5 - 0.5 * s * y * y);
-  return y;
-}
-
-// 1/x to double precision: hardware estimate + two Newton steps (6 instructions instead of the ~14 of an IEEE divide; last-bit
-// differences only).  Used on the physics path; the IK keeps IEEE divides (its TRF control flow mirrors SciPy's decisions).
-__device__ __forceinline__ real frcp(real x) {
-  real r = __builtin_amdgcn_rcp(x);
-  r = r + r * (1.0 - x * r);
-  r = r + r * (1.0 - x * r);
-  return r;
-}
-// mju_normalize3 / normalize4 without sqrt + divide sequences (physics path)
-__device__ __forceinline__ real normalize3_fast(real* v) {
-  const real s = dot3(v, v);
-  if (s < MJ_MINVAL * MJ_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return sqrt(s); }
-  const real inv = rsqrt_nr(s);
-  v[0] *= inv; v[1] *= inv; v[2] *= inv;
-  return s * inv;
-}
-__device__ __forceinline__ void normalize4_fast(real* q) {
-  const real s = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-  if (s < MJ_MINVAL * MJ_MINVAL) { q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; return; }
-  const real inv = rsqrt_nr(s);
-  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 
 // cross-lane double move with a DPP control word (a DPP row is 16 lanes)

@@ -206,7 +206,7 @@ __device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int
       p[0] += R[2] * q; p[1] += R[5] * q; p[2] += R[8] * q;
     } else {
       real sn, cs;
-      sincos(q, &sn, &cs);
+      km_sincos(q, &sn, &cs);
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const real c0 = lm.R[sub][3 * a], c1 = lm.R[sub][3 * a + 1];
@@ -1729,7 +1729,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
   const int maxit = m->solver_iterations;
   {
     const real g0 = in ? grad : 0.0;
-    if (sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
+    if (km_sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
   }
   // this lane's share of the subset's contact edges (t = sub + G*q), for the whole solve in registers: the friction sign,
   // regulariser and its reciprocal never change, and x = J a - aref of the current point is advanced with the step
@@ -1911,7 +1911,7 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
 #pragma unroll
     for (int q = 0; q < NEQ; q++) lx[q] += alpha * ly[q];
     const real g1 = in ? grad : 0.0;
-    const real improvement = scale * (cost - cost_new), gradient = scale * sqrt(gsum<G>(g1 * g1));
+    const real improvement = scale * (cost - cost_new), gradient = scale * km_sqrt(gsum<G>(g1 * g1));
     cost = cost_new;
     pf.ph(14 + 6 * S);
     if (improvement < tol || gradient < tol || w.bad) break;
@@ -2257,14 +2257,14 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     real v2 = gsum<G>(sub < NV ? w.qvel[sub] * w.qvel[sub] : 0.0);
     GSYNC();
     // get_reward, env_sim.py:148-179
-    rew = -m->reward_vel_penalty * sqrt(v2);
+    rew = -m->reward_vel_penalty * km_sqrt(v2);
     for (int arm = 1; arm >= 0; arm--) {
       if (!m->arm_present[arm] || !m->arm_has_grip[arm]) continue;
       const int l = m->arm_site_link[arm];
       real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]}, sp[3];
       mat_vec3(sp, w.k.xmat[l], so);
       real df[3] = {w.qpos[NL] - (sp[0] + w.k.xpos[l][0]), w.qpos[NL + 1] - (sp[1] + w.k.xpos[l][1]), w.qpos[NL + 2] - (sp[2] + w.k.xpos[l][2])};
-      rew += m->reward_grip_dist * (1.0 / (sqrt(dot3(df, df)) + m->epsilon));
+      rew += m->reward_grip_dist * (1.0 / (km_sqrt(dot3(df, df)) + m->epsilon));
     }
     if (m->touch_reward_enabled && (w.contact_mask & KM_CON_FINGERS_CUBE(NL))) {      // a FINGER on the cube (palm / link spheres do not count)
       rew += m->reward_touch_cube;

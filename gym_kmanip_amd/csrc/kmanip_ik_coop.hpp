@@ -113,7 +113,7 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
       p[0] += R[2] * q; p[1] += R[5] * q; p[2] += R[8] * q;
     } else {
       real sn, cs;
-      sincos(q, &sn, &cs);
+      km_sincos(q, &sn, &cs);
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         R[3 * i] = cs * P.cR[3 * i] + sn * P.cR[3 * i + 1];
@@ -176,7 +176,7 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
   if (JAC) {
     // mjd_subQuat: Da = I + h K + (1 - h / tan h) K^2, D_ee = -Da^T; mat = rad * D_ee^T * site_xmat^T
     real axs[3] = {rq[0], rq[1], rq[2]};
-    real half = 0.5 * normalize3(axs);
+    real half = 0.5 * normalize3_fast(axs);
     real K[9] = {0, -axs[2], axs[1], axs[2], 0, -axs[0], -axs[1], axs[0], 0};
     real coef = 1.0 - (half < 6e-8 ? 1.0 : half * ac_h / sn_h);      // half / tan(half), tan(half) = sn_h / ac_h
     real Da[9];
@@ -292,10 +292,10 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], int c, real
   real pn = 0;
   if (full_rank) {
     p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
-    pn = sqrt(gsum8(p * p));
+    pn = km_sqrt(gsum8(p * p));
     if (pn <= Delta) { alpha = 0.0; return; }
   }
-  real alpha_upper = sqrt(gsum8(g_h * g_h)) / Delta, alpha_lower = 0.0;
+  real alpha_upper = km_sqrt(gsum8(g_h * g_h)) / Delta, alpha_lower = 0.0;
   if (full_rank) {
     const real q = tr_fwd<N>(F, p);
     const real phi = pn - Delta, phip = -gsum8(q * q) / pn;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], int c, real
     if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
     chol_coop<N>(arow, alpha, c, F);
     p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
-    pn = sqrt(gsum8(p * p));
+    pn = km_sqrt(gsum8(p * p));
     const real q = tr_fwd<N>(F, p);
     const real phi = pn - Delta, phip = -gsum8(q * q) / pn;
     if (phi < 0) alpha_upper = alpha;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], int c, real
   }
   chol_coop<N>(arow, alpha, c, F);
   p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
-  p *= Delta / sqrt(gsum8(p * p));
+  p *= Delta / km_sqrt(gsum8(p * p));
 }
 
 __device__ __forceinline__ void min_quad_1d_c(real a, real b, real lo, real hi, real c, real& t_out, real& y_out) {
@@ -387,7 +387,7 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, const real
   const real pht = phs * theta;              // strictly interior version of the restricted step
   const real p_value = 0.5 * gsum8(pht * (Aphs * theta)) + gsum8(gh * pht);
   real agh = -gh;
-  const real to_tr2 = Delta / sqrt(gsum8(agh * agh));
+  const real to_tr2 = Delta / km_sqrt(gsum8(agh * agh));
   const real to_bound2 = gmin8(lane_step_to_bound<N>(P, x, d * agh));
   real ag_stride = (to_bound2 < to_tr2) ? theta * to_bound2 : to_tr2;
   real ag_value;
@@ -435,7 +435,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
   real v = 1;
   if (g < 0) v = P.ub - x;
   if (g > 0) v = x - P.lb;
-  real Delta = sqrt(gsum8(P.on ? x * x / v : 0.0));
+  real Delta = km_sqrt(gsum8(P.on ? x * x / v : 0.0));
   if (Delta == 0) Delta = 1.0;
   real alpha = 0.0, cost_new = cost;
   int status = -1;
@@ -448,7 +448,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
     const real g_norm = gmax8(P.on ? fabs(g * v) : 0.0);
     if (g_norm < gtol) status = 1;
     if (status != -1 || nfev == max_nfev) break;
-    const real d = sqrt(v), diag_h = g * dv, g_h = d * g;
+    const real d = km_sqrt(v), diag_h = g * dv, g_h = d * g;
     // ---- normal matrix row c: A[c][j] = d_c d_j (J_c . J_j + 2 reg^2 [c==j]) + diag_h [c==j], in registers.  The other lanes'
     // Jacobian columns and scalings arrive by row broadcasts folded into the FMAs (no LDS, no synchronisation); the matrix is
     // symmetric, so the lane's row is also its column -- all the trust-region solve and the step selection need.
@@ -481,7 +481,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       P.pf->ph(33);
       x_last = x_new;
       nfev++;
-      const real shn = sqrt(gsum8(step_h * step_h));
+      const real shn = km_sqrt(gsum8(step_h * step_h));
       bool fin = true;
 #pragma unroll
       for (int r = 0; r < 6; r++) fin = fin && isfinite(ft_new[r]);
@@ -494,7 +494,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       else ratio = 0;
       if (ratio < 0.25) Delta_new = 0.25 * shn;
       else if (ratio > 0.75 && shn > 0.95 * Delta) Delta_new = Delta * 2.0;
-      const real sn = sqrt(gsum8(step * step)), xn = sqrt(gsum8(P.on ? x * x : 0.0));
+      const real sn = km_sqrt(gsum8(step * step)), xn = km_sqrt(gsum8(P.on ? x * x : 0.0));
       const bool ft_ok = (actual < ftol * cost) && (ratio > 0.25);
       const bool xt_ok = sn < xtol * (xtol + xn);
       if (ft_ok && xt_ok) status = 4; else if (ft_ok) status = 2; else if (xt_ok) status = 3;
@@ -568,14 +568,16 @@ __device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds
     real ft0[6], sp[3], smat[9];
     coop_eval<N, false>(P, x0, ft0, nullptr, sp, smat);
     // EE-delta decode (env_sim.py:60-69): euler("xyz", extrinsic) of the site matrix + delta -> quaternion
-    real e0 = atan2(smat[7], smat[8]);
-    real e1 = atan2(-smat[6], sqrt(smat[7] * smat[7] + smat[8] * smat[8]));
-    real e2 = atan2(smat[3], smat[0]);
+    real e0 = km_atan2(smat[7], smat[8]);
+    real e1 = km_atan2(-smat[6], km_sqrt(smat[7] * smat[7] + smat[8] * smat[8]));
+    real e2 = km_atan2(smat[3], smat[0]);
     e0 += (double)a[co] * m->ee_orn_delta[0];
     e1 += (double)a[co + 1] * m->ee_orn_delta[1];
     e2 += (double)a[co + 2] * m->ee_orn_delta[2];
-    real qx[4] = {cos(e0 * 0.5), sin(e0 * 0.5), 0, 0}, qy[4] = {cos(e1 * 0.5), 0, sin(e1 * 0.5), 0};
-    real qz[4] = {cos(e2 * 0.5), 0, 0, sin(e2 * 0.5)}, t4[4];
+    real s0, c0, s1, c1, s2, c2;
+    km_sincos(e0 * 0.5, &s0, &c0); km_sincos(e1 * 0.5, &s1, &c1); km_sincos(e2 * 0.5, &s2, &c2);
+    real qx[4] = {c0, s0, 0, 0}, qy[4] = {c1, 0, s1, 0};
+    real qz[4] = {c2, 0, 0, s2}, t4[4];
     qmul(t4, qy, qx);
     qmul(P.goal_quat, qz, t4);
     P.goal_pos[0] = (double)a[cp] * m->ee_pos_delta[0] + sp[0];
