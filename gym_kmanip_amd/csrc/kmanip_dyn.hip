@@ -126,6 +126,11 @@ struct Ws {
   int s_dof[NS], s_type[NS], s_quad[NS];
   real s_sign[NS], s_pos[NS], s_f[NS], s_R[NS], s_aref[NS], s_den[NS], s_inv[NS], s_floss[NS];
 #endif
+#if KM_VAR_SOLVER == 1      // (Newton; the enum constants are not visible to the preprocessor)
+  // the Cholesky factor of a one-row Newton system on its way from row-per-lane to column-per-lane (rows padded to an odd
+  // number of doubles: the lanes' row writes then fall into different banks)
+  real LT[NL <= 10 ? NL + 6 : 1][(NL <= 10 ? NL + 6 : 1) + 1];     // (one-row groups only)
+#endif
   // contact geometry per slot
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
   int slot_sph[NC];        // sphere index held by each active sphere slot (4..NC-1)
@@ -1319,6 +1324,76 @@ __device__ __forceinline__ real chol_solve_rows(const real (&h)[N], real invd, i
   return x;
 }
 
+// ---- One-row systems (round 3): the same right-looking Cholesky, but column k of L is MASKED to its strictly-lower part as
+// it is formed (lik = sub > k ? h[k] * inv : 0), so rows on and above the pivot never change again and hold exact zeros there.
+// Both triangular solves are then column-oriented -- one multiply and one broadcast-FMA per pivot, no lane tests, no lane
+// reductions -- given row `sub` of L^T next to row `sub` of L.  Row `sub` of L^T is column `sub` of L, which lives in the
+// OTHER lanes' registers; it arrives either from the factorisation's own broadcasts (UT: ut[j] += bcast_j(l) * [sub == k],
+// (D1-D0)(D1-D0-1)/2 extra broadcast-FMAs: small blocks) or through one LDS transposition (chol_transpose: larger blocks).
+// Round 2's transposed solve took one 16-lane reduction per pivot (12-20 instructions each).
+// `sl` = this lane's dof index relative to the DPP row's first dof (two-row groups run a block that sits in one row with the
+// other row inert: sl < 0 or rows of zeros); `live` = the lane's row holds the block (only those lanes report a bad pivot).
+template <int N, int D0, int D1, int BASE, bool UT>
+__device__ __forceinline__ void chol_rows1(real (&h)[N], real (&ut)[N], real& invd, int sl, bool live, int& bad) {
+  invd = 0;
+  if constexpr (UT) {
+#pragma unroll
+    for (int j = 0; j < N; j++) ut[j] = 0;
+  }
+  static_for<D0, D1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, kl = k - BASE;
+    const real dk = gbcast<16, kl>(h[k]);
+    bad |= live && !(dk > 0);
+    const real inv = rsqrt_nr(dk);
+    const bool me = sl == kl;
+    const real lik = sl > kl ? h[k] * inv : 0.0;
+    h[k] = lik;
+    invd = me ? inv : invd;
+    if constexpr (UT) {
+      const real isk = me ? 1.0 : 0.0;
+      static_for<k + 1, D1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        dppfma_pn<j - BASE>(ut[j], lik, isk, h[j], lik, lik);      // ut[j] += L[j][k] [sub == k];  h[j] -= L[j][k] L[sub][k]
+      });
+    } else {
+      static_for<k + 1, D1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        fnmac_bcast16<j - BASE>(h[j], lik, lik);
+      });
+    }
+  });
+}
+// ut[k] = L[k][sub] through LDS: lane i writes row i of L (exact zeros on and above the diagonal), lane s reads column s
+template <int N, int D0, int D1, int BASE, class LT>
+__device__ __forceinline__ void chol_transpose(LT& lt, const real (&h)[N], real (&ut)[N], int sl) {
+  const int r = sl < 0 ? 0 : sl;                        // (lanes of an inert row write zeros over zeros)
+#pragma unroll
+  for (int k = D0; k < D1; k++) lt[r][k - D0] = h[k];
+  GSYNC();
+  // lanes outside the block read a column of the block too (finite numbers, never stale LDS): their invd = 0 then gives the
+  // zero they need without a select per entry
+  const int col = r + BASE - D0 < 0 ? 0 : (r + BASE - D0 > D1 - D0 - 1 ? D1 - D0 - 1 : r + BASE - D0);
+#pragma unroll
+  for (int k = D0; k < D1; k++) ut[k] = lt[k - BASE][col];
+  GSYNC();
+}
+// x = (L L^T)^-1 b, b distributed one component per lane (zero outside the block)
+template <int N, int D0, int D1, int BASE>
+__device__ __forceinline__ real chol_solve_rows1(const real (&h)[N], const real (&ut)[N], real invd, real b) {
+  static_for<D0, D1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const real t = b * invd;                            // lane k's t is z_k (its b is final: h[j] = 0 for j >= sub)
+    fnmac_bcast16<k - BASE>(b, t, h[k]);
+  });
+  real z = b * invd;
+  static_for<D0, D1>([&](auto kc) {
+    constexpr int k = D1 - 1 - (decltype(kc)::value - D0);
+    const real t = z * invd;                            // lane k's t is x_k (ut[j] = 0 for j <= sub)
+    fnmac_bcast16<k - BASE>(z, t, ut[k]);
+  });
+  return z * invd;
+}
+
 // s_i'(x) and s_i''(x) contributions of one row to the line-search derivatives
 __device__ __forceinline__ void row_ls(int type, real x, real y, real R, real Dn, real fl, real& d1, real& d2) {
   if (type == 0) {
@@ -1832,21 +1907,40 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
           loc[k] = (on && k < nb) ? v : ((!on && k == c) ? 1.0 : 0.0);
         }
         const real gsrc = __shfl(in ? -grad : 0.0, src, 64);
-        real invl = 1;
-        chol_rows<16, NB, 0, NB>(loc, invl, c, hbad);
+        real invl = 0, utl[NB];
+        chol_rows1<NB, 0, NB, 0, true>(loc, utl, invl, c, true, hbad);
         if (__any(hbad)) { const int gb = gor<G>(hbad); if (gb && sub == 0) w.bad = 1; }
         pf.ph(10 + 6 * S);
-        const real pl = chol_solve_rows<16, NB, 0, NB>(loc, invl, c, on ? gsrc : 0.0);
+        const real pl = chol_solve_rows1<NB, 0, NB, 0>(loc, utl, invl, on ? gsrc : 0.0);
         const int back = lane0 + (sub < split ? sub : 16 + (sub < NL ? sub - split : 0));
         const real pb = __shfl(pl, back, 64);
         p = in ? pb : 0.0;
         pf.ph(11 + 6 * S);
       }
     } else {
+    // blocks that sit inside one DPP row use the one-row code (single-arm models: every subset; two-arm models: the cube block,
+    // dofs NL..NL+5 of the group's second row)
+    constexpr bool onerow = G == 16 || (S == KM_SUB_CUBE && NL >= 16);
+    if constexpr (onerow) {
+      constexpr int BASE = G == 16 ? 0 : 16, ND = SS::D1 - SS::D0;
+      const int sl = sub - BASE;
+      const bool live = G == 16 || sub >= 16;
+      real ut[NV];
+      if constexpr (ND <= 6) {
+        chol_rows1<NV, SS::D0, SS::D1, BASE, true>(h, ut, invd, sl, live, hbad);
+      } else {
+        chol_rows1<NV, SS::D0, SS::D1, BASE, false>(h, ut, invd, sl, live, hbad);
+        chol_transpose<NV, SS::D0, SS::D1, BASE>(w.LT, h, ut, sl);
+      }
+      if (hbad && sub == 0) w.bad = 1;
+      pf.ph(10 + 6 * S);
+      p = chol_solve_rows1<NV, SS::D0, SS::D1, BASE>(h, ut, invd, in ? -grad : 0.0);
+    } else {
     chol_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, hbad);
     if (hbad && sub == 0) w.bad = 1;
     pf.ph(10 + 6 * S);
     p = chol_solve_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, in ? -grad : 0.0);
+    }
     pf.ph(11 + 6 * S);
     }
     }
