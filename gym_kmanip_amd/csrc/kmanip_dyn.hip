@@ -1977,25 +1977,28 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
     }
     const real xf = a - cr.areff, xl = cr.sg * a - cr.arefl, yl = cr.sg * p;
     pf.ph(12 + 6 * S);
-    real alpha = 0, lo = 0, hi = INFINITY, d1 = 0, d2 = 0, d10 = 0;
-    for (int it = 0; it <= 50; it++) {
-      real e1 = 0, e2 = 0;
-      if (in && cr.fl > 0) row_ls(0, xf + alpha * p, p, cr.Rf, cr.Df, cr.fl, e1, e2);
-      if (in && cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, cr.Dl, 0.0, e1, e2);
+    // phi'(0) = grad . p; p is the exact Newton direction of the current active set, so the first trial is the full step
+    // alpha = 1 (phi''(0) = p^T H p = -grad . p): no evaluation of the rows at alpha = 0
+    real alpha = 0, lo = 0, hi = INFINITY;
+    const real d10 = gsum<G>(in ? p * grad : 0.0);
+    if (d10 < 0) {
+      alpha = 1;
+      for (int it = 0; it < 50; it++) {
+        real e1 = 0, e2 = 0;
+        if (in && cr.fl > 0) row_ls(0, xf + alpha * p, p, cr.Rf, cr.Df, cr.fl, e1, e2);
+        if (in && cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, cr.Dl, 0.0, e1, e2);
 #pragma unroll
-      for (int q = 0; q < NEQ; q++) if (lR[q] != 0) row_ls(1, lx[q] + alpha * ly[q], ly[q], lR[q], lD[q], 0.0, e1, e2);
-      d1 = gp + alpha * pMp + gsum<G>(e1);
-      d2 = pMp + gsum<G>(e2);
-      if (it == 0) { d10 = d1; if (!(d10 < 0)) break; }
-      else {
-        if (fabs(d1) <= 1e-8 * fabs(d10)) break;      // MuJoCo's ls_tolerance is 1e-2; the outer Newton absorbs the rest
+        for (int q = 0; q < NEQ; q++) if (lR[q] != 0) row_ls(1, lx[q] + alpha * ly[q], ly[q], lR[q], lD[q], 0.0, e1, e2);
+        const real d1 = gp + alpha * pMp + gsum<G>(e1);
+        const real d2 = pMp + gsum<G>(e2);
+        if (fabs(d1) <= 1e-8 * fabs(d10)) break;        // MuJoCo's ls_tolerance is 1e-2; the outer Newton absorbs the rest
         if (d1 < 0) lo = alpha; else hi = alpha;
-        if (hi - lo <= 1e-14 * hi) break;               // bracket collapsed to roundoff
+        if (hi - lo <= 1e-14 * hi) break;                 // bracket collapsed to roundoff
+        if (it == 49) break;
+        real an = alpha - d1 * frcp(d2);
+        if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
+        alpha = an;
       }
-      if (it == 50) break;
-      real an = alpha - d1 * frcp(d2);
-      if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
-      alpha = an;
     }
     pf.ph(13 + 6 * S);
     // ---- advance the point and everything linear in it

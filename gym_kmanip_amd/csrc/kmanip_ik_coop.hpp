@@ -233,31 +233,28 @@ __device__ __forceinline__ real coop_grad(const CoopCtx<N>& P, real x, const rea
 // lane k picks its row of L^T up from the same broadcasts (ut[j] += bcast_j(l) * [c == k]), which makes BOTH triangular
 // solves column-oriented: one multiply and one broadcast-FMA per pivot, no lane reductions.  Lanes >= N carry zero rows and
 // stay inert.
-template <int N> struct TrFac { real h[N], hm[N], ut[N], invd; };
+template <int N> struct TrFac { real h[N], ut[N], invd; };
+// e[j] = [c == j] as a double (built once per IK call): the diagonal shift, the lane's own 1 / L[c][c] and its row of L^T are
+// then FMAs against it instead of a compare and two selects each
 template <int N>
-__device__ __forceinline__ bool chol_coop(const real (&arow)[N], real alpha, int c, TrFac<N>& F) {
+__device__ __forceinline__ bool chol_coop(const real (&arow)[N], const real (&e)[N], real alpha, int c, TrFac<N>& F) {
   bool ok = true;
 #pragma unroll
-  for (int j = 0; j < N; j++) { F.h[j] = arow[j] + (j == c ? alpha : 0.0); F.ut[j] = 0; }
+  for (int j = 0; j < N; j++) { F.h[j] = __builtin_fma(e[j], alpha, arow[j]); F.ut[j] = 0; }
   F.invd = 0;
   static_for<0, N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    real dk = bcast8<k>(F.h[k]);
-    if (!(dk > 0)) { ok = false; dk = 1; }             // (uniform over the problem: dk is a broadcast)
+    const real dk = bcast8<k>(F.h[k]);
+    ok = ok && dk > 0;                                 // (uniform over the problem: dk is a broadcast; a failed factor is never used)
     const real inv = rsqrt_nr(dk);
-    const real lik = F.h[k] * inv;                     // lanes i >= k: L[i][k]
+    const real lik = c > k ? F.h[k] * inv : 0.0;       // strictly-lower part: rows on and above the pivot hold exact zeros
     F.h[k] = lik;
-    const bool me = c == k;
-    F.invd = me ? inv : F.invd;
-    const real isk = me ? 1.0 : 0.0;
+    F.invd = __builtin_fma(e[k], inv, F.invd);
     static_for<k + 1, N>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      dppfma_pn<j>(F.ut[j], lik, isk, F.h[j], lik, lik);             // ut[j] += L[j][k] [c == k];  h[j] -= L[j][k] L[c][k]
+      dppfma_pn<j>(F.ut[j], lik, e[k], F.h[j], lik, lik);             // ut[j] += L[j][k] [c == k];  h[j] -= L[j][k] L[c][k]
     });
   });
-  // the strictly-lower part of the lane's row, zero elsewhere: the forward substitution's multipliers need no lane tests
-#pragma unroll
-  for (int j = 0; j < N; j++) F.hm[j] = c > j ? F.h[j] : 0.0;
   return ok;
 }
 // z = L^-1 b (b, z distributed one component per lane)
@@ -265,8 +262,8 @@ template <int N>
 __device__ __forceinline__ real tr_fwd(const TrFac<N>& F, real b) {
   static_for<0, N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const real t = b * F.invd;                         // lane k's t is z_k (its b is final: hm[j] = 0 for j >= c)
-    fnmac_bcast16<k>(b, t, F.hm[k]);
+    const real t = b * F.invd;                         // lane k's t is z_k (its b is final: h[j] = 0 for j >= c)
+    fnmac_bcast16<k>(b, t, F.h[k]);
   });
   return b * F.invd;
 }
@@ -285,10 +282,10 @@ __device__ __forceinline__ real tr_bwd(const TrFac<N>& F, real z) {
 // iteration on the secular equation, phi = |p(alpha)| - Delta, phi' = -|L^-1 p|^2 / |p| (SciPy evaluates the same two
 // numbers from its SVD).  g_h, p: this lane's components.
 template <int N>
-__device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], int c, real g_h, real Delta, real& alpha, real& p) {
+__device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], const real (&e)[N], int c, real g_h, real Delta, real& alpha, real& p) {
   TrFac<N> F;
   const real ng = -g_h;
-  const bool full_rank = chol_coop<N>(arow, 0.0, c, F);
+  const bool full_rank = chol_coop<N>(arow, e, 0.0, c, F);
   real pn = 0;
   if (full_rank) {
     p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
@@ -304,7 +301,7 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], int c, real
   if (!full_rank && alpha == 0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
   for (int it = 0; it < 10; it++) {
     if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-    chol_coop<N>(arow, alpha, c, F);
+    chol_coop<N>(arow, e, alpha, c, F);
     p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
     pn = km_sqrt(gsum8(p * p));
     const real q = tr_fwd<N>(F, p);
@@ -315,7 +312,7 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], int c, real
     alpha -= (phi + Delta) * ratio / Delta;
     if (fabs(phi) < 0.01 * Delta) break;
   }
-  chol_coop<N>(arow, alpha, c, F);
+  chol_coop<N>(arow, e, alpha, c, F);
   p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
   p *= Delta / km_sqrt(gsum8(p * p));
 }
@@ -426,7 +423,9 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
   const real ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
   const int max_nfev = 100 * N;
   const real jreg2 = 2 * P.m->ik_jac_reg * P.m->ik_jac_reg;
-  real ft[6], Jc[6], ft_new[6], Jn[6];
+  real ft[6], Jc[6], ft_new[6], Jn[6], e[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) e[j] = P.c == j ? 1.0 : 0.0;
   coop_eval<N, true>(P, x, ft, Jc, nullptr, nullptr);
   P.pf->ph(33);
   int nfev = 1;
@@ -458,17 +457,16 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       real s = 0;
       dppfma_acc3<j>(s, Jc[0], Jc[0], Jc[1], Jc[1], Jc[2], Jc[2]);
       dppfma_acc3<j>(s, Jc[3], Jc[3], Jc[4], Jc[4], Jc[5], Jc[5]);
-      if (j == P.c) s += jreg2;
+      s = __builtin_fma(e[j], jreg2, s);
       s *= d * bcast8<j>(d);
-      if (j == P.c) s += diag_h;
-      arow[j] = P.on ? s : 0.0;
+      arow[j] = P.on ? __builtin_fma(e[j], diag_h, s) : 0.0;
     });
     P.pf->ph(34);
     const real theta = fmax(0.995, 1 - g_norm);
     real actual = -1, x_new = x;
     while (actual <= 0 && nfev < max_nfev) {
       real ph = 0;
-      solve_tr_coop<N>(arow, P.c, g_h, Delta, alpha, ph);
+      solve_tr_coop<N>(arow, e, P.c, g_h, Delta, alpha, ph);
       P.pf->ph(35);
       real step_h;
       const real predicted = coop_select_step<N>(P, arow, x, d, ph, g_h, Delta, theta, step_h);
