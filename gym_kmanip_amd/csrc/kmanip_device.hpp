@@ -201,6 +201,10 @@ template <int K> __device__ __forceinline__ void fmac_bcast16(real& acc, real x,
 template <int K> __device__ __forceinline__ void fnmac_bcast16(real& acc, real x, real t) {
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
 }
+// The compiler's hazard recogniser does not look inside inline asm: a register WRITTEN by one of the asm runs here and then read
+// through DPP by compiler-generated code (gbcast, dpp_f64, bcast8) within the next two instructions would be read too early
+// (the 2 wait states a DPP read needs after a VALU write).  dpp_settle(x) spends them and pins x's definition before it.
+__device__ __forceinline__ void dpp_settle(real& x) { asm volatile("s_nop 1" : "+v"(x)); }
 // The same for one- or two-row groups.  A broadcast source is prepared once (BSrc): for G = 16 the value itself; for
 // G = 32 two copies made by one v_permlane16_swap per 32-bit half -- `e` carries the even row's values in both rows
 // of the pair, `o` the odd row's -- so that lane K of the 32-lane group is row_newbcast:(K & 15) of the right copy and

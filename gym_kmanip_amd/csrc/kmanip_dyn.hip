@@ -136,6 +136,18 @@ struct Ws {
   int slot_sph[NC];        // sphere index held by each active sphere slot (4..NC-1)
 };
 
+// One-row groups (round 3): lane c < NC OWNS contact slot c for the Newton solve -- its regulariser, friction coefficients and
+// reference offsets live in that lane's registers, the slot's pyramid edges are evaluated there (all slots at once, one per
+// lane), and what the other lanes need (four force components, seven Hessian weights) reaches them as row broadcasts folded
+// into their FMAs.  Round 2 spread the EDGES over the lanes and exchanged projections and forces through LDS records /
+// per-slot broadcasts, every lane redoing each slot's scalar arithmetic.
+// x_e = (u_0 - A_0) +- mu_k (u_k - A_k), u = J_c a: A_0 = -b v_0 - k imp dist, A_k = -b v_k (v = J_c qvel).
+struct SlotC {
+  real D, D3;        // 1 / R of the slot's edges and of its torsion pair (0: condim-3 pair / inactive slot / lane owns no slot)
+  real mu, mu3;      // tangential / torsional friction coefficient
+  real A[4];
+};
+
 // this lane's column of every contact basis: J (jb) and M^-1 J^T (bb); compile-time indexed only
 // (bb only for the slots that involve arm dofs: for table-cube slots M^-1 is diagonal, bb = jb * invm)
 // Newton path only: mrow = this lane's row of the arm inertia M; the lane's OWN single-dof constraint rows
@@ -146,6 +158,7 @@ template <int NL> struct CReg {
   real mrow[NL];
   real fl, Rf, Df, areff;    // friction-loss row x = a - areff          (fl = 0: no row); Df = 1 / Rf
   real sg, Rl, Dl, arefl;    // limit row         x = sg * a - arefl     (sg = 0: no row); Dl = 1 / Rl
+  SlotC sc;                  // one-row groups: the contact slot this lane owns
 };
 
 #ifdef KM_PROFILE
@@ -1302,6 +1315,7 @@ __device__ __forceinline__ void chol_rows(real (&h)[N], real& invd, int sub, int
     if (sub == k) invd = inv;
     const BSrc<G> lsrc = bsrc<G>(lik);
     fnmac_cols<G, k + 1, D1>(h, lsrc, lik);
+    if constexpr (k + 2 >= D1 && k + 1 < D1) dpp_settle(h[k + 1]);     // the next pivot's broadcast reads what the last run just wrote
   });
 }
 // x = (L L^T)^-1 b, b distributed one component per lane.  Forward substitution is column-oriented (z_k broadcast,
@@ -1361,6 +1375,7 @@ __device__ __forceinline__ void chol_rows1(real (&h)[N], real (&ut)[N], real& in
         fnmac_bcast16<j - BASE>(h[j], lik, lik);
       });
     }
+    if constexpr (k + 2 >= D1 && k + 1 < D1) dpp_settle(h[k + 1]);     // the next pivot's broadcast reads what the last run just wrote
   });
 }
 // ut[k] = L[k][sub] through LDS: lane i writes row i of L (exact zeros on and above the diagonal), lane s reads column s
@@ -1432,6 +1447,13 @@ __device__ __forceinline__ void plane_proj(const Ws<NL>& w, int c, const real* l
   u[0] = v[2]; u[1] = v[1]; u[2] = -v[0]; u[3] = angw[2];     // KM_PLANE_FRAME rows
 }
 
+// the same for the table-cube slot that lane `sub` owns (lanes 0..3; the others get slot 0's numbers, which they never use):
+// ONE evaluation serves all four corner slots
+template <int NL>
+__device__ __forceinline__ void plane_proj_lane(const Ws<NL>& w, int sub, const real* lin, const real* angw, real* u) {
+  plane_proj<NL>(w, sub < 4 ? sub : 0, lin, angw, u);
+}
+
 // Constraint assembly for Newton: like build_constraints but no B = M^-1 J^T / Gram tables -- only the
 // first-edge diagonal (for MuJoCo's pyramidal regulariser) and the velocity projections (for aref).  The
 // single-dof rows (friction loss, joint limits) of dof `sub` are built into this lane's registers: the primal
@@ -1439,6 +1461,7 @@ __device__ __forceinline__ void plane_proj(const Ws<NL>& w, int c, const real* l
 template <int NL, int G>
 __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
                                                          CReg<NL>& cr, real invm) {
+  SlotC& sc = cr.sc;
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   cr.fl = 0; cr.Rf = 1; cr.Df = 1; cr.areff = 0; cr.sg = 0; cr.Rl = 1; cr.Dl = 1; cr.arefl = 0;
   if (sub < NV) {
@@ -1515,8 +1538,19 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   const real qv = sub < NV ? w.qvel[sub] : 0.0;
   real qlin[3], qangw[3];
   cube_part<NL, G>(w, qv, qlin, qangw);
-  // velocity projections of every active slot (group sums: the same on every lane); lane c keeps slot c's
+  // velocity projections of every active slot; lane c keeps slot c's
   real vb[4] = {0, 0, 0, 0};
+  if constexpr (G == 16) {
+    plane_proj_lane<NL>(w, sub, qlin, qangw, vb);                 // table-cube slots: lane c < 4 evaluates ITS corner
+    static_for<4, NC>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      if ((act >> c) & 1u) {
+#pragma unroll
+        for (int k = 0; k < (slot_kind<NL>(c) == 2 ? 3 : 4); k++) { const real v = gsum<G>(cr.jb[c][k] * qv); vb[k] = sub == c ? v : vb[k]; }
+        if (slot_kind<NL>(c) == 2) vb[3] = sub == c ? 0.0 : vb[3];
+      }
+    });
+  } else {
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     if ((act >> c) & 1u) {
@@ -1530,8 +1564,10 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       for (int k = 0; k < 4; k++) vb[k] = sub == c ? v[k] : vb[k];
     }
   }
+  }
   // the solver record of slot `sub`, one slot per lane (all slots through ONE pass of the impedance / regulariser / reference
   // acceleration arithmetic instead of one unrolled copy per slot)
+  sc.D = 0; sc.D3 = 0; sc.mu = 0; sc.mu3 = 0; sc.A[0] = 0; sc.A[1] = 0; sc.A[2] = 0; sc.A[3] = 0;
   if (sub < NC && ((act >> sub) & 1u)) {
     const int c = sub, kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
     const bool cube = kind != 2;
@@ -1541,18 +1577,22 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
     const real Ad = kind == 0 ? lm.cornerA : lm.sphA[kind == 2][sp];   // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
     const real dist = w.c_dist[c];
     const real imp = impedance_c(lm.imp[cube ? 1 : 0], dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
+    const real R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad), Dn = frcp(R);
+    if constexpr (G == 16) {
+      sc.D = Dn; sc.D3 = kind == 2 ? 0.0 : Dn; sc.mu = fr[0]; sc.mu3 = fr[1];
+      sc.A[0] = -bb * vb[0] - kk * imp * dist; sc.A[1] = -bb * vb[1]; sc.A[2] = -bb * vb[2]; sc.A[3] = -bb * vb[3];
+    } else {
     ConRec& rc = w.rec[c];
-    rc.R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad);
-    rc.D = frcp(rc.R);
-    if constexpr (G != 16) {                       // (one-row groups exchange the edge forces by DPP, not through f[])
+    rc.R = R;
+    rc.D = Dn;
 #pragma unroll
-      for (int e = 0; e < 6; e++) rc.f[e] = 0;     // edge forces (the unused edges of a condim-3 pair stay 0)
-    }
+    for (int e = 0; e < 6; e++) rc.f[e] = 0;     // edge forces (the unused edges of a condim-3 pair stay 0)
 #pragma unroll
     for (int e = 0; e < 6; e++) {
       const int k = e / 2 + 1;
       const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
       rc.aref[e] = -bb * (vb[0] + sm * vb[k]) - kk * imp * dist;
+    }
     }
   }
   GSYNC();
@@ -2015,6 +2055,338 @@ __device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, con
   }
 }
 
+// =============================================================================================
+// Slot-lane Newton (one-row groups, G = 16).  Same mathematics and the same iterates as the edge-distributed code above (which
+// the two-row groups still run); the oracle mirrors neither layout, only the algorithm.
+
+// All six pyramid edges of the slot this lane owns at the shifted projections X (x_e = X_0 +- mu_k X_k): the slot's cost, the
+// force it applies along its four basis rows (F = sum_e f_e (1, +-mu_k)), and the Hessian weights of its active edges
+// W = sum_{x_e < 0} D_e (1, +-mu_k)(1, +-mu_k)^T, stored (W00, W01, W02, W03, W11, W22, W33).  Branch-free; an inactive slot
+// (D = D3 = 0) yields zeros.
+template <bool WEIGHTS>
+__device__ __forceinline__ real slot_eval(const SlotC& sc, const real (&X)[4], real (&F)[4], real (&W)[7]) {
+  const real t1 = sc.mu * X[1], t2 = sc.mu * X[2], t3 = sc.mu3 * X[3];
+  const real x1p = X[0] + t1, x1m = X[0] - t1, x2p = X[0] + t2, x2m = X[0] - t2, x3p = X[0] + t3, x3m = X[0] - t3;
+  const real m1p = fmin(x1p, 0.0), m1m = fmin(x1m, 0.0), m2p = fmin(x2p, 0.0), m2m = fmin(x2m, 0.0), m3p = fmin(x3p, 0.0), m3m = fmin(x3m, 0.0);
+  const real s12 = (m1p + m1m) + (m2p + m2m), s3 = m3p + m3m;
+  F[0] = -(sc.D * s12 + sc.D3 * s3);                         // f_e = -D x_e on the active edges
+  F[1] = -(sc.mu * sc.D) * (m1p - m1m); F[2] = -(sc.mu * sc.D) * (m2p - m2m); F[3] = -(sc.mu3 * sc.D3) * (m3p - m3m);
+  if constexpr (WEIGHTS) {
+    const real d1p = x1p < 0 ? sc.D : 0.0, d1m = x1m < 0 ? sc.D : 0.0, d2p = x2p < 0 ? sc.D : 0.0, d2m = x2m < 0 ? sc.D : 0.0;
+    const real d3p = x3p < 0 ? sc.D3 : 0.0, d3m = x3m < 0 ? sc.D3 : 0.0;
+    W[0] = ((d1p + d1m) + (d2p + d2m)) + (d3p + d3m);
+    W[1] = sc.mu * (d1p - d1m); W[2] = sc.mu * (d2p - d2m); W[3] = sc.mu3 * (d3p - d3m);
+    W[4] = (sc.mu * sc.mu) * (d1p + d1m); W[5] = (sc.mu * sc.mu) * (d2p + d2m); W[6] = (sc.mu3 * sc.mu3) * (d3p + d3m);
+  }
+  return 0.5 * (sc.D * ((m1p * m1p + m1m * m1m) + (m2p * m2p + m2m * m2m)) + sc.D3 * (m3p * m3p + m3m * m3m));
+}
+// this slot's contribution to phi'(alpha) and phi''(alpha) along y (X already holds u + alpha y)
+__device__ __forceinline__ void slot_ls(const SlotC& sc, const real (&X)[4], const real (&y)[4], real& e1, real& e2) {
+  const real t1 = sc.mu * X[1], t2 = sc.mu * X[2], t3 = sc.mu3 * X[3], s1 = sc.mu * y[1], s2 = sc.mu * y[2], s3 = sc.mu3 * y[3];
+  const real x1p = X[0] + t1, x1m = X[0] - t1, x2p = X[0] + t2, x2m = X[0] - t2, x3p = X[0] + t3, x3m = X[0] - t3;
+  const real y1p = y[0] + s1, y1m = y[0] - s1, y2p = y[0] + s2, y2m = y[0] - s2, y3p = y[0] + s3, y3m = y[0] - s3;
+  const real a = (fmin(x1p, 0.0) * y1p + fmin(x1m, 0.0) * y1m) + (fmin(x2p, 0.0) * y2p + fmin(x2m, 0.0) * y2m);
+  const real a3 = fmin(x3p, 0.0) * y3p + fmin(x3m, 0.0) * y3m;
+  e1 += sc.D * a + sc.D3 * a3;
+  const real b = ((x1p < 0 ? y1p * y1p : 0.0) + (x1m < 0 ? y1m * y1m : 0.0)) + ((x2p < 0 ? y2p * y2p : 0.0) + (x2m < 0 ? y2m * y2m : 0.0));
+  const real b3 = (x3p < 0 ? y3p * y3p : 0.0) + (x3m < 0 ? y3m * y3m : 0.0);
+  e2 += sc.D * b + sc.D3 * b3;
+}
+
+// J_c v of every active slot of the subset, delivered to the lane that owns the slot (u of the other lanes / slots: finite
+// numbers that meet D = 0).  Table-cube slots: lane c < 4 reads the contact point's velocity off the cube twist (one
+// evaluation for all four); sphere slots: a group sum per basis row, kept by lane c.
+template <int NL, int G, int S>
+__device__ __forceinline__ void slot_project(const Ws<NL>& w, const CReg<NL>& cr, uint32_t act, int sub, real v, real (&u)[4]) {
+  constexpr int NC = Dim<NL>::NC;
+  using SS = SubSet<NL, S>;
+  u[0] = 0; u[1] = 0; u[2] = 0; u[3] = 0;
+  if constexpr (S != KM_SUB_ARM) {
+    real lin[3], angw[3];
+    cube_part<NL, G>(w, v, lin, angw);
+    plane_proj_lane<NL>(w, sub, lin, angw, u);
+  }
+  static_for<4, NC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if constexpr (SS::slot(c)) {
+      if ((act >> c) & 1u) {
+#pragma unroll
+        for (int k = 0; k < (slot_kind<NL>(c) == 2 ? 3 : 4); k++) { const real s = gsum<G>(cr.jb[c][k] * v); u[k] = sub == c ? s : u[k]; }
+        if (slot_kind<NL>(c) == 2) u[3] = sub == c ? 0.0 : u[3];
+      }
+    }
+  });
+}
+// grad -= J^T F over the subset's active slots: the four force components of slot c arrive from lane c inside the FMAs
+template <int NL, int G, int S>
+__device__ __forceinline__ void slot_grad(const CReg<NL>& cr, uint32_t act, const real (&F)[4], real& grad) {
+  constexpr int NC = Dim<NL>::NC;
+  using SS = SubSet<NL, S>;
+  static_for<0, NC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if constexpr (SS::slot(c)) {
+      if ((act >> c) & 1u) {
+        if constexpr (slot_kind<NL>(c) == 2) {
+          real g2 = 0;
+          dppfma_acc3<c>(g2, F[0], cr.jb[c][0], F[1], cr.jb[c][1], F[2], cr.jb[c][2]);
+          grad -= g2;
+        } else {
+          real g2 = 0;
+          dppfma_acc4<c>(g2, F[0], cr.jb[c][0], F[1], cr.jb[c][1], F[2], cr.jb[c][2], F[3], cr.jb[c][3]);
+          grad -= g2;
+        }
+      }
+    }
+  });
+}
+// does lane `sub` own a slot of the subset?
+template <int NL, int S> __device__ __forceinline__ bool slot_lane_in(int sub) {
+  constexpr int NC = Dim<NL>::NC, NSS = Dim<NL>::NSS;
+  return S == KM_SUB_ALL ? sub < NC : (S == KM_SUB_ARM ? (sub >= 4 + NSS && sub < NC) : sub < 4);
+}
+
+// Newton state at a start point (all slots, both cost parts): u = J a - A on the slot lanes, gradient, the lanes' own rows,
+// the slots' Hessian weights.  cs != nullptr: also this lane's share of the cost at a_s (MuJoCo's warm-start comparison).
+template <int NL, int G>
+__device__ __forceinline__ void newton_eval_sl(const Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr, real& grad, int& qf,
+                                               int& ql, real (&u)[4], real (&W)[7], real& c0, real& c1, real* cs = nullptr) {
+  constexpr int NV = Dim<NL>::NV;
+  const uint32_t act = w.cact;
+  const SlotC& sc = cr.sc;
+  slot_project<NL, G, KM_SUB_ALL>(w, cr, act, sub, a, u);
+#pragma unroll
+  for (int k = 0; k < 4; k++) u[k] -= sc.A[k];
+  real F[4];
+  const real cslot = slot_eval<true>(sc, u, F, W);
+  real csl = 0;
+  if (cs) {
+    real us[4], Fs[4], Ws_[7];
+    slot_project<NL, G, KM_SUB_ALL>(w, cr, act, sub, a_s, us);
+#pragma unroll
+    for (int k = 0; k < 4; k++) us[k] -= sc.A[k];
+    csl = slot_eval<false>(sc, us, Fs, Ws_);
+  }
+  c0 = 0; c1 = 0;
+  grad = Mr;
+  qf = 0; ql = 0;
+  {
+    real co = 0.5 * (a - a_s) * Mr;
+    if (cr.fl > 0) { real f; co += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
+    if (cr.sg != 0) { real f; co += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
+    if (sub < NL) c0 = co; else if (sub < NV) c1 = co;
+    if (cs) {                                   // (the Gauss term vanishes at a_s)
+      real f; int qd;
+      if (cr.fl > 0) csl += row_eval(0, a_s - cr.areff, cr.Rf, cr.Df, cr.fl, f, qd);
+      if (cr.sg != 0) csl += row_eval(1, cr.sg * a_s - cr.arefl, cr.Rl, cr.Dl, 0.0, f, qd);
+    }
+  }
+  if (sub < 4) c1 += cslot; else c0 += cslot;       // table-cube slots belong to the cube part (lanes without a slot: cslot = 0)
+  slot_grad<NL, G, KM_SUB_ALL>(cr, act, F, grad);
+  if (cs) *cs = csl;
+}
+
+// Hessian row `sub` (block [D0, D1) of the subset) from the slots' weights: H += J_c^T W_c J_c, the weights of slot c arriving
+// from lane c inside the FMAs that build t = W_c J_c[:, sub]
+template <int NL, int G, int S>
+__device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, const CReg<NL>& cr, real mdiag, int qf, int ql,
+                                                  const real (&W)[7], real (&h)[Dim<NL>::NV]) {
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+  using SS = SubSet<NL, S>;
+  const uint32_t act = w.cact;
+  const bool in = sub >= SS::D0 && sub < SS::D1;
+  {
+    real dg = sub < NL ? 0.0 : mdiag;
+    if (qf) dg += cr.Df;
+    if (ql) dg += cr.Dl;
+#pragma unroll
+    for (int j = 0; j < NV; j++) h[j] = in ? (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0) : 0.0;
+  }
+  static_for<0, NC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if constexpr (SS::slot(c)) {
+      if ((act >> c) & 1u) {
+        const real j0 = cr.jb[c][0], j1 = cr.jb[c][1], j2 = cr.jb[c][2], j3 = cr.jb[c][3];
+        real t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if constexpr (SS::kind(c) != 2) {
+          dppfma_acc4<c>(t0, W[0], j0, W[1], j1, W[2], j2, W[3], j3);
+          dppfma3<false, c, c, c>(t1, W[1], j0, t2, W[2], j0, t3, W[3], j0);
+          dppfma3<false, c, c, c>(t1, W[4], j1, t2, W[5], j2, t3, W[6], j3);
+        } else {                                                                // (condim-3 pairs have no torsion row)
+          dppfma_acc3<c>(t0, W[0], j0, W[1], j1, W[2], j2);
+          dppfma2<false, c, c>(t1, W[1], j0, t2, W[2], j0);
+          dppfma2<false, c, c>(t1, W[4], j1, t2, W[5], j2);
+        }
+        static_for<SS::c0(c), SS::c1(c)>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (SS::kind(c) != 2) dppfma_acc4<j & 15>(h[j], j0, t0, j1, t1, j2, t2, j3, t3);
+          else dppfma_acc3<j & 15>(h[j], j0, t0, j1, t1, j2, t2);
+        });
+      }
+    }
+  });
+}
+
+// Newton iterations on one dof subset, from the point (a, Mr, grad, qf, ql, u, W) with cost `cost` (all of the subset).
+template <int NL, int G, int S>
+__device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, const CReg<NL>& cr,
+                                               real mdiag, real a_s, real& a, real& Mr, real cost, real& grad, int& qf, int& ql,
+                                               real (&u)[4], real (&W)[7], Prof& pf) {
+  static_assert(G == 16, "slot-lane Newton: one DPP row per env");
+  constexpr int NV = Dim<NL>::NV;
+  using SS = SubSet<NL, S>;
+  const uint32_t act = w.cact;
+  const SlotC& sc = cr.sc;
+  const bool in = sub >= SS::D0 && sub < SS::D1;
+  const bool slin = slot_lane_in<NL, S>(sub);          // this lane's slot belongs to the subset (its cost counts, its u moves)
+  const real scale = lm.scale;
+  const real tol = m->solver_tolerance;
+  const int maxit = m->solver_iterations;
+  {
+    const real g0 = in ? grad : 0.0;
+    if (km_sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
+  }
+  for (int iter = 0; iter < maxit; iter++) {
+    real p;
+    // (Woodbury shortcut of the arm problem: see newton_loop)
+    bool plain = false;
+    uint32_t rows = 0;
+    if constexpr (S == KM_SUB_ARM) {
+      const unsigned long long bq = __ballot(slin && W[0] != 0);              // a sphere-table slot with edges in their quadratic zone
+      const unsigned long long bal = __ballot(in && (qf | ql));
+      const int sh = (threadIdx.x & 63) - sub;
+      rows = (uint32_t)(bal >> sh) & 0xFFFFu;
+      plain = ((uint32_t)(bq >> sh) & 0xFFFFu) == 0 && __popc(rows) <= 2;
+    }
+    if (plain) {
+      real y = 0;
+      const BSrc<G> gs = bsrc<G>(in ? grad : 0.0);
+      const int row = sub < NL ? sub : 0;
+      fmac_rowvec<G, 0, NL>(y, gs, [&](int j) { return w.Minv[row][j]; });
+      real corr = 0;
+      if (rows) {
+        const int i1 = __ffs(rows) - 1, i2 = (rows & (rows - 1)) ? __ffs(rows & (rows - 1)) - 1 : i1;
+        const real dl = (qf ? cr.Df : 0.0) + (ql ? cr.Dl : 0.0);
+        const real y1 = __shfl(y, i1, G), y2 = __shfl(y, i2, G);
+        const real a11 = frcp(__shfl(dl, i1, G)) + w.Minv[i1][i1];
+        real z1, z2 = 0;
+        if (i2 == i1) z1 = y1 * frcp(a11);
+        else {
+          const real a22 = frcp(__shfl(dl, i2, G)) + w.Minv[i2][i2], a12 = w.Minv[i1][i2];
+          const real idet = frcp(a11 * a22 - a12 * a12);
+          z1 = (a22 * y1 - a12 * y2) * idet;
+          z2 = (a11 * y2 - a12 * y1) * idet;
+        }
+        corr = w.Minv[row][i1] * z1 + (i2 == i1 ? 0.0 : w.Minv[row][i2] * z2);
+      }
+      p = in ? -(y - corr) : 0.0;
+      pf.ph(11 + 6 * S);
+    } else {
+      real h[NV];
+      newton_hessian_sl<NL, G, S>(w, sub, cr, mdiag, qf, ql, W, h);
+      pf.ph(9 + 6 * S);
+      real invd = 0, ut[NV];
+      int hbad = 0;
+      constexpr int ND = SS::D1 - SS::D0;
+      if constexpr (ND <= 6) {
+        chol_rows1<NV, SS::D0, SS::D1, 0, true>(h, ut, invd, sub, true, hbad);
+      } else {
+        chol_rows1<NV, SS::D0, SS::D1, 0, false>(h, ut, invd, sub, true, hbad);
+        chol_transpose<NV, SS::D0, SS::D1, 0>(w.LT, h, ut, sub);
+      }
+      if (hbad && sub == 0) w.bad = 1;
+      pf.ph(10 + 6 * S);
+      p = chol_solve_rows1<NV, SS::D0, SS::D1, 0>(h, ut, invd, in ? -grad : 0.0);
+      pf.ph(11 + 6 * S);
+    }
+    // ---- exact line search on phi(alpha) = cost(a + alpha p)
+    real Mp;
+    if constexpr (S == KM_SUB_CUBE) Mp = mdiag * p; else Mp = mass_mul<NL, G>(cr, sub, mdiag, p);
+    const real gp = gsum<G>(in ? p * Mr : 0.0), pMp = gsum<G>(p * Mp), d10 = gsum<G>(in ? p * grad : 0.0);
+    real y[4];
+    slot_project<NL, G, S>(w, cr, act, sub, p, y);
+    if (!slin) { y[0] = 0; y[1] = 0; y[2] = 0; y[3] = 0; }     // slots outside the subset do not move
+    const real xf = a - cr.areff, xl = cr.sg * a - cr.arefl, yl = cr.sg * p;
+    pf.ph(12 + 6 * S);
+    real alpha = 0, lo = 0, hi = INFINITY;
+    if (d10 < 0) {
+      alpha = 1;
+      for (int it = 0; it < 50; it++) {
+        real e1 = 0, e2 = 0;
+        if (in && cr.fl > 0) row_ls(0, xf + alpha * p, p, cr.Rf, cr.Df, cr.fl, e1, e2);
+        if (in && cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, cr.Dl, 0.0, e1, e2);
+        const real X[4] = {u[0] + alpha * y[0], u[1] + alpha * y[1], u[2] + alpha * y[2], u[3] + alpha * y[3]};
+        slot_ls(sc, X, y, e1, e2);
+        const real d1 = gp + alpha * pMp + gsum<G>(e1);
+        const real d2 = pMp + gsum<G>(e2);
+        if (fabs(d1) <= 1e-8 * fabs(d10)) break;        // MuJoCo's ls_tolerance is 1e-2; the outer Newton absorbs the rest
+        if (d1 < 0) lo = alpha; else hi = alpha;
+        if (hi - lo <= 1e-14 * hi) break;                 // bracket collapsed to roundoff
+        if (it == 49) break;
+        real an = alpha - d1 * frcp(d2);
+        if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
+        alpha = an;
+      }
+    }
+    pf.ph(13 + 6 * S);
+    // ---- advance the point and everything linear in it, evaluate
+    a += alpha * p;
+    Mr += alpha * Mp;
+#pragma unroll
+    for (int k = 0; k < 4; k++) u[k] += alpha * y[k];
+    real F[4];
+    const real cslot = slot_eval<true>(sc, u, F, W);
+    real cl = slin ? cslot : 0.0;
+    if (in) {
+      cl += 0.5 * (a - a_s) * Mr;
+      grad = Mr;
+      qf = 0; ql = 0;
+      if (cr.fl > 0) { real f; cl += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
+      if (cr.sg != 0) { real f; cl += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
+    }
+    real gsl = grad;
+    slot_grad<NL, G, S>(cr, act, F, gsl);
+    if (in) grad = gsl;
+    const real cost_new = gsum<G>(cl);
+    const real g1 = in ? grad : 0.0;
+    const real improvement = scale * (cost - cost_new), gradient = scale * km_sqrt(gsum<G>(g1 * g1));
+    cost = cost_new;
+    pf.ph(14 + 6 * S);
+    if (improvement < tol || gradient < tol || w.bad) break;
+  }
+}
+
+template <int NL, int G>
+__device__ __forceinline__ real solve_newton_sl(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, CReg<NL>& cr, real a_s,
+                                                real invm, Prof& pf) {
+  constexpr int NV = Dim<NL>::NV;
+  const uint32_t act = w.cact;
+  const real warm = sub < NV ? w.warm[sub] : 0.0;
+  const real mdiag = (sub >= NL && sub < NV) ? 1.0 / invm : 0.0;
+  real grad; int qf, ql;
+  real u[4], W[7];
+  real c0, c1, csl;
+  real a = warm;
+  real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
+  newton_eval_sl<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1, &csl);
+  const real cs = gsum<G>(csl);
+  real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
+  pf.ph(8);
+  if (!(cost0 + cost1 < cs)) {
+    a = a_s; Mr = 0;
+    newton_eval_sl<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1);
+    cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
+    pf.ph(38);
+  }
+  constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
+  if (act & FC_MASK) {
+    newton_loop_sl<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, u, W, pf);
+  } else {
+    newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, u, W, pf);
+    newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, u, W, pf);
+  }
+  return a;
+}
+
 template <int NL, int G>
 __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
                                              CReg<NL>& cr, real invm, Prof& pf) {
@@ -2035,6 +2407,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   if (sub < NL) { for (int j = 0; j < NL; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
   else if (sub < NV) a_s = w.tmp[sub] * invm;
   pf.ph(7);
+  if constexpr (G == 16) return solve_newton_sl<NL, G>(w, lm, m, sub, cr, a_s, invm, pf);
   const uint32_t act = w.cact;
   const real warm = sub < NV ? w.warm[sub] : 0.0;
   const real mdiag = (sub >= NL && sub < NV) ? 1.0 / invm : 0.0;
@@ -2202,6 +2575,12 @@ __device__ __forceinline__ void reset_env(Ws<NL>& w, const LModel<NL>& lm, const
   GSYNC();
 }
 
+// contact points of slots that never became active are read (and multiplied by zero weights) by the slot-lane solver: give
+// them finite values once per launch
+template <int NL>
+__device__ __forceinline__ void init_ws(Ws<NL>& w, int sub) {
+  if (sub < Dim<NL>::NC) { w.c_pos[sub][0] = 0; w.c_pos[sub][1] = 0; w.c_pos[sub][2] = 0; w.c_dist[sub] = 0; }
+}
 // fused = before_step runs in this kernel: ctrl <- float32(ctrl) (env_sim.py:40) and qpos_ik <- qpos here
 template <int NL, int G>
 __device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, int env, int sub, bool fused) {
@@ -2292,6 +2671,10 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   Prof pf;
   pf.start();
   const bool fused = act != nullptr;
+#ifdef KM_DEBUG_NANFILL
+  { double* wp = reinterpret_cast<double*>(&w); for (int i = sub; i < (int)(sizeof(Ws<NL>) / 8); i += G) wp[i] = KM_DEBUG_NANFILL; GSYNC(); }
+#endif
+  init_ws<NL>(w, sub);
   load_state<NL, G>(w, st, env, sub, fused);
   int step_idx = st.step_idx[env], episode = st.episode[env];
   const size_t NE = (size_t)st.num_envs;
@@ -2416,6 +2799,7 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   int episode = st.episode[env] + 1;
   Prof pf;
   pf.start();
+  init_ws<NL>(w, sub);
   reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
   if (obs) write_obs<NL, G>(w, lm, m, sub, obs + (size_t)env * m->obs_dim);
   if (sub == 0) { st.step_idx[env] = 0; st.episode[env] = episode; st.contact_mask[env] = 0; if (st.sim_time) st.sim_time[env] = 0; }

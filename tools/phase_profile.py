@@ -73,3 +73,7 @@ if "B" in dir():
         g = B[wv]
         print("  wave %4d  %8.0f | IK %7.0f  ALL %7.0f  ARM %7.0f  CUBE %7.0f  fixed %7.0f" % (
             wv, tot_b[wv], g[:, ik].sum(1).max(), g[:, allp].sum(1).max(), g[:, armp].sum(1).min(), g[:, cubep].sum(1).max(), g[:, fixed].sum(1).max()))
+    print("IK slots of the IK-heaviest group of the 4 slowest waves: before_step | res+jac | normal matrix | TR solve | select_step | ratio/tests")
+    for wv in order[-4:][::-1]:
+        g = B[wv]; gi = g[:, ik].sum(1).argmax()
+        print("  wave %4d group %d  " % (wv, gi) + "  ".join("%8.0f" % g[gi, i] for i in ik))
