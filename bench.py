@@ -3,7 +3,9 @@
 
 A "step" is one control step of every env on the rank = one pass of the hot path
 (decode + IK -> 10 physics sub-steps -> reward/obs/done, auto-reset every 64 steps) over one batch of
-synthetic actions (i.i.d. U(-1,1) float32, pre-generated, resident in HBM).  One process per GPU; envs
+synthetic actions: action_space.sample() of every env (i.i.d. U[-1,1) float32) from the counter-based stream SURVEY 8d specifies
+-- Philox4x32-10 keyed (seed; global env id, episode, step), drawn ON THE DEVICE by kmanip_sample_action for every step of the
+run before the timed region starts (resident in HBM); the CPU baseline leg draws the same stream from the oracle.  One process per GPU; envs
 shard by global env index with no data-path collective except the per-step reward/done all-gather the
 north star names (RCCL, async, off the critical path).  Rank 0 prints ONE JSON line.
 
@@ -203,26 +205,38 @@ def cpu_baseline(cm, n_envs, budget_s=12.0):
     n = min(n_envs, 1024)
     o = Oracle(cm, n, seed=0)
     o.reset()
-    rng = np.random.default_rng(0)
-    acts = rng.uniform(-1, 1, (8, n, cm.act_dim)).astype(np.float32)
     for k in range(10):                   # untimed: let the cubes land so contacts are in the sample
-        o.step(acts[k % 8], nthreads=cores)
+        o.step(o.sample_action(), nthreads=cores)
     t0 = time.perf_counter(); steps = 0
     while True:
-        o.step(acts[steps % 8], nthreads=cores); steps += 1
+        o.step(o.sample_action(), nthreads=cores); steps += 1       # the device's action stream (same Philox keys), drawn per step
         dt = time.perf_counter() - t0
         if dt > budget_s or steps >= 54:
             break
     return {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d control steps (episode steps 10..%d, contacts active), OpenMP over envs, %d threads"
+            "sample": "%d envs x %d control steps (episode steps 10..%d, contacts active; the device's Philox action stream), OpenMP over envs, %d threads"
                       % (n, steps, 10 + steps, cores),
             "mujoco": "absent on the GPU box (import probe: profiles/r02_probe_imports.txt), so no MuJoCo-timed baseline"}
 
 
-class Workload:
-    """One rank's envs + action bank, prepared to the desynchronised steady state."""
+def check_ranks_seen(ranks_seen, world, rank):
+    """Start-up self-check of the rank path: the all-reduce of ones must count every rank, or the collective backend is not
+    spanning the job (a mis-set MASTER_* / IPC mode would otherwise show up only as a wrong whole-job value).  Returns the
+    process exit code (0 = fine)."""
+    if ranks_seen != world:
+        sys.stderr.write("bench.py: rank %d: the collective backend sees %d rank(s), WORLD_SIZE is %d -- refusing to report a whole-job value\n"
+                         % (rank, ranks_seen, world))
+        return 4
+    return 0
 
-    def __init__(self, torch, env_id, n, device_index, rank, off, solver, solver_iterations, seed_gen, stagger=True, nbank=16):
+
+class Workload:
+    """One rank's envs, prepared to the desynchronised steady state, stepping on the counter-based action stream
+    (kmanip_sample_action: Philox keyed (seed; global env id, episode, step) -- fresh actions every step of every episode, as
+    the loop this imitates samples them: examples/2_log_with_h5py.py:22-26)."""
+    BANK_MAX = 4096                       # steps laid out ahead in HBM at most (4096 x 4096 envs x 7 x 4 B = 470 MB)
+
+    def __init__(self, torch, env_id, n, device_index, rank, off, solver, solver_iterations, stagger=True):
         from gym_kmanip_amd import env_hip
         from gym_kmanip_amd.model import compile_model
         import numpy as np
@@ -230,10 +244,8 @@ class Workload:
         self.cm = compile_model(env_id, auto_reset=True, solver_iterations=solver_iterations, solver=solver)
         self.n = n
         self.env = env_hip.KManipEnvHip(self.cm, num_envs=n, device=device_index, seed=0, env_id_offset=off)
-        gen = torch.Generator(device="cuda"); gen.manual_seed(seed_gen)
-        self.gen = gen
-        self.nbank = nbank
-        self.acts = [(torch.rand((n, self.cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous() for _ in range(nbank)]
+        self.act = torch.empty((n, self.cm.act_dim), dtype=torch.float32, device="cuda")
+        self.bank = None
         self.k = 0
         self.env.k_reset()
         if stagger:
@@ -243,8 +255,22 @@ class Workload:
             self.run(EPISODE)             # one full episode: every env has been through its own reset since the stagger
         torch.cuda.synchronize()
 
+    def lay_out(self, steps):
+        """Draw the actions of the next `steps` control steps into HBM now (the timed region then only steps)."""
+        torch = self.torch
+        steps = min(steps, self.BANK_MAX)
+        self.bank = torch.empty((steps, self.n, self.cm.act_dim), dtype=torch.float32, device="cuda")
+        for k in range(steps):
+            self.env.sample_action(self.bank[k], ahead=k)
+        self.k = 0
+        torch.cuda.synchronize()
+
     def step(self):
-        self.env.step_flat(self.acts[self.k % self.nbank]); self.k += 1
+        if self.bank is not None and self.k < self.bank.shape[0]:
+            a = self.bank[self.k]
+        else:                             # beyond the bank: drawn in the loop (one tiny extra launch per step)
+            a = self.env.sample_action(self.act)
+        self.env.step_flat(a); self.k += 1
 
     def run(self, steps):
         for _ in range(steps):
@@ -252,6 +278,7 @@ class Workload:
 
     def timed(self, steps, warmup):
         torch = self.torch
+        self.lay_out(warmup + steps)
         self.run(warmup)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         self.run(steps)
@@ -263,7 +290,7 @@ class Workload:
 
 
 def measure_variant(torch, args, n, local_rank, rank, solver, stagger, steps, warmup):
-    w = Workload(torch, args.env, n, local_rank, rank, rank * n, solver, args.solver_iterations, 99, stagger=stagger)
+    w = Workload(torch, args.env, n, local_rank, rank, rank * n, solver, args.solver_iterations, stagger=stagger)
     dt = w.timed(steps, warmup)
     w.close()
     return {"solver": solver, "staggered": stagger, "value": n * steps / dt, "unit": "env steps/s", "steps": steps,
@@ -274,16 +301,19 @@ def measure_chunked(torch, w, K):
     """Secondary: the same workload through kmanip_step_chunk (K pre-supplied actions per env and launch, as an
     action-chunking policy or a scripted stream provides).  Not the headline: the metric is per-step stepping."""
     n, cm, env = w.n, w.cm, w.env
-    acts = (torch.rand((K, n, cm.act_dim), generator=w.gen, device="cuda") * 2 - 1).contiguous()
+    launches, warm = 16, 4
+    acts = torch.empty((warm + launches, K, n, cm.act_dim), dtype=torch.float32, device="cuda")
+    for i in range(warm + launches):          # the stream's next (warm + launches) * K steps, laid out before the timed region
+        for k in range(K):
+            env.sample_action(acts[i, k], ahead=i * K + k)
     obs = torch.empty((K, n, cm.obs_dim), dtype=torch.float64, device="cuda")
     rew = torch.empty((K, n), dtype=torch.float64, device="cuda"); done = torch.empty((K, n), dtype=torch.uint8, device="cuda")
-    for _ in range(4):
-        env.step_chunk(acts, obs, rew, done)
+    for i in range(warm):
+        env.step_chunk(acts[i], obs, rew, done)
     torch.cuda.synchronize()
-    launches = 16
     t0 = time.perf_counter()
-    for _ in range(launches):
-        env.step_chunk(acts, obs, rew, done)
+    for i in range(launches):
+        env.step_chunk(acts[warm + i], obs, rew, done)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"api": "kmanip_step_chunk", "steps_per_launch": K, "value": n * K * launches / dt, "unit": "env steps/s",
@@ -295,18 +325,20 @@ def measure_seam(torch, w, steps=256):
     """The drop-in path: KManipEnvHip.k_step with a DICT of device tensors keyed like the reference action space
     (env_base.py:241-259 -> env_sim.py:196-200), returning the 5-tuple -- vs step_flat on the same envs."""
     n, cm, env = w.n, w.cm, w.env
-    bank = [{k: a[:, sl] for k, sl in cm.act_slices.items()} for a in w.acts]
+    w.lay_out(2 * steps + 16)
+    flat = [w.bank[k] for k in range(w.bank.shape[0])]
+    bank = [{k: a[:, sl] for k, sl in cm.act_slices.items()} for a in flat]
     for k in range(8):
         env.k_step(bank[k % len(bank)])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(steps):
-        terminated, reward, discount, obs, sim_time = env.k_step(bank[k % len(bank)])
+        terminated, reward, discount, obs, sim_time = env.k_step(bank[8 + k])
     torch.cuda.synchronize(); dt_seam = time.perf_counter() - t0
     for k in range(8):
-        env.step_flat(w.acts[k % len(w.acts)])
+        env.step_flat(flat[8 + steps + k])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(steps):
-        env.step_flat(w.acts[k % len(w.acts)])
+        env.step_flat(flat[16 + steps + k])
     torch.cuda.synchronize(); dt_flat = time.perf_counter() - t0
     return {"api": "KManipEnvHip.k_step(dict of device tensors) -> (terminated, reward, discount, obs dict, sim_time)",
             "value": n * steps / dt_seam, "unit": "env steps/s", "steps": steps, "step_flat_value": n * steps / dt_flat,
@@ -347,14 +379,16 @@ def run_rank(args):
         n, off = hi - lo, lo
     else:
         n, off = args.envs_per_gpu, rank * args.envs_per_gpu
-    w = Workload(torch, args.env, n, local_rank, rank, off, args.solver, args.solver_iterations, 1234 + rank,
-                 stagger=not args.no_stagger)
+    w = Workload(torch, args.env, n, local_rank, rank, off, args.solver, args.solver_iterations, stagger=not args.no_stagger)
     env, cm = w.env, w.cm
 
     gather = None
     ranks_seen = 1
     if dist is not None:
         t = torch.ones(1, device="cuda"); dist.all_reduce(t); ranks_seen = int(t.item())      # RCCL really spans all ranks
+        rc = check_ranks_seen(ranks_seen, world, rank)
+        if rc:
+            return rc
         if not args.no_gather:
             from gym_kmanip_amd.dist import RewardDoneGather
             gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist)
@@ -374,6 +408,7 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    w.lay_out(args.warmup + args.steps)
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -385,7 +420,7 @@ def run_rank(args):
         gather.wait()
     barrier()
     dt = time.perf_counter() - t0
-    ik_ms, dyn_ms, nt = env.timing_summary()
+    ik_ms, dyn_ms, rnd_ms, nt = env.timing_summary()
     env.enable_timing(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -397,9 +432,12 @@ def run_rank(args):
         total_envs = args.envs_total if args.envs_total else world * n
         total_env_steps = total_envs * args.steps
         bpe = algorithmic_bytes_per_env_step(cm, args.depth)
-        bytes_per_launch = algorithmic_bytes_per_env_step(cm) * n        # k_step alone (the depth image is k_render_depth's)
+        # the launch(es) of one step: k_step, plus k_render when the depth image is rendered in the step (config 5) -- the
+        # algorithmic bytes of BOTH over the time of BOTH
+        bytes_per_launch = bpe * n
         dyn_avg_s = dyn_ms / max(nt, 1) * 1e-3
-        achieved = bytes_per_launch / dyn_avg_s / 1e9
+        step_kernels_s = (dyn_ms + rnd_ms) / max(nt, 1) * 1e-3
+        achieved = bytes_per_launch / step_kernels_s / 1e9
         nl = cm.nlink
         kprefix = "void k_step<%d, %d, %d" % (10 if nl <= 10 else 20, 16 if nl <= 10 else 32, 1 if args.solver == "newton" else 0)
         cc = committed_counters(version, kprefix) if (args.env == "KManipSoloArm" and n == 4096 and not args.no_stagger) else \
@@ -417,9 +455,11 @@ def run_rank(args):
             "metric": metric,
             "value": total_env_steps / dt, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if args.envs_total else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.envs_total else "weak",
+            "vs_baseline": None,          # BASELINE.md holds no published number for this metric (the CPU leg below is a port, not a baseline to divide by)
+            "dtype": "f64", "data": "synthetic",
             "timed_window_s": dt,
-            "config": {"workload": "%s, %d envs per GPU (%d total), %s, random U(-1,1) actions, 64-step episodes with auto-reset, %s"
+            "config": {"workload": "%s, %d envs per GPU (%d total), %s, action_space.sample() per step from the Philox stream keyed (seed; env id, episode, step), 64-step episodes with auto-reset, %s"
                                    % (args.env, n, total_envs, ("%dx%d float32 grip_r depth render in the step" % (args.depth, args.depth)) if args.depth else "no cameras",
                                       "phase-locked envs" if args.no_stagger else "envs desynchronised (episode phase = global env id % 64, one pre-rolled episode)"),
                        "envs_per_gpu": n, "depth_image": ("%dx%d float32 grip_r" % (args.depth, args.depth)) if args.depth else None,
@@ -427,12 +467,13 @@ def run_rank(args):
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
                        "collective": "async all_gather of (reward, done) per step" if gather is not None else "none",
                        "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None, "library": version},
-            "roofline": {"bound": "hbm", "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "bound_note": "the contract's two choices are hbm | mfma; this kernel is bound by FP64 VALU issue and dependent latency (see valu), its HBM fraction is small by construction",
+                         "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)" + (" + k_render (in-step depth image)" if args.depth else ""), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": cc["traffic"], "traffic_source": cc["traffic_source"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_env_step": bpe,
-                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1), "launches_timed": nt},
+                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1), "launches_timed": nt},
                          "valu": valu,
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }

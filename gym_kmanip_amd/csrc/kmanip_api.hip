@@ -25,14 +25,14 @@ struct KHandle_ {
   int device = 0;
   int num_envs = 0;
   std::string err;
-  std::vector<hipEvent_t> ev;   // 3 events per timed step
+  std::vector<hipEvent_t> ev;   // 4 events per timed step
+  std::vector<char> ev_render;  // the step rendered in the step (its fourth event was recorded)
   bool timing = false;
   int timed_steps = 0;
   // render target bound to the step (BASELINE config 5: "depth render in the step"): kmanip_step then also renders
   int step_cam = -1, step_h = 0, step_w = 0;
   float* step_depth = nullptr;
   bool ik_unfused = false;      // KMANIP_IK_UNFUSED=1: before_step as its own launch (A/B timing only)
-  bool ik_serial = false;       // KMANIP_IK_SERIAL=1: one-lane-per-problem IK kernel (A/B and cross-check only)
   std::vector<void*> allocs;
 };
 
@@ -207,11 +207,7 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.seed = seed;
   h->st.sim_time = nullptr;
   h->st.control_dt = desc->n_sub_steps * desc->timestep;
-  { const char* e = getenv("KMANIP_IK_SERIAL"); h->ik_serial = e && e[0] == '1'; }
   { const char* e = getenv("KMANIP_IK_UNFUSED"); h->ik_unfused = e && e[0] == '1'; }
-#ifndef KM_DIAG_SERIAL_IK
-  if (h->ik_serial) { g_create_error = "KMANIP_IK_SERIAL needs the diagnostic build (make diag): the one-lane IK kernel is not in the product library"; kmanip_destroy(h); return -5; }
-#endif
   // the initialisation above ran on the null stream; the caller's (non-blocking) streams must not start before it
   CR(hipDeviceSynchronize());
 #undef CR
@@ -244,22 +240,24 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   KM_ENTER(h);
   hipStream_t s = (hipStream_t)stream;
   const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
-  hipEvent_t* ev = tm ? &h->ev[3 * (size_t)h->timed_steps] : nullptr;
+  hipEvent_t* ev = tm ? &h->ev[4 * (size_t)h->timed_steps] : nullptr;
   if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
   // product path: ONE launch, before_step (decode + IK) fused into k_step so that no device-wide barrier sits between
-  // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1 / KMANIP_IK_SERIAL=1)
-  const bool split = h->ik_serial || h->ik_unfused;
-  if (split && nchunk != 1) { h->err = "kmanip_step_chunk needs the fused path (unset KMANIP_IK_UNFUSED / KMANIP_IK_SERIAL)"; return -1; }
-#ifdef KM_DIAG_SERIAL_IK
-  if (h->ik_serial) kmanip_launch_ik(h->dmodel, h->desc, h->st, act_dev, s);
-  else
-#endif
+  // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1)
+  const bool split = h->ik_unfused;
+  if (split && nchunk != 1) { h->err = "kmanip_step_chunk needs the fused path (unset KMANIP_IK_UNFUSED)"; return -1; }
   if (h->ik_unfused) kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
   kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);
-  if (tm) { HIPCHK(h, hipEventRecord(ev[2], s)); h->timed_steps++; }
-  if (h->step_depth && nchunk == 1)       // the observation's camera branch (env_sim.py:140-145) of the state just produced
+  if (tm) HIPCHK(h, hipEventRecord(ev[2], s));
+  const bool render = h->step_depth && nchunk == 1;
+  if (render)                             // the observation's camera branch (env_sim.py:140-145) of the state just produced
     kmanip_launch_render_depth(h->dmodel, h->st, h->step_cam, h->step_h, h->step_w, h->step_depth, s);
+  if (tm) {
+    if (render) HIPCHK(h, hipEventRecord(ev[3], s));
+    h->ev_render[h->timed_steps] = render;
+    h->timed_steps++;
+  }
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -324,26 +322,29 @@ int kmanip_enable_timing(KHandle h, int enable) {
   if (!h) return -1;
   KM_ENTER(h);
   if (enable && h->ev.empty()) {
-    h->ev.resize(3 * KM_TIMING_SLOTS, nullptr);
+    h->ev.resize(4 * KM_TIMING_SLOTS, nullptr);
+    h->ev_render.assign(KM_TIMING_SLOTS, 0);
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
   }
   h->timing = enable != 0;
   h->timed_steps = 0;
   return 0;
 }
-int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, int32_t* nsteps) {
+int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, double* render_ms_sum, int32_t* nsteps) {
   if (!h) return -1;
   KM_ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
-  double a = 0, b = 0;
+  double a = 0, b = 0, c = 0;
   for (int k = 0; k < h->timed_steps; k++) {
-    float m1 = 0, m2 = 0;
-    HIPCHK(h, hipEventElapsedTime(&m1, h->ev[3 * k], h->ev[3 * k + 1]));
-    HIPCHK(h, hipEventElapsedTime(&m2, h->ev[3 * k + 1], h->ev[3 * k + 2]));
-    a += m1; b += m2;
+    float m1 = 0, m2 = 0, m3 = 0;
+    HIPCHK(h, hipEventElapsedTime(&m1, h->ev[4 * k], h->ev[4 * k + 1]));
+    HIPCHK(h, hipEventElapsedTime(&m2, h->ev[4 * k + 1], h->ev[4 * k + 2]));
+    if (h->ev_render[k]) HIPCHK(h, hipEventElapsedTime(&m3, h->ev[4 * k + 2], h->ev[4 * k + 3]));
+    a += m1; b += m2; c += m3;
   }
   if (ik_ms_sum) *ik_ms_sum = a;
   if (dyn_ms_sum) *dyn_ms_sum = b;
+  if (render_ms_sum) *render_ms_sum = c;
   if (nsteps) *nsteps = h->timed_steps;
   h->timed_steps = 0;
   return 0;
@@ -476,10 +477,6 @@ int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos, c
   HIPCHK(h, hipMemcpy(dgp.p, goal_pos, sizeof(double) * n * 3, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(dgq.p, goal_quat, sizeof(double) * n * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipDeviceSynchronize());
-#ifdef KM_DIAG_SERIAL_IK
-  if (h->ik_serial) kmanip_launch_ik_standalone(h->dmodel, h->desc, arm, n, dq.as<double>(), dgp.as<double>(), dgq.as<double>(), dqo.as<double>(), dnf.as<int32_t>(), dst.as<int32_t>(), nullptr);
-  else
-#endif
   kmanip_launch_ik_coop_standalone(h->dmodel, h->desc, arm, n, dq.as<double>(), dgp.as<double>(), dgq.as<double>(), dqo.as<double>(), dnf.as<int32_t>(), dst.as<int32_t>(), nullptr);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipDeviceSynchronize());

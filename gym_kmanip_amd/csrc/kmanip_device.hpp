@@ -392,8 +392,6 @@ struct KDeviceState {
   uint64_t seed;
 };
 
-void kmanip_launch_ik(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act,
-                      hipStream_t stream);
 void kmanip_launch_ik_coop(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act,
                            hipStream_t stream);
 void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
@@ -401,9 +399,6 @@ void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& 
                                       int32_t* status, hipStream_t stream);
 void kmanip_launch_ik_eval_coop(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, const double* qpos_env_major,
                                 const double* goal_pos, const double* goal_quat, double* res, double* jac, hipStream_t stream);
-void kmanip_launch_ik_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,
-                                 const double* goal_pos, const double* goal_quat, double* q_out, int32_t* nfev,
-                                 int32_t* status, hipStream_t stream);
 // act != NULL: the decode + IK of before_step run inside k_step (product path); NULL: they already ran
 // nchunk > 1 (act != NULL only): that many control steps per launch, act / obs / reward / done laid out [nchunk][num_envs][..]
 void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act, double* obs,

@@ -351,10 +351,11 @@ class KManipEnvHip:
         self._check(self.L.kmanip_enable_timing(self.h, int(on)), "kmanip_enable_timing")
 
     def timing_summary(self):
-        """(ik_ms_sum, dyn_ms_sum, nsteps) of the steps recorded since enable_timing / the last summary."""
-        a = C.c_double(); b = C.c_double(); n = C.c_int32()
-        self._check(self.L.kmanip_timing_summary(self.h, C.byref(a), C.byref(b), C.byref(n)), "kmanip_timing_summary")
-        return float(a.value), float(b.value), int(n.value)
+        """(ik_ms_sum, dyn_ms_sum, render_ms_sum, nsteps) of the steps recorded since enable_timing / the last summary: the
+        launch gap / stand-alone IK leg, k_step, and the in-step render kernel (bind_step_depth; 0 when nothing is bound)."""
+        a = C.c_double(); b = C.c_double(); r = C.c_double(); n = C.c_int32()
+        self._check(self.L.kmanip_timing_summary(self.h, C.byref(a), C.byref(b), C.byref(r), C.byref(n)), "kmanip_timing_summary")
+        return float(a.value), float(b.value), float(r.value), int(n.value)
 
 
 def spec_from_gym_env(gym_env) -> EnvSpec:

@@ -59,7 +59,7 @@ def load():
     lib.kmanip_bind_sim_time.argtypes = [vp, vp]
     lib.kmanip_set_seed.argtypes = [vp, C.c_uint64, C.c_int]
     lib.kmanip_get_diag.argtypes = [vp, C.POINTER(C.c_uint32), i32p, i32p]
-    lib.kmanip_timing_summary.argtypes = [vp, f64p, f64p, i32p]
+    lib.kmanip_timing_summary.argtypes = [vp, f64p, f64p, f64p, i32p]
     lib.kmanip_enable_timing.argtypes = [vp, C.c_int]
     lib.kmanip_ik.argtypes = [vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, i32p, i32p]
     lib.kmanip_ik_eval.argtypes = [vp, C.c_int, C.c_int, f64p, f64p, f64p, f64p, f64p]

@@ -230,15 +230,15 @@ int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes);
  * ik_status int32[num_envs, 2]. Synchronous. */
 int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status);
 
-/* Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).  While
- * enabled, every kmanip_step records three events (before the decode/IK launches, between IK and the
- * physics kernel, after the physics kernel) into a ring of `KM_TIMING_SLOTS` steps.
- * kmanip_timing_summary synchronises the device and returns the summed durations in milliseconds of
- * the IK leg (k_prepare + k_before_step) and of the physics kernel (k_step) over the recorded steps,
- * then clears the ring. */
+/* Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).  While enabled, every kmanip_step
+ * records four events (before the step, after the stand-alone decode/IK launches of the KMANIP_IK_UNFUSED=1 A/B path -- the
+ * product path has none, so that leg is the gap between two event records --, after k_step, after the bound in-step render)
+ * into a ring of `KM_TIMING_SLOTS` steps.  kmanip_timing_summary synchronises the device and returns the summed durations in
+ * milliseconds of the three legs (IK / launch gap, k_step, k_render of kmanip_bind_step_depth: 0 when nothing is bound) over
+ * the recorded steps, then clears the ring.  Any output pointer may be NULL. */
 #define KM_TIMING_SLOTS 1024
 int kmanip_enable_timing(KHandle h, int enable);
-int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, int32_t* nsteps);
+int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, double* render_ms_sum, int32_t* nsteps);
 
 /* nsteps control steps in ONE launch, for callers that already hold the next nsteps actions of every env (action-chunking
  * policies such as ACT, scripted / replayed action streams): exactly the result of nsteps consecutive kmanip_step calls,

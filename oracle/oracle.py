@@ -101,32 +101,34 @@ class Oracle:
                                 self.states, int(ahead), _p(act, C.c_float))
         return act
 
-    # ---- state access
+    # ---- state access (numpy views of the ctypes array: no per-element Python loops)
+    _DT = np.dtype([("qpos", np.float64, NQMAX), ("qvel", np.float64, NVMAX), ("ctrl", np.float64, NLMAX),
+                    ("qacc_warm", np.float64, NVMAX), ("time", np.float64), ("step_idx", np.int32), ("episode", np.int32)])
+
+    def _view(self):
+        assert self._DT.itemsize == C.sizeof(KoState)
+        return np.frombuffer(self.states, dtype=self._DT)
+
     def get_state(self):
         nq, nv, nu = self.cm.nq, self.cm.nv, self.cm.nu
-        qpos = np.array([list(s.qpos)[:nq] for s in self.states])
-        qvel = np.array([list(s.qvel)[:nv] for s in self.states])
-        ctrl = np.array([list(s.ctrl)[:nu] for s in self.states])
-        warm = np.array([list(s.qacc_warm)[:nv] for s in self.states])
-        step = np.array([s.step_idx for s in self.states], dtype=np.int32)
-        return qpos, qvel, ctrl, warm, step
+        v = self._view()
+        return (v["qpos"][:, :nq].copy(), v["qvel"][:, :nv].copy(), v["ctrl"][:, :nu].copy(), v["qacc_warm"][:, :nv].copy(),
+                v["step_idx"].copy())
 
     def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None, step=None):
-        for e, s in enumerate(self.states):
-            if qpos is not None:
-                for i, v in enumerate(qpos[e]):
-                    s.qpos[i] = v
-            if qvel is not None:
-                for i, v in enumerate(qvel[e]):
-                    s.qvel[i] = v
-            if ctrl is not None:
-                for i, v in enumerate(ctrl[e]):
-                    s.ctrl[i] = v
-            if warm is not None:
-                for i, v in enumerate(warm[e]):
-                    s.qacc_warm[i] = v
-            if step is not None:
-                s.step_idx = int(step[e])
+        v = self._view()
+        for name, val in (("qpos", qpos), ("qvel", qvel), ("ctrl", ctrl), ("qacc_warm", warm)):
+            if val is not None:
+                val = np.asarray(val, dtype=np.float64)
+                v[name][:, :val.shape[1]] = val
+        if step is not None:
+            v["step_idx"][:] = np.asarray(step, dtype=np.int32)
+
+    def get_episode(self):
+        return self._view()["episode"].copy()
+
+    def set_episode(self, episode):
+        self._view()["episode"][:] = np.asarray(episode, dtype=np.int32)
 
     def get_diag(self):
         mask = np.array([d.contact_mask for d in self.diag], dtype=np.uint32)

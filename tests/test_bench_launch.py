@@ -67,3 +67,14 @@ def test_bytes_per_env_step_counts_the_depth_image():
     cm = compile_model("KManipSoloArm")
     assert bench.algorithmic_bytes_per_env_step(cm) == 1197
     assert bench.algorithmic_bytes_per_env_step(cm, 64) == 1197 + 64 * 64 * 4    # BASELINE config 5
+
+
+def test_rank_path_refuses_a_collective_that_does_not_span_the_job(capsys):
+    """bench.py's start-up self-check (run_rank, right after init_process_group): an all-reduce of ones must count WORLD_SIZE
+    ranks; anything else is a loud non-zero exit instead of a whole-job value computed from part of the job."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.check_ranks_seen(8, 8, 0) == 0 and capsys.readouterr().err == ""
+    assert bench.check_ranks_seen(1, 8, 3) == 4
+    err = capsys.readouterr().err
+    assert "sees 1 rank(s), WORLD_SIZE is 8" in err and "rank 3" in err

@@ -1,0 +1,207 @@
+"""GPU tests (-m gpu) that close the configuration gaps of BASELINE.json on one MI355X:
+  * config 2 (KManipSoloArm @ 4096) at full width with an oracle slice over a whole episode + the auto-reset,
+  * config 4's LAST shard (KManipTorso, env ids 57344..65535 = rank 7 of 8) against the oracle, and the whole 65536-env
+    job on ONE handle (determinism + invariants across the auto-reset),
+  * a wide one-step parity soak (512 envs x 70 steps x 3 models, oracle re-synchronised every step),
+  * the counter-based action stream of SURVEY 8d (kmanip_sample_action == the oracle's draw, bit for bit).
+Tolerances as in test_gpu_parity.py (float64 both sides; done / masks / counters / float32 actions bit-exact)."""
+import numpy as np
+import pytest
+
+from conftest import ENVS3
+from gym_kmanip_amd.model import KM_DONE_DIVERGED, KM_DONE_TRUNCATED, compile_model
+
+pytestmark = pytest.mark.gpu
+
+TOL_Q, TOL_V, TOL_R = 1e-7, 1e-5, 1e-6
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_sample_action_matches_oracle(env):
+    """action_space.sample() on the device (Philox keyed (seed; global env id, episode, step)) == the oracle's draw, bit for
+    bit: after the reset, `ahead` steps into the future (across the episode boundary), after stepping, and for a shard created
+    at an env_id_offset; values are float32 in [-1, 1)."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    cm = compile_model(env, auto_reset=True)
+    n, off = 96, 5000
+    dev = env_hip.KManipEnvHip(cm, num_envs=n, seed=21, env_id_offset=off)
+    orc = Oracle(cm, n, seed=21, env_id_offset=off)
+    dev.k_reset(); orc.reset()
+    stagger = (np.arange(n) % 64).astype(np.int32)
+    dev.set_state(step=stagger); orc.set_state(step=stagger)
+    seen = []
+    for ahead in (0, 1, 63, 64, 130):
+        a = dev.sample_action(ahead=ahead).cpu().numpy()
+        assert a.dtype == np.float32 and np.array_equal(a, orc.sample_action(ahead)), ahead
+        assert (a >= -1).all() and (a < 1).all()
+        seen.append(a)
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[0], seen[3])      # fresh per step and per episode
+    for k in range(3):                                                                       # the stream follows the env's own counters
+        a = dev.sample_action()
+        dev.step_flat(a)
+        ao = orc.sample_action()
+        assert np.array_equal(a.cpu().numpy(), ao), k
+        orc.step(ao)
+    # a shard of the job draws what the whole job draws for the same global env ids
+    part = env_hip.KManipEnvHip(cm, num_envs=16, seed=21, env_id_offset=off + 32)
+    part.k_reset(); part.set_state(step=stagger[32:48] + 3)
+    assert np.array_equal(part.sample_action().cpu().numpy(), dev.sample_action().cpu().numpy()[32:48])
+    assert abs(float(seen[0].mean())) < 0.1 and 0.5 < float(seen[0].std()) < 0.65                # U[-1, 1): mean 0, sd 0.577
+    dev.k_close(); part.k_close()
+
+
+def test_config2_full_width_with_oracle_slice():
+    """BASELINE config 2 (KManipSoloArm @ 4096, the headline) for 70 control steps on the bench's own action stream: a 16-env
+    oracle slice of the full batch every step (obs / reward / done; contact masks and state at checkpoints), bitwise
+    determinism against a second handle, invariants."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    n, lo, no = 4096, 2048, 16
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=3)
+    b = env_hip.make("KManipSoloArm", num_envs=n, seed=3)
+    orc = Oracle(a.cm, no, seed=3, env_id_offset=lo)
+    a.k_reset(); b.k_reset(); orc.reset()
+    nl = a.cm.nlink
+    saw_contact = False
+    for k in range(70):
+        act = a.sample_action()
+        assert np.array_equal(act[lo:lo + no].cpu().numpy(), orc.sample_action()), k
+        a.step_flat(act); b.step_flat(act.clone())
+        oo, ro, do = orc.step(act[lo:lo + no].cpu().numpy())
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), k
+        assert np.abs(a.obs[lo:lo + no].cpu().numpy() - oo).max() < TOL_Q, k
+        assert np.abs(a.reward[lo:lo + no].cpu().numpy() - ro).max() < TOL_R, k
+        assert np.array_equal(a.done[lo:lo + no].cpu().numpy(), do), k
+        done = a.done.cpu().numpy()
+        assert not (done & KM_DONE_DIVERGED).any() and (done == (KM_DONE_TRUNCATED if k == 63 else 0)).all(), k
+        if k in (20, 40, 62, 69):
+            mg = a.get_diag()[0]
+            assert np.array_equal(mg[lo:lo + no], orc.get_diag()[0]), k
+            saw_contact |= bool(mg.any())
+    sa, so = a.get_state(), orc.get_state()
+    assert np.abs(sa[0][lo:lo + no] - so[0]).max() < TOL_Q and np.abs(sa[1][lo:lo + no] - so[1]).max() < TOL_V
+    assert np.array_equal(sa[2][lo:lo + no], so[2]) and (sa[4] == 6).all() and saw_contact
+    assert np.abs(np.linalg.norm(sa[0][:, nl + 3:], axis=1) - 1).max() < 1e-12
+    obs = a.obs.cpu().numpy()
+    assert np.isfinite(obs).all() and (np.abs(obs) <= 1).all()
+    a.k_close(); b.k_close()
+
+
+def test_config4_last_shard_vs_oracle():
+    """Rank 7 of BASELINE config 4 (KManipTorso, 65536 envs over 8 ranks): env ids 57344..65535 on one handle, 66 steps across
+    the auto-reset, with an oracle on the first and the last 8 env ids of the shard (incl. 65535, the job's last env)."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    n, off = 8192, 57344
+    a = env_hip.make("KManipTorso", num_envs=n, seed=3, env_id_offset=off)
+    o_lo = Oracle(a.cm, 8, seed=3, env_id_offset=off)
+    o_hi = Oracle(a.cm, 8, seed=3, env_id_offset=off + n - 8)
+    a.k_reset(); o_lo.reset(); o_hi.reset()
+    for k in range(66):
+        act = a.sample_action()
+        an = act.cpu().numpy()
+        assert np.array_equal(an[:8], o_lo.sample_action()) and np.array_equal(an[-8:], o_hi.sample_action()), k
+        a.step_flat(act)
+        obs, rew, done = a.obs.cpu().numpy(), a.reward.cpu().numpy(), a.done.cpu().numpy()
+        for sl, orc in ((slice(0, 8), o_lo), (slice(n - 8, n), o_hi)):
+            oo, ro, do = orc.step(an[sl])
+            assert np.abs(obs[sl] - oo).max() < TOL_Q and np.abs(rew[sl] - ro).max() < TOL_R and np.array_equal(done[sl], do), k
+        assert (done == (KM_DONE_TRUNCATED if k == 63 else 0)).all(), k
+    sa = a.get_state()
+    for sl, orc in ((slice(0, 8), o_lo), (slice(n - 8, n), o_hi)):
+        so = orc.get_state()
+        assert np.abs(sa[0][sl] - so[0]).max() < TOL_Q and np.abs(sa[1][sl] - so[1]).max() < TOL_V and np.array_equal(sa[2][sl], so[2])
+    a.k_close()
+
+
+def test_config4_whole_job_on_one_handle():
+    """All 65536 KManipTorso envs of BASELINE config 4 on ONE handle (the 8-rank run shards exactly these env ids): 66 control
+    steps across the auto-reset, two handles bit for bit, the 8192-env shard at rank 7's offset reproducing its slice of the
+    whole job bit for bit (what a rank computes does not depend on the shard layout), invariants."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    n, ns, off = 65536, 8192, 57344
+    a = env_hip.make("KManipTorso", num_envs=n, seed=3)
+    b = env_hip.make("KManipTorso", num_envs=n, seed=3)
+    c = env_hip.make("KManipTorso", num_envs=ns, seed=3, env_id_offset=off)
+    a.k_reset(); b.k_reset(); c.k_reset()
+    nl = a.cm.nlink
+    for k in range(66):
+        act = a.sample_action()
+        assert torch.equal(act[off:off + ns], c.sample_action()), k
+        a.step_flat(act); b.step_flat(act.clone()); c.step_flat(act[off:off + ns].contiguous())
+        if k % 8 == 0 or k >= 62:
+            assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), k
+            assert torch.equal(a.obs[off:off + ns], c.obs) and torch.equal(a.done[off:off + ns], c.done), k
+            done = a.done.cpu().numpy()
+            assert (done == (KM_DONE_TRUNCATED if k == 63 else 0)).all(), k
+    sa, sb, sc = a.get_state(), b.get_state(), c.get_state()
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+    for x, z in zip(sa, sc):
+        assert np.array_equal(x[off:off + ns], z)
+    assert (sa[4] == 2).all()
+    assert np.abs(np.linalg.norm(sa[0][:, nl + 3:], axis=1) - 1).max() < 1e-12
+    obs = a.obs.cpu().numpy()
+    assert np.isfinite(obs).all() and (np.abs(obs) <= 1).all()
+    assert bool(a.get_diag()[0].any())                                   # contacts are live at this point of the episode
+    for e in (a, b, c):
+        e.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_parity_soak_one_step_samples(env):
+    """512 envs x 70 control steps with desynchronised episode phases, on the counter-based action stream, the oracle
+    re-synchronised to the device state after every step: 35 840 independent one-step parity samples per model (a free-running
+    comparison measures the chaos of a cube rocking on a stiff contact, not the kernel).  Contact masks and done bytes identical
+    in every sample; float32 ctrl identical except for rounding-boundary flips of one ulp (bounded); on the envs whose ctrl
+    agrees, one-step deviations at roundoff; IK evaluation counts at most one apart."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    cm = compile_model(env, auto_reset=True)
+    n, steps = 512, 70
+    dev = env_hip.KManipEnvHip(cm, num_envs=n, seed=11, env_id_offset=3)
+    orc = Oracle(cm, n, seed=11, env_id_offset=3)
+    dev.k_reset(); orc.reset()
+    stagger = (np.arange(n) % 64).astype(np.int32)
+    dev.set_state(step=stagger); orc.set_state(step=stagger)
+    worst_q = worst_v = worst_r = 0.0
+    n_ctrl = 0
+    seen = 0
+    for k in range(steps):
+        act = dev.sample_action()
+        an = act.cpu().numpy()
+        assert np.array_equal(an, orc.sample_action()), k
+        dev.step_flat(act)
+        oo, ro, do = orc.step(an, nthreads=8)
+        sg, so = dev.get_state(), orc.get_state()
+        flip = (sg[2] != so[2]).any(axis=1)       # a float32 rounding flip of ctrl (1 ulp) legitimately moves that env's step by ~1e-5
+        if flip.any():
+            ulp = np.spacing(np.abs(so[2][flip]).astype(np.float32)).astype(np.float64)
+            assert (np.abs(sg[2][flip] - so[2][flip]) <= ulp).all(), k
+        ok = ~flip
+        n_ctrl += int(flip.sum())
+        worst_q = max(worst_q, float(np.abs(sg[0] - so[0])[ok].max())); worst_v = max(worst_v, float(np.abs(sg[1] - so[1])[ok].max()))
+        worst_r = max(worst_r, float(np.abs(dev.reward.cpu().numpy() - ro)[ok].max()))
+        mg, nfg, stg = dev.get_diag(); mo, nfo, sto = orc.get_diag()
+        assert np.array_equal(mg, mo), (k, np.where(mg != mo)[0][:8])
+        assert np.array_equal(dev.done.cpu().numpy(), do), k
+        assert np.array_equal(sg[4], so[4]), k
+        assert np.abs(nfg - nfo).max() <= 1 and np.array_equal(stg == -2, sto == -2), k
+        seen |= int(np.bitwise_or.reduce(mg))
+        orc.set_state(*sg)                         # one-step samples
+    assert worst_q < 1e-9 and worst_v < 1e-7 and worst_r < 1e-9, (worst_q, worst_v, worst_r)
+    assert n_ctrl <= 4, n_ctrl
+    assert seen & 0xF, hex(seen)                   # cube-table contacts were in the sample
+    dev.k_close()

@@ -474,8 +474,7 @@ def test_render_depth_config5_size():
 @pytest.mark.parametrize("env", ["KManipSoloArm", "KManipTorso"])
 def test_fused_and_split_launches_agree(env, monkeypatch):
     """The product path runs before_step inside k_step; KMANIP_IK_UNFUSED=1 keeps it as separate launches.  Same device
-    code on the same inputs => bit-identical state/obs/reward.  (The one-lane-per-problem IK kernel is a diagnostic build
-    only -- `make -C gym_kmanip_amd/csrc diag` -- and the product library refuses KMANIP_IK_SERIAL=1.)"""
+    code on the same inputs => bit-identical state/obs/reward."""
     torch = _torch()
     from gym_kmanip_amd import env_hip
     from gym_kmanip_amd.lib import KManipError
@@ -483,16 +482,11 @@ def test_fused_and_split_launches_agree(env, monkeypatch):
     cm = compile_model(env)
     envs = {}
     for name, var in (("fused", None), ("split", "KMANIP_IK_UNFUSED")):
-        monkeypatch.delenv("KMANIP_IK_UNFUSED", raising=False); monkeypatch.delenv("KMANIP_IK_SERIAL", raising=False)
+        monkeypatch.delenv("KMANIP_IK_UNFUSED", raising=False)
         if var:
             monkeypatch.setenv(var, "1")
         envs[name] = env_hip.KManipEnvHip(cm, num_envs=n, seed=9)      # the switch is read at kmanip_create
     monkeypatch.delenv("KMANIP_IK_UNFUSED", raising=False)
-    if "diag" not in os.path.basename(env_hip._libmod.LIB_PATH):
-        monkeypatch.setenv("KMANIP_IK_SERIAL", "1")
-        with pytest.raises(KManipError, match="diagnostic build"):
-            env_hip.KManipEnvHip(cm, num_envs=4, seed=9)
-        monkeypatch.delenv("KMANIP_IK_SERIAL", raising=False)
     gen = torch.Generator(device="cuda"); gen.manual_seed(4)
     for e in envs.values():
         e.k_reset()
