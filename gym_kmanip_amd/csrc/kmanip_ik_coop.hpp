@@ -140,19 +140,12 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
       for (int i = 0; i < 9; i++) R[i] = Rn[i];
     }
   });
-  // lane GI-1 holds the product over the whole chain (positions >= clen are identities)
-  real* pub = P.L->pub;
-  if (P.c == GI - 1) {
-#pragma unroll
-    for (int i = 0; i < 9; i++) pub[i] = R[i];
-    pub[9] = p[0]; pub[10] = p[1]; pub[11] = p[2];
-  }
-  KM_GSYNC();
+  // lane GI-1 holds the product over the whole chain (positions >= clen are identities): the site link's world transform reaches
+  // the other lanes by row broadcasts (registers only; round 2 published it through LDS: two synchronisations per evaluation)
   real mat[9], pos[3];
 #pragma unroll
-  for (int i = 0; i < 9; i++) mat[i] = pub[i];
-  pos[0] = pub[9]; pos[1] = pub[10]; pos[2] = pub[11];
-  KM_GSYNC();
+  for (int i = 0; i < 9; i++) mat[i] = bcast8<GI - 1>(R[i]);
+  pos[0] = bcast8<GI - 1>(p[0]); pos[1] = bcast8<GI - 1>(p[1]); pos[2] = bcast8<GI - 1>(p[2]);
   const real anc[3] = {p[0], p[1], p[2]}, axw[3] = {R[2], R[5], R[8]};
   real sp[3], smat[9], cur[4], rq[3];
   real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]};
@@ -174,25 +167,12 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
   ft[0] = sp[0] - P.goal_pos[0]; ft[1] = sp[1] - P.goal_pos[1]; ft[2] = sp[2] - P.goal_pos[2];
   ft[3] = rq[0] * m->ik_res_rad; ft[4] = rq[1] * m->ik_res_rad; ft[5] = rq[2] * m->ik_res_rad;
   if (JAC) {
-    // mjd_subQuat: Da = I + h K + (1 - h / tan h) K^2, D_ee = -Da^T; mat = rad * D_ee^T * site_xmat^T
+    // mjd_subQuat: Da = I + h K + (1 - h / tan h) K^2 (K = [axs]x, |axs| = 1, so K^2 v = axs (axs . v) - v), D_ee = -Da^T;
+    // J_orn column = rad * D_ee^T * site_xmat^T * axis = -rad * Da * (site_xmat^T axis): applied to the one vector this lane
+    // needs (27 operations) instead of forming Da and the 3 x 3 product first (~95)
     real axs[3] = {rq[0], rq[1], rq[2]};
     real half = 0.5 * normalize3_fast(axs);
-    real K[9] = {0, -axs[2], axs[1], axs[2], 0, -axs[0], -axs[1], axs[0], 0};
     real coef = 1.0 - (half < 6e-8 ? 1.0 : half * ac_h / sn_h);      // half / tan(half), tan(half) = sn_h / ac_h
-    real Da[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        real kk = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
-        Da[3 * i + j] = (i == j ? 1.0 : 0.0) + half * K[3 * i + j] + coef * kk;
-      }
-    real T[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        T[3 * i + j] = -m->ik_jac_rad * (Da[3 * i] * smat[3 * j] + Da[3 * i + 1] * smat[3 * j + 1] + Da[3 * i + 2] * smat[3 * j + 2]);
     const int l = P.ax->chain_link[arm][P.on ? P.c : 0];
     if (!P.on) { Jc[0] = 0; Jc[1] = 0; Jc[2] = 0; Jc[3] = 0; Jc[4] = 0; Jc[5] = 0; }
     else if (m->jnt_type[l] == KM_JNT_SLIDE) { Jc[0] = axw[0]; Jc[1] = axw[1]; Jc[2] = axw[2]; Jc[3] = 0; Jc[4] = 0; Jc[5] = 0; }
@@ -200,9 +180,12 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
       real r[3] = {sp[0] - anc[0], sp[1] - anc[1], sp[2] - anc[2]}, jp[3];
       cross3(jp, axw, r);
       Jc[0] = jp[0]; Jc[1] = jp[1]; Jc[2] = jp[2];
-      Jc[3] = T[0] * axw[0] + T[1] * axw[1] + T[2] * axw[2];
-      Jc[4] = T[3] * axw[0] + T[4] * axw[1] + T[5] * axw[2];
-      Jc[5] = T[6] * axw[0] + T[7] * axw[1] + T[8] * axw[2];
+      real uu[3], cx[3];
+      matT_vec3(uu, smat, axw);
+      cross3(cx, axs, uu);
+      const real du = dot3(axs, uu);
+#pragma unroll
+      for (int i = 0; i < 3; i++) Jc[3 + i] = -m->ik_jac_rad * ((uu[i] + half * cx[i]) + coef * (axs[i] * du - uu[i]));
     }
   }
 }
