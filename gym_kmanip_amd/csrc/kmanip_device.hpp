@@ -195,11 +195,11 @@ template <int G, int K> __device__ __forceinline__ real gbcast(real v) {
 // into the FMA, and it does not track hazards inside inline asm, so the two wait states a DPP read needs after a VALU
 // write of its source register (e.g. an AGPR reload just before) are spent explicitly.  One 16-lane row only.
 template <int K> __device__ __forceinline__ void fmac_bcast16(real& acc, real x, real t) {
-  asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
 }
 // acc -= bcast_K(x) * t
 template <int K> __device__ __forceinline__ void fnmac_bcast16(real& acc, real x, real t) {
-  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(t), "n"(K));
 }
 // The compiler's hazard recogniser does not look inside inline asm: a register WRITTEN by one of the asm runs here and then read
 // through DPP by compiler-generated code (gbcast, dpp_f64, bcast8) within the next two instructions would be read too early
@@ -240,79 +240,92 @@ template <int G, int K> __device__ __forceinline__ real bsel(const BSrc<G>& s) {
   if constexpr (G == 32) return K < 16 ? s.e : s.o; else return s.v;
 }
 #define KM_DPPF(N, A, X, T, K) "v_fmac_f64_dpp %" #A ", " N "%" #X ", %" #T " row_newbcast:%" #K " row_mask:0xf bank_mask:0xf\n\t"
+// WAIT = false: the caller knows that no DPP source of the run was written by the last two VALU instructions before it (a later
+// run over the SAME sources, ordered behind the first through its accumulators) and saves the two wait states
+// (the runs are `asm volatile`: they keep their program order among themselves, which is what makes "a later run" mean "issued
+// later" -- a plain asm may be scheduled ahead of an earlier, independent one)
+#define KM_RUN(WAIT, BODY, ...) do { if constexpr (WAIT) asm volatile("s_nop 1\n\t" BODY __VA_ARGS__); else asm volatile(BODY __VA_ARGS__); } while (0)
 // acc_i (-)= bcast_{K_i}(x_i) * t_i, i = 0..3 (four different accumulators)
-template <bool NEG, int K0, int K1, int K2, int K3>
+template <bool NEG, int K0, int K1, int K2, int K3, bool WAIT = true>
 __device__ __forceinline__ void dppfma4(real& a0, real x0, real t0, real& a1, real x1, real t1, real& a2, real x2, real t2, real& a3, real x3, real t3) {
   if constexpr (NEG)
-    asm("s_nop 1\n\t" KM_DPPF("-", 0, 4, 8, 12) KM_DPPF("-", 1, 5, 9, 13) KM_DPPF("-", 2, 6, 10, 14) KM_DPPF("-", 3, 7, 11, 15)
-        : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+    KM_RUN(WAIT, KM_DPPF("-", 0, 4, 8, 12) KM_DPPF("-", 1, 5, 9, 13) KM_DPPF("-", 2, 6, 10, 14) KM_DPPF("-", 3, 7, 11, 15),
+           : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
   else
-    asm("s_nop 1\n\t" KM_DPPF("", 0, 4, 8, 12) KM_DPPF("", 1, 5, 9, 13) KM_DPPF("", 2, 6, 10, 14) KM_DPPF("", 3, 7, 11, 15)
-        : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+    KM_RUN(WAIT, KM_DPPF("", 0, 4, 8, 12) KM_DPPF("", 1, 5, 9, 13) KM_DPPF("", 2, 6, 10, 14) KM_DPPF("", 3, 7, 11, 15),
+           : "+&v"(a0), "+&v"(a1), "+&v"(a2), "+&v"(a3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
 }
-template <bool NEG, int K0, int K1, int K2>
+template <bool NEG, int K0, int K1, int K2, bool WAIT = true>
 __device__ __forceinline__ void dppfma3(real& a0, real x0, real t0, real& a1, real x1, real t1, real& a2, real x2, real t2) {
   if constexpr (NEG)
-    asm("s_nop 1\n\t" KM_DPPF("-", 0, 3, 6, 9) KM_DPPF("-", 1, 4, 7, 10) KM_DPPF("-", 2, 5, 8, 11)
-        : "+&v"(a0), "+&v"(a1), "+&v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
+    KM_RUN(WAIT, KM_DPPF("-", 0, 3, 6, 9) KM_DPPF("-", 1, 4, 7, 10) KM_DPPF("-", 2, 5, 8, 11),
+           : "+&v"(a0), "+&v"(a1), "+&v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
   else
-    asm("s_nop 1\n\t" KM_DPPF("", 0, 3, 6, 9) KM_DPPF("", 1, 4, 7, 10) KM_DPPF("", 2, 5, 8, 11)
-        : "+&v"(a0), "+&v"(a1), "+&v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
+    KM_RUN(WAIT, KM_DPPF("", 0, 3, 6, 9) KM_DPPF("", 1, 4, 7, 10) KM_DPPF("", 2, 5, 8, 11),
+           : "+&v"(a0), "+&v"(a1), "+&v"(a2) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K0), "n"(K1), "n"(K2));
 }
-template <bool NEG, int K0, int K1>
+template <bool NEG, int K0, int K1, bool WAIT = true>
 __device__ __forceinline__ void dppfma2(real& a0, real x0, real t0, real& a1, real x1, real t1) {
   if constexpr (NEG)
-    asm("s_nop 1\n\t" KM_DPPF("-", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 7) : "+&v"(a0), "+&v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+    KM_RUN(WAIT, KM_DPPF("-", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 7), : "+&v"(a0), "+&v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
   else
-    asm("s_nop 1\n\t" KM_DPPF("", 0, 2, 4, 6) KM_DPPF("", 1, 3, 5, 7) : "+&v"(a0), "+&v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+    KM_RUN(WAIT, KM_DPPF("", 0, 2, 4, 6) KM_DPPF("", 1, 3, 5, 7), : "+&v"(a0), "+&v"(a1) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K0), "n"(K1));
+}
+// single instruction, optional wait states
+template <bool NEG, int K, bool WAIT = true>
+__device__ __forceinline__ void dppfma1(real& a0, real x0, real t0) {
+  if constexpr (NEG) KM_RUN(WAIT, KM_DPPF("-", 0, 1, 2, 3), : "+v"(a0) : "v"(x0), "v"(t0), "n"(K));
+  else KM_RUN(WAIT, KM_DPPF("", 0, 1, 2, 3), : "+v"(a0) : "v"(x0), "v"(t0), "n"(K));
 }
 // ap += bcast_K(xp) * tp ; an -= bcast_K(xn) * tn (one run, two accumulators, one lane K)
-template <int K>
+template <int K, bool WAIT = true>
 __device__ __forceinline__ void dppfma_pn(real& ap, real xp, real tp, real& an, real xn, real tn) {
-  asm("s_nop 1\n\t" KM_DPPF("", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 6) : "+&v"(ap), "+&v"(an) : "v"(xp), "v"(xn), "v"(tp), "v"(tn), "n"(K));
+  KM_RUN(WAIT, KM_DPPF("", 0, 2, 4, 6) KM_DPPF("-", 1, 3, 5, 6), : "+&v"(ap), "+&v"(an) : "v"(xp), "v"(xn), "v"(tp), "v"(tn), "n"(K));
 }
 // acc += sum_i bcast_K(x_i) * t_i, i = 0..NS-1 (one accumulator, NS = 3 or 4 sources, one lane K), in this order
-template <int K>
+template <int K, bool WAIT = true>
 __device__ __forceinline__ void dppfma_acc4(real& acc, real x0, real t0, real x1, real t1, real x2, real t2, real x3, real t3) {
-  asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 9) KM_DPPF("", 0, 3, 7, 9) KM_DPPF("", 0, 4, 8, 9)
-      : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K));
+  KM_RUN(WAIT, KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 9) KM_DPPF("", 0, 3, 7, 9) KM_DPPF("", 0, 4, 8, 9),
+         : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K));
 }
-template <int K>
+template <int K, bool WAIT = true>
 __device__ __forceinline__ void dppfma_acc3(real& acc, real x0, real t0, real x1, real t1, real x2, real t2) {
-  asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 4, 7) KM_DPPF("", 0, 2, 5, 7) KM_DPPF("", 0, 3, 6, 7)
-      : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K));
+  KM_RUN(WAIT, KM_DPPF("", 0, 1, 4, 7) KM_DPPF("", 0, 2, 5, 7) KM_DPPF("", 0, 3, 6, 7),
+         : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K));
 }
 // acc += sum_i bcast_{K_i}(x) * t_i, i = 0..3: four lanes of ONE distributed vector against four coefficients (a row-times-
 // vector product), in this order
-template <int K0, int K1, int K2, int K3>
+template <int K0, int K1, int K2, int K3, bool WAIT = true>
 __device__ __forceinline__ void dppfma_row4(real& acc, real x0, real x1, real x2, real x3, real t0, real t1, real t2, real t3) {
-  asm("s_nop 1\n\t" KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 10) KM_DPPF("", 0, 3, 7, 11) KM_DPPF("", 0, 4, 8, 12)
-      : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
+  KM_RUN(WAIT, KM_DPPF("", 0, 1, 5, 9) KM_DPPF("", 0, 2, 6, 10) KM_DPPF("", 0, 3, 7, 11) KM_DPPF("", 0, 4, 8, 12),
+         : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "n"(K0), "n"(K1), "n"(K2), "n"(K3));
 }
-// acc += sum_{j in [J0, J1)} bcast_j(x) * row(j), row given as a callable (registers or LDS), runs of four then singles
-template <int G, int J0, int J1, class ROW>
+// acc += sum_{j in [J0, J1)} bcast_j(x) * row(j), row given as a callable (registers or LDS), runs of four then singles; every
+// run reads the same source x and accumulates into the same register, so only the first one waits for x
+template <int G, int J0, int J1, bool WAIT = true, class ROW>
 __device__ __forceinline__ void fmac_rowvec(real& acc, const BSrc<G>& x, ROW&& row) {
   if constexpr (J1 - J0 >= 4) {
-    dppfma_row4<J0 & 15, (J0 + 1) & 15, (J0 + 2) & 15, (J0 + 3) & 15>(acc, bsel<G, J0>(x), bsel<G, J0 + 1>(x), bsel<G, J0 + 2>(x), bsel<G, J0 + 3>(x),
-                                                                  row(J0), row(J0 + 1), row(J0 + 2), row(J0 + 3));
-    fmac_rowvec<G, J0 + 4, J1>(acc, x, row);
+    dppfma_row4<J0 & 15, (J0 + 1) & 15, (J0 + 2) & 15, (J0 + 3) & 15, WAIT>(acc, bsel<G, J0>(x), bsel<G, J0 + 1>(x), bsel<G, J0 + 2>(x), bsel<G, J0 + 3>(x),
+                                                                        row(J0), row(J0 + 1), row(J0 + 2), row(J0 + 3));
+    fmac_rowvec<G, J0 + 4, J1, false>(acc, x, row);
   } else if constexpr (J1 - J0 >= 1) {
-    fmac_b<G, J0>(acc, x, row(J0));
-    fmac_rowvec<G, J0 + 1, J1>(acc, x, row);
+    dppfma1<false, J0 & 15, WAIT>(acc, bsel<G, J0>(x), row(J0));
+    fmac_rowvec<G, J0 + 1, J1, false>(acc, x, row);
   }
 }
 // a[j] -= bcast_j(src) * t for j in [J0, J1): the row update of a right-looking factorisation, in runs of four / two / one
-template <int G, int J0, int J1, int N>
+// (one source for all of them: only the first run waits)
+template <int G, int J0, int J1, int N, bool WAIT = true>
 __device__ __forceinline__ void fnmac_cols(real (&a)[N], const BSrc<G>& src, real t) {
   if constexpr (J1 - J0 >= 4) {
-    dppfma4<true, J0 & 15, (J0 + 1) & 15, (J0 + 2) & 15, (J0 + 3) & 15>(a[J0], bsel<G, J0>(src), t, a[J0 + 1], bsel<G, J0 + 1>(src), t,
-                                                                      a[J0 + 2], bsel<G, J0 + 2>(src), t, a[J0 + 3], bsel<G, J0 + 3>(src), t);
-    fnmac_cols<G, J0 + 4, J1>(a, src, t);
+    dppfma4<true, J0 & 15, (J0 + 1) & 15, (J0 + 2) & 15, (J0 + 3) & 15, WAIT>(a[J0], bsel<G, J0>(src), t, a[J0 + 1], bsel<G, J0 + 1>(src), t,
+                                                                            a[J0 + 2], bsel<G, J0 + 2>(src), t, a[J0 + 3], bsel<G, J0 + 3>(src), t);
+    fnmac_cols<G, J0 + 4, J1, N, false>(a, src, t);
   } else if constexpr (J1 - J0 >= 2) {
-    dppfma2<true, J0 & 15, (J0 + 1) & 15>(a[J0], bsel<G, J0>(src), t, a[J0 + 1], bsel<G, J0 + 1>(src), t);
-    fnmac_cols<G, J0 + 2, J1>(a, src, t);
+    dppfma2<true, J0 & 15, (J0 + 1) & 15, WAIT>(a[J0], bsel<G, J0>(src), t, a[J0 + 1], bsel<G, J0 + 1>(src), t);
+    fnmac_cols<G, J0 + 2, J1, N, false>(a, src, t);
   } else if constexpr (J1 - J0 == 1) {
-    fnmac_b<G, J0>(a[J0], src, t);
+    dppfma1<true, J0 & 15, WAIT>(a[J0], bsel<G, J0>(src), t);
   }
 }
 

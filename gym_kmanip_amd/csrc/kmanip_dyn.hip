@@ -434,10 +434,11 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
   static_for<0, W>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const real take = ((dm >> j) & 1u) ? 1.0 : 0.0;
-    dppfma4<false, j, j, j, j>(acc[0], own[0], take, acc[1], own[1], take, acc[2], own[2], take, acc[3], own[3], take);
-    dppfma4<false, j, j, j, j>(acc[4], own[4], take, acc[5], own[5], take, acc[6], own[6], take, acc[7], own[7], take);
-    dppfma4<false, j, j, j, j>(acc[8], own[8], take, acc[9], own[9], take, acc[10], own[10], take, acc[11], own[11], take);
-    dppfma4<false, j, j, j, j>(acc[12], own[12], take, acc[13], own[13], take, acc[14], own[14], take, acc[15], own[15], take);
+    constexpr bool WT = j == 0;                  // (the sources own[] are read again for every j: only the first pass can trail their writes)
+    dppfma4<false, j, j, j, j, WT>(acc[0], own[0], take, acc[1], own[1], take, acc[2], own[2], take, acc[3], own[3], take);
+    dppfma4<false, j, j, j, j, WT>(acc[4], own[4], take, acc[5], own[5], take, acc[6], own[6], take, acc[7], own[7], take);
+    dppfma4<false, j, j, j, j, WT>(acc[8], own[8], take, acc[9], own[9], take, acc[10], own[10], take, acc[11], own[11], take);
+    dppfma4<false, j, j, j, j, WT>(acc[12], own[12], take, acc[13], own[13], take, acc[14], own[14], take, acc[15], own[15], take);
   });
   if (on) {
     const int j = li;
@@ -596,7 +597,7 @@ __device__ __forceinline__ void anc_sum3(uint32_t mask, const real* v, real* s) 
   static_for<0, NL>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const real take = ((mask >> j) & 1u) ? 1.0 : 0.0;
-    dppfma3<false, j, j, j>(s[0], v[0], take, s[1], v[1], take, s[2], v[2], take);
+    dppfma3<false, j, j, j, j == 0>(s[0], v[0], take, s[1], v[1], take, s[2], v[2], take);
   });
 }
 // cube (free joint, qvel = [v_world, w_body]): bias = [-m g, w x I w]
@@ -1367,12 +1368,12 @@ __device__ __forceinline__ void chol_rows1(real (&h)[N], real (&ut)[N], real& in
       const real isk = me ? 1.0 : 0.0;
       static_for<k + 1, D1>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        dppfma_pn<j - BASE>(ut[j], lik, isk, h[j], lik, lik);      // ut[j] += L[j][k] [sub == k];  h[j] -= L[j][k] L[sub][k]
+        dppfma_pn<j - BASE, j == k + 1>(ut[j], lik, isk, h[j], lik, lik);      // ut[j] += L[j][k] [sub == k];  h[j] -= L[j][k] L[sub][k]
       });
     } else {
       static_for<k + 1, D1>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        fnmac_bcast16<j - BASE>(h[j], lik, lik);
+        dppfma1<true, j - BASE, j == k + 1>(h[j], lik, lik);
       });
     }
     if constexpr (k + 2 >= D1 && k + 1 < D1) dpp_settle(h[k + 1]);     // the next pivot's broadcast reads what the last run just wrote
@@ -2147,9 +2148,9 @@ template <int NL, int S> __device__ __forceinline__ bool slot_lane_in(int sub) {
 
 // Newton state at a start point (all slots, both cost parts): u = J a - A on the slot lanes, gradient, the lanes' own rows,
 // the slots' Hessian weights.  cs != nullptr: also this lane's share of the cost at a_s (MuJoCo's warm-start comparison).
-template <int NL, int G>
+template <int NL, int G, bool CS>
 __device__ __forceinline__ void newton_eval_sl(const Ws<NL>& w, int sub, const CReg<NL>& cr, real a, real a_s, real Mr, real& grad, int& qf,
-                                               int& ql, real (&u)[4], real (&W)[7], real& c0, real& c1, real* cs = nullptr) {
+                                               int& ql, real (&u)[4], real (&W)[7], real& c0, real& c1, real& cs) {
   constexpr int NV = Dim<NL>::NV;
   const uint32_t act = w.cact;
   const SlotC& sc = cr.sc;
@@ -2159,30 +2160,30 @@ __device__ __forceinline__ void newton_eval_sl(const Ws<NL>& w, int sub, const C
   real F[4];
   const real cslot = slot_eval<true>(sc, u, F, W);
   real csl = 0;
-  if (cs) {
+  if constexpr (CS) {
     real us[4], Fs[4], Ws_[7];
     slot_project<NL, G, KM_SUB_ALL>(w, cr, act, sub, a_s, us);
 #pragma unroll
     for (int k = 0; k < 4; k++) us[k] -= sc.A[k];
     csl = slot_eval<false>(sc, us, Fs, Ws_);
   }
-  c0 = 0; c1 = 0;
   grad = Mr;
   qf = 0; ql = 0;
   {
     real co = 0.5 * (a - a_s) * Mr;
     if (cr.fl > 0) { real f; co += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
     if (cr.sg != 0) { real f; co += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
-    if (sub < NL) c0 = co; else if (sub < NV) c1 = co;
-    if (cs) {                                   // (the Gauss term vanishes at a_s)
+    // (selects, not `if (..) c0 = ..; else c1 = ..`: the latter made the compiler index {c0, c1} in scratch memory)
+    c0 = sub < NL ? co : 0.0; c1 = (sub >= NL && sub < NV) ? co : 0.0;
+    if constexpr (CS) {                         // (the Gauss term vanishes at a_s)
       real f; int qd;
       if (cr.fl > 0) csl += row_eval(0, a_s - cr.areff, cr.Rf, cr.Df, cr.fl, f, qd);
       if (cr.sg != 0) csl += row_eval(1, cr.sg * a_s - cr.arefl, cr.Rl, cr.Dl, 0.0, f, qd);
     }
   }
-  if (sub < 4) c1 += cslot; else c0 += cslot;       // table-cube slots belong to the cube part (lanes without a slot: cslot = 0)
+  c1 += sub < 4 ? cslot : 0.0; c0 += sub < 4 ? 0.0 : cslot;   // table-cube slots belong to the cube part (lanes without a slot: cslot = 0)
   slot_grad<NL, G, KM_SUB_ALL>(cr, act, F, grad);
-  if (cs) *cs = csl;
+  cs = csl;
 }
 
 // Hessian row `sub` (block [D0, D1) of the subset) from the slots' weights: H += J_c^T W_c J_c, the weights of slot c arriving
@@ -2210,16 +2211,17 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
         if constexpr (SS::kind(c) != 2) {
           dppfma_acc4<c>(t0, W[0], j0, W[1], j1, W[2], j2, W[3], j3);
           dppfma3<false, c, c, c>(t1, W[1], j0, t2, W[2], j0, t3, W[3], j0);
-          dppfma3<false, c, c, c>(t1, W[4], j1, t2, W[5], j2, t3, W[6], j3);
+          dppfma3<false, c, c, c, false>(t1, W[4], j1, t2, W[5], j2, t3, W[6], j3);
         } else {                                                                // (condim-3 pairs have no torsion row)
           dppfma_acc3<c>(t0, W[0], j0, W[1], j1, W[2], j2);
           dppfma2<false, c, c>(t1, W[1], j0, t2, W[2], j0);
-          dppfma2<false, c, c>(t1, W[4], j1, t2, W[5], j2);
+          dppfma2<false, c, c, false>(t1, W[4], j1, t2, W[5], j2);
         }
         static_for<SS::c0(c), SS::c1(c)>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          if constexpr (SS::kind(c) != 2) dppfma_acc4<j & 15>(h[j], j0, t0, j1, t1, j2, t2, j3, t3);
-          else dppfma_acc3<j & 15>(h[j], j0, t0, j1, t1, j2, t2);
+          // (DPP sources = the Jacobian columns, written in the constraint assembly: no wait states)
+          if constexpr (SS::kind(c) != 2) dppfma_acc4<j & 15, false>(h[j], j0, t0, j1, t1, j2, t2, j3, t3);
+          else dppfma_acc3<j & 15, false>(h[j], j0, t0, j1, t1, j2, t2);
         });
       }
     }
@@ -2367,13 +2369,14 @@ __device__ __forceinline__ real solve_newton_sl(Ws<NL>& w, const LModel<NL>& lm,
   real c0, c1, csl;
   real a = warm;
   real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
-  newton_eval_sl<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1, &csl);
+  newton_eval_sl<NL, G, true>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1, csl);
   const real cs = gsum<G>(csl);
   real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
   pf.ph(8);
   if (!(cost0 + cost1 < cs)) {
     a = a_s; Mr = 0;
-    newton_eval_sl<NL, G>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1);
+    real dummy;
+    newton_eval_sl<NL, G, false>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1, dummy);
     cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
     pf.ph(38);
   }
@@ -2709,8 +2712,12 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   int bad = 0;
   const int nsub = m->n_sub_steps;
   for (int s = 0; s < nsub; s++) {
-    step1_products<NL, G, SOLVER>(w, lm, m, sub, cr, invm, pf);      // s == 0: products of the pre-IK state (stale mj_step2)
-    real a = solve<NL, G, SOLVER>(w, lm, m, sub, 1, cr, invm, pf);
+    // the lane's dof index, opaque to the optimiser once per sub-step: everything derived from it (LDS addresses, per-link
+    // constants, masks) is recomputed inside the sub-step instead of being hoisted out of this loop and kept alive -- or
+    // shuttled through AGPRs -- across all ten (380 -> 318 registers, measured)
+    int subv = sub; asm volatile("" : "+v"(subv));
+    step1_products<NL, G, SOLVER>(w, lm, m, subv, cr, invm, pf);      // s == 0: products of the pre-IK state (stale mj_step2)
+    real a = solve<NL, G, SOLVER>(w, lm, m, subv, 1, cr, invm, pf);
     pf.ph(28);
     int lb = (sub < NV) && (!isfinite(a) || fabs(a) > 1e10);   // mjWARN_BADQACC
     bad = gor<G>(lb) | w.bad;

@@ -235,7 +235,7 @@ __device__ __forceinline__ bool chol_coop(const real (&arow)[N], const real (&e)
     F.invd = __builtin_fma(e[k], inv, F.invd);
     static_for<k + 1, N>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      dppfma_pn<j>(F.ut[j], lik, e[k], F.h[j], lik, lik);             // ut[j] += L[j][k] [c == k];  h[j] -= L[j][k] L[c][k]
+      dppfma_pn<j, j == k + 1>(F.ut[j], lik, e[k], F.h[j], lik, lik);     // ut[j] += L[j][k] [c == k];  h[j] -= L[j][k] L[c][k]
     });
     if constexpr (k + 2 >= N && k + 1 < N) dpp_settle(F.h[k + 1]);     // the next pivot's broadcast reads what the last run just wrote
   });
