@@ -110,8 +110,8 @@ struct Ws {
     struct { union { real bsc[NL][9]; real comp[NL][10]; }; real FN[NL][6]; } f;   // bias-pass scratch | composite inertias; bias wrenches
 #if KM_VAR_SOLVER == KM_SOLVER_PGS
     real stage[4][NV];                               // staging of basis rows for B = M^-1 J^T
+    ConRec rec[NC];                                  // solver records (built last; Newton keeps a slot's constants in its lane)
 #endif
-    ConRec rec[NC];                                  // solver records (built last)
   };
   real bias[NV], tmp[NV];
 #if KM_VAR_SOLVER == KM_SOLVER_PGS
@@ -1541,60 +1541,29 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   cube_part<NL, G>(w, qv, qlin, qangw);
   // velocity projections of every active slot; lane c keeps slot c's
   real vb[4] = {0, 0, 0, 0};
-  if constexpr (G == 16) {
-    plane_proj_lane<NL>(w, sub, qlin, qangw, vb);                 // table-cube slots: lane c < 4 evaluates ITS corner
-    static_for<4, NC>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      if ((act >> c) & 1u) {
-#pragma unroll
-        for (int k = 0; k < (slot_kind<NL>(c) == 2 ? 3 : 4); k++) { const real v = gsum<G>(cr.jb[c][k] * qv); vb[k] = sub == c ? v : vb[k]; }
-        if (slot_kind<NL>(c) == 2) vb[3] = sub == c ? 0.0 : vb[3];
-      }
-    });
-  } else {
-#pragma unroll
-  for (int c = 0; c < NC; c++) {
+  plane_proj_lane<NL>(w, sub, qlin, qangw, vb);                 // table-cube slots: lane c < 4 evaluates ITS corner
+  static_for<4, NC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
     if ((act >> c) & 1u) {
-      real v[4];
-      if (slot_kind<NL>(c) == 0) plane_proj<NL>(w, c, qlin, qangw, v);
-      else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = gsum<G>(cr.jb[c][k] * qv);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) vb[k] = sub == c ? v[k] : vb[k];
+      for (int k = 0; k < (slot_kind<NL>(c) == 2 ? 3 : 4); k++) { const real v = gsum<G>(cr.jb[c][k] * qv); vb[k] = sub == c ? v : vb[k]; }
+      if (slot_kind<NL>(c) == 2) vb[3] = sub == c ? 0.0 : vb[3];
     }
-  }
-  }
-  // the solver record of slot `sub`, one slot per lane (all slots through ONE pass of the impedance / regulariser / reference
+  });
+  // the solver constants of slot `sub`, one slot per lane (all slots through ONE pass of the impedance / regulariser / reference
   // acceleration arithmetic instead of one unrolled copy per slot)
   sc.D = 0; sc.D3 = 0; sc.mu = 0; sc.mu3 = 0; sc.A[0] = 0; sc.A[1] = 0; sc.A[2] = 0; sc.A[3] = 0;
   if (sub < NC && ((act >> sub) & 1u)) {
     const int c = sub, kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
     const bool cube = kind != 2;
     const real* fr = cube ? m->con_cube_friction : m->con_def_friction;
-    const real mu[3] = {fr[0], fr[0], fr[1]};
     const int sp = kind == 0 ? 0 : w.slot_sph[c];
     const real Ad = kind == 0 ? lm.cornerA : lm.sphA[kind == 2][sp];   // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
     const real dist = w.c_dist[c];
     const real imp = impedance_c(lm.imp[cube ? 1 : 0], dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
     const real R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad), Dn = frcp(R);
-    if constexpr (G == 16) {
-      sc.D = Dn; sc.D3 = kind == 2 ? 0.0 : Dn; sc.mu = fr[0]; sc.mu3 = fr[1];
-      sc.A[0] = -bb * vb[0] - kk * imp * dist; sc.A[1] = -bb * vb[1]; sc.A[2] = -bb * vb[2]; sc.A[3] = -bb * vb[3];
-    } else {
-    ConRec& rc = w.rec[c];
-    rc.R = R;
-    rc.D = Dn;
-#pragma unroll
-    for (int e = 0; e < 6; e++) rc.f[e] = 0;     // edge forces (the unused edges of a condim-3 pair stay 0)
-#pragma unroll
-    for (int e = 0; e < 6; e++) {
-      const int k = e / 2 + 1;
-      const real sm = (e & 1) ? -mu[k - 1] : mu[k - 1];
-      rc.aref[e] = -bb * (vb[0] + sm * vb[k]) - kk * imp * dist;
-    }
-    }
+    sc.D = Dn; sc.D3 = kind == 2 ? 0.0 : Dn; sc.mu = fr[0]; sc.mu3 = fr[1];
+    sc.A[0] = -bb * vb[0] - kk * imp * dist; sc.A[1] = -bb * vb[1]; sc.A[2] = -bb * vb[2]; sc.A[3] = -bb * vb[3];
   }
   GSYNC();
 }
@@ -1609,461 +1578,21 @@ __device__ __forceinline__ real mass_mul(const CReg<NL>& cr, int sub, real mdiag
   return sub < NL ? s : mdiag * x;
 }
 
-// Hessian row `sub` in registers (block [D0, D1) of the subset): M, plus D on the diagonal for the lane's own quadratic
-// rows, plus J^T W J per contact of the subset (active edges from the masks the last evaluation produced).  Lanes outside
-// the subset get a zero row (inert in the factorisation).
-template <int NL, int G, int S>
-__device__ __forceinline__ void newton_hessian(const Ws<NL>& w, const KModelDesc* m, int sub, const CReg<NL>& cr, real mdiag, int qf, int ql,
-                                               const uint32_t (&qm)[Dim<NL>::NC], real (&h)[Dim<NL>::NV]) {
-  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
-  using SS = SubSet<NL, S>;
-  const uint32_t act = w.cact;
-  const bool in = sub >= SS::D0 && sub < SS::D1;
-  {
-    real dg = sub < NL ? 0.0 : mdiag;
-    if (qf) dg += cr.Df;
-    if (ql) dg += cr.Dl;
-#pragma unroll
-    for (int j = 0; j < NV; j++) h[j] = in ? (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0) : 0.0;
-  }
-  static_for<0, NC>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    if constexpr (SS::slot(c)) {
-      if ((act >> c) & 1u) {
-        const ConRec& rc = w.rec[c];
-        const real Dn = rc.D;
-        real W[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-        for (int e = 0; e < 6; e++) {
-          const int k = e / 2 + 1;
-          const real muk = slot_mu(m, SS::kind(c), k - 1);
-          const real sm = (e & 1) ? -muk : muk;
-          const real d = ((qm[c] >> e) & 1u) ? Dn : 0.0;
-          W[0][0] += d; W[0][k] += d * sm; W[k][k] += d * sm * sm;
-        }
-        real t[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          t[k] = 0;
-#pragma unroll
-          for (int l = 0; l < 4; l++) t[k] += (k <= l ? W[k][l] : W[l][k]) * cr.jb[c][l];
-        }
-        // H[sub][j] += sum_k t_k(sub) * J_k[j]: lane j's basis entries arrive by row broadcast (only the columns the
-        // slot's Jacobian can be nonzero in: cube block for table-cube slots, arm block for finger-table slots)
-        const BSrc<G> j0s = bsrc<G>(cr.jb[c][0]), j1s = bsrc<G>(cr.jb[c][1]), j2s = bsrc<G>(cr.jb[c][2]), j3s = bsrc<G>(cr.jb[c][3]);
-        static_for<SS::c0(c), SS::c1(c)>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          if constexpr (SS::kind(c) != 2)
-            dppfma_acc4<j & 15>(h[j], bsel<G, j>(j0s), t[0], bsel<G, j>(j1s), t[1], bsel<G, j>(j2s), t[2], bsel<G, j>(j3s), t[3]);
-          else                                                                  // (condim-3 pairs have no torsion row)
-            dppfma_acc3<j & 15>(h[j], bsel<G, j>(j0s), t[0], bsel<G, j>(j1s), t[1], bsel<G, j>(j2s), t[2]);
-        });
-      }
-    }
-  });
-}
-
-// the six edge forces of contact slot C on every lane: edge t = 6 C + e was evaluated by lane t % G, which holds its force in
-// lf[t / G] -- one-row groups fetch it with a row broadcast (compile-time lane and register); two-row groups go through the
-// records in LDS (the caller has synchronised)
-template <int NL, int G, int C, int NEQ>
-__device__ __forceinline__ void edge_forces(const ConRec& rc, const real (&lf)[NEQ], real (&f)[6]) {
-  if constexpr (G == 16) {
-    static_for<0, 6>([&](auto ec) {
-      constexpr int e = decltype(ec)::value, t = 6 * C + e;
-      f[e] = gbcast<G, t % G>(lf[t / G]);
-    });
-  } else {
-#pragma unroll
-    for (int e = 0; e < 6; e++) f[e] = rc.f[e];
-  }
-}
-
-// Newton state at a start point: a, Mr = M (a - a_s) (lane components).  The basis projections u_k = J_k a of every active
-// contact go into the record's inv[] slots (group-uniform, LDS; afterwards the loops advance x = J a - aref incrementally, as
-// MuJoCo does); then the contact edges are evaluated DISTRIBUTED over the lanes (edge t on lane t % G, like the line search
-// does), the edge forces are exchanged through the records, and every lane builds its gradient component and the
-// active-edge masks from six forces per contact -- instead of every lane evaluating every edge of every contact.
-// c0 / c1: this lane's share of the cost of the arm part (arm dofs, finger contacts) / the cube part (cube dofs, table-cube
-// contacts); callers sum them over the lanes (total = both).
-template <int NL, int G>
-__device__ __forceinline__ void newton_eval(Ws<NL>& w, const KModelDesc* m, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
-                                            real& grad, int& qf, int& ql, uint32_t (&qm)[Dim<NL>::NC], real& c0, real& c1, real* cs = nullptr) {
-  // cs != nullptr: ALSO the cost of the smooth point a_s (this lane's share), in the same pass -- MuJoCo's warm start compares
-  // the two costs; sharing the contact tables' loads, the synchronisations and the slot loop makes the second evaluation
-  // cost a fraction of a stand-alone one.  The projections of a_s are parked in the records' den[] slots (free until the
-  // first line search).
-  constexpr int NC = Dim<NL>::NC, NV = Dim<NL>::NV;
-  const uint32_t act = w.cact;
-  real alin[3] = {0, 0, 0}, aangw[3] = {0, 0, 0}, slin[3] = {0, 0, 0}, sangw[3] = {0, 0, 0};
-  cube_part<NL, G>(w, a, alin, aangw);
-  if (cs) cube_part<NL, G>(w, a_s, slin, sangw);
-  static_for<0, NC>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    if ((act >> c) & 1u) {
-      real u[4], us[4] = {0, 0, 0, 0};
-      if constexpr (slot_kind<NL>(c) == 0) {
-        plane_proj<NL>(w, c, alin, aangw, u);
-        if (cs) plane_proj<NL>(w, c, slin, sangw, us);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
-        if (cs) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) us[k] = gsum<G>(cr.jb[c][k] * a_s);
-        }
-      }
-      if (sub == 0) {
-        w.rec[c].inv[0] = u[0]; w.rec[c].inv[1] = u[1]; w.rec[c].inv[2] = u[2]; w.rec[c].inv[3] = u[3];
-        if (cs) { w.rec[c].den[0] = us[0]; w.rec[c].den[1] = us[1]; w.rec[c].den[2] = us[2]; w.rec[c].den[3] = us[3]; }
-      }
-    }
-  });
-  GSYNC();
-  real csl = 0;
-  c0 = 0; c1 = 0;
-  grad = Mr;
-  qf = 0; ql = 0;
-  {
-    real co = 0.5 * (a - a_s) * Mr;
-    if (cr.fl > 0) { real f; co += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
-    if (cr.sg != 0) { real f; co += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
-    if (sub < NL) c0 = co; else if (sub < NV) c1 = co;
-    if (cs) {                                   // (the Gauss term vanishes at a_s)
-      real f; int qd;
-      if (cr.fl > 0) csl += row_eval(0, a_s - cr.areff, cr.Rf, cr.Df, cr.fl, f, qd);
-      if (cr.sg != 0) csl += row_eval(1, cr.sg * a_s - cr.arefl, cr.Rl, cr.Dl, 0.0, f, qd);
-    }
-  }
-  constexpr int NEQ = (6 * NC + G - 1) / G;
-  real lf[NEQ];                             // forces of this lane's edges (one-row groups exchange them by DPP, not LDS)
-#pragma unroll
-  for (int q = 0; q < NEQ; q++) {
-    const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
-    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
-    lf[q] = 0;
-    if (c < NC && ((act >> c) & 1u) && !(kind == 2 && e >= 4)) {
-      const ConRec& rc = w.rec[c];
-      const real muk = slot_mu(m, kind, k - 1);
-      const real sm = (e & 1) ? -muk : muk;
-      real f; int quad;
-      const real aref = rc.aref[e], R = rc.R, Dn = rc.D;
-      const real ce = row_eval(1, rc.inv[0] + sm * rc.inv[k] - aref, R, Dn, 0.0, f, quad);
-      if constexpr (G == 16) lf[q] = f; else w.rec[c].f[e] = f;
-      if (kind == 0) c1 += ce; else c0 += ce;
-      if (cs) { real fs; int qd; csl += row_eval(1, rc.den[0] + sm * rc.den[k] - aref, R, Dn, 0.0, fs, qd); }
-    }
-  }
-  if constexpr (G != 16) GSYNC();
-  static_for<0, NC>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    qm[c] = 0;
-    if ((act >> c) & 1u) {
-      const ConRec& rc = w.rec[c];
-      real f[6];
-      edge_forces<NL, G, c>(rc, lf, f);
-      uint32_t q = 0;
-#pragma unroll
-      for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
-      qm[c] = q;
-      const real F0 = ((f[0] + f[1]) + (f[2] + f[3])) + (f[4] + f[5]);
-      const real F1 = slot_mu(m, slot_kind<NL>(c), 0) * (f[0] - f[1]), F2 = slot_mu(m, slot_kind<NL>(c), 1) * (f[2] - f[3]);
-      const real F3 = slot_mu(m, slot_kind<NL>(c), 2) * (f[4] - f[5]);
-      grad -= cr.jb[c][0] * F0 + cr.jb[c][1] * F1 + cr.jb[c][2] * F2 + cr.jb[c][3] * F3;
-    }
-  });
-  if (cs) *cs = csl;
-}
-
-// The same evaluation after a line-search step, without touching the projections: the contact edges this lane owns
-// in the line search (x = lx + alpha ly, registers) give their forces directly; the forces are exchanged through the
-// records (f[] slots), after which every lane needs only 6 forces + 3 friction coefficients per contact for its
-// gradient component and the active-edge mask.  Restricted to the subset's dofs, rows and slots; returns its cost.
-template <int NL, int G, int S, int NEQ>
-__device__ __forceinline__ real newton_eval_step(Ws<NL>& w, const KModelDesc* m, int sub, const CReg<NL>& cr, real a, real a_s, real Mr,
-                                                 const real (&lx)[NEQ], const real (&ly)[NEQ], const real (&lR)[NEQ],
-                                                 const real (&lD)[NEQ], real alpha, real& grad, int& qf, int& ql,
-                                                 uint32_t (&qm)[Dim<NL>::NC]) {
-  constexpr int NC = Dim<NL>::NC;
-  using SS = SubSet<NL, S>;
-  const uint32_t act = w.cact;
-  const bool in = sub >= SS::D0 && sub < SS::D1;
-  real cost = 0;
-  if (in) {
-    cost = 0.5 * (a - a_s) * Mr;        // per-lane share; summed at the end
-    grad = Mr;
-    qf = 0; ql = 0;
-    if (cr.fl > 0) { real f; cost += row_eval(0, a - cr.areff, cr.Rf, cr.Df, cr.fl, f, qf); grad -= f; }
-    if (cr.sg != 0) { real f; cost += row_eval(1, cr.sg * a - cr.arefl, cr.Rl, cr.Dl, 0.0, f, ql); grad -= cr.sg * f; }
-  }
-  real lf[NEQ];
-#pragma unroll
-  for (int q = 0; q < NEQ; q++) {
-    lf[q] = 0;
-    if (lR[q] != 0) {
-      const int t = sub + G * q, c = t / 6, e = t - 6 * c;
-      const real x = lx[q] + alpha * ly[q];
-      real f; int quad;
-      cost += row_eval(1, x, lR[q], lD[q], 0.0, f, quad);
-      if constexpr (G == 16) lf[q] = f; else w.rec[c].f[e] = f;
-    }
-  }
-  if constexpr (G != 16) GSYNC();
-  static_for<0, NC>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    if constexpr (SS::slot(c)) {
-      qm[c] = 0;
-      if ((act >> c) & 1u) {
-        const ConRec& rc = w.rec[c];
-        real f[6];
-        edge_forces<NL, G, c>(rc, lf, f);
-        uint32_t q = 0;
-#pragma unroll
-        for (int e = 0; e < 6; e++) q |= (f[e] > 0 ? 1u : 0u) << e;     // quadratic zone <=> x < 0 <=> f = -D x > 0
-        qm[c] = q;
-        const real F0 = ((f[0] + f[1]) + (f[2] + f[3])) + (f[4] + f[5]);
-        const real F1 = slot_mu(m, slot_kind<NL>(c), 0) * (f[0] - f[1]), F2 = slot_mu(m, slot_kind<NL>(c), 1) * (f[2] - f[3]);
-        const real F3 = slot_mu(m, slot_kind<NL>(c), 2) * (f[4] - f[5]);
-        if (in) grad -= cr.jb[c][0] * F0 + cr.jb[c][1] * F1 + cr.jb[c][2] * F2 + cr.jb[c][3] * F3;
-      }
-    }
-  });
-  return gsum<G>(cost);
-}
-
-// Newton iterations on one dof subset, from the point (a, Mr, grad, qf, ql, qm) with cost `cost` (all of the subset).
-template <int NL, int G, int S>
-__device__ __forceinline__ void newton_loop(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, const CReg<NL>& cr,
-                                            real mdiag, real a_s, real& a, real& Mr, real cost, real& grad, int& qf, int& ql,
-                                            uint32_t (&qm)[Dim<NL>::NC], Prof& pf) {
-  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
-  using SS = SubSet<NL, S>;
-  const uint32_t act = w.cact;
-  const bool in = sub >= SS::D0 && sub < SS::D1;
-  const real scale = lm.scale;
-  const real tol = m->solver_tolerance;
-  const int maxit = m->solver_iterations;
-  {
-    const real g0 = in ? grad : 0.0;
-    if (km_sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
-  }
-  // this lane's share of the subset's contact edges (t = sub + G*q), for the whole solve in registers: the friction sign,
-  // regulariser and its reciprocal never change, and x = J a - aref of the current point is advanced with the step
-  // (x += alpha * J p) instead of being rebuilt from the records every iteration.  lR = 0: no row.
-  constexpr int NEQ = (6 * NC + G - 1) / G;
-  real lx[NEQ], ly[NEQ], lR[NEQ], lD[NEQ], lsm[NEQ];
-#pragma unroll
-  for (int q = 0; q < NEQ; q++) {
-    const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
-    lx[q] = 0; ly[q] = 0; lR[q] = 0; lD[q] = 0; lsm[q] = 0;
-    const int kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
-    const bool insub = S == KM_SUB_ALL || (S == KM_SUB_ARM ? kind == 2 : kind == 0);
-    const bool valid = c < NC && insub && ((act >> c) & 1u) && !(kind == 2 && e >= 4);
-    if (valid) {
-      const ConRec& rc = w.rec[c];
-      const real muk = slot_mu(m, kind, k - 1);
-      const real sm = (e & 1) ? -muk : muk;
-      lx[q] = rc.inv[0] + sm * rc.inv[k] - rc.aref[e];
-      lR[q] = rc.R; lD[q] = rc.D; lsm[q] = sm;
-    }
-  }
-  for (int iter = 0; iter < maxit; iter++) {
-    real p;
-    // The arm problem's quadratic rows are usually just single-dof rows (the two slider friction-loss rows; now and then a
-    // joint at its limit) -- no finger on the table.  Its Hessian is then M + diag(delta) with at most two nonzero deltas, and
-    // this sub-step already holds M^-1: by the Woodbury identity  p = -(y - M^-1[:,S] z),  y = M^-1 grad,
-    // (diag(1/delta_S) + M^-1[S,S]) z = y_S  -- one row-times-vector product and a 2 x 2 solve instead of a 10-pivot
-    // factorisation and two triangular solves.
-    bool plain = false;
-    uint32_t rows = 0;
-    if constexpr (S == KM_SUB_ARM) {
-      bool cq = false;
-      static_for<0, NC>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        if constexpr (SS::slot(c)) cq = cq || (((act >> c) & 1u) && qm[c] != 0);
-      });
-      const unsigned long long bal = __ballot(in && (qf | ql));
-      rows = (uint32_t)(bal >> ((threadIdx.x & 63) - sub)) & ((G == 32) ? 0xFFFFFFFFu : 0xFFFFu);
-      if constexpr (G == 32) {
-        // two-arm models: M^-1 is block diagonal, so the identity holds per block -- up to two quadratic rows in EACH block,
-        // every lane correcting with the rows of its own block
-        const uint32_t lowm = lm.split ? (1u << lm.split) - 1u : 0xFFFFFFFFu;
-        plain = !cq && __popc(rows & lowm) <= 2 && __popc(rows & ~lowm) <= 2;
-        rows &= (sub < lm.split || !lm.split) ? lowm : ~lowm;
-      } else plain = !cq && __popc(rows) <= 2;
-    }
-    if (plain) {
-      real y = 0;
-      const BSrc<G> gs = bsrc<G>(in ? grad : 0.0);
-      const int row = sub < NL ? sub : 0;
-      fmac_rowvec<G, 0, NL>(y, gs, [&](int j) { return w.Minv[row][j]; });
-      real corr = 0;
-      if (rows) {
-        const int i1 = __ffs(rows) - 1, i2 = (rows & (rows - 1)) ? __ffs(rows & (rows - 1)) - 1 : i1;
-        const real dl = (qf ? cr.Df : 0.0) + (ql ? cr.Dl : 0.0);
-        const real y1 = __shfl(y, i1, G), y2 = __shfl(y, i2, G);
-        const real a11 = frcp(__shfl(dl, i1, G)) + w.Minv[i1][i1];
-        real z1, z2 = 0;
-        if (i2 == i1) z1 = y1 * frcp(a11);
-        else {
-          const real a22 = frcp(__shfl(dl, i2, G)) + w.Minv[i2][i2], a12 = w.Minv[i1][i2];
-          const real idet = frcp(a11 * a22 - a12 * a12);
-          z1 = (a22 * y1 - a12 * y2) * idet;
-          z2 = (a11 * y2 - a12 * y1) * idet;
-        }
-        corr = w.Minv[row][i1] * z1 + (i2 == i1 ? 0.0 : w.Minv[row][i2] * z2);
-      }
-      p = in ? -(y - corr) : 0.0;
-      pf.ph(11 + 6 * S);
-    } else {
-    real h[NV];
-    newton_hessian<NL, G, S>(w, m, sub, cr, mdiag, qf, ql, qm, h);
-    pf.ph(9 + 6 * S);
-    // ---- p = -H^-1 grad
-    real invd = 1;
-    int hbad = 0;
-    bool blocks = false;
-    if constexpr (S == KM_SUB_ARM && G == 32) blocks = lm.split != 0;
-    if (blocks) {
-      // Two-arm models: the arm problem's Hessian has the inertia's two diagonal blocks (a finger / link sphere on the table
-      // touches one arm only).  Each DPP row factorises and solves ONE block with the one-row code: lane c of row r takes over
-      // row base_r + c of H (block-local columns) and that dof's gradient from the lane that built them, and hands the
-      // direction back -- 13 wave shuffles around two 11-pivot solves side by side instead of one 20-pivot solve across rows.
-      if constexpr (S == KM_SUB_ARM && G == 32) {
-        constexpr int NB = KM_BLOCK_MAX;
-        const int split = lm.split, lane0 = (threadIdx.x & 63) & ~31;
-        const int row = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
-        const int base = row ? split : 0, nb = row ? NL - split : split;
-        const bool on = c < nb;
-        const int src = lane0 + (on ? base + c : 0);
-        real mine[NB], loc[NB];                                  // my dof's row of H in ITS block's column order
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-          const real lo = h[k], hi = split == 10 ? h[(10 + k) < NL ? 10 + k : NL - 1] : h[(11 + k) < NL ? 11 + k : NL - 1];
-          mine[k] = sub < split ? lo : hi;
-        }
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-          const real v = __shfl(mine[k], src, 64);
-          loc[k] = (on && k < nb) ? v : ((!on && k == c) ? 1.0 : 0.0);
-        }
-        const real gsrc = __shfl(in ? -grad : 0.0, src, 64);
-        real invl = 0, utl[NB];
-        chol_rows1<NB, 0, NB, 0, true>(loc, utl, invl, c, true, hbad);
-        if (__any(hbad)) { const int gb = gor<G>(hbad); if (gb && sub == 0) w.bad = 1; }
-        pf.ph(10 + 6 * S);
-        const real pl = chol_solve_rows1<NB, 0, NB, 0>(loc, utl, invl, on ? gsrc : 0.0);
-        const int back = lane0 + (sub < split ? sub : 16 + (sub < NL ? sub - split : 0));
-        const real pb = __shfl(pl, back, 64);
-        p = in ? pb : 0.0;
-        pf.ph(11 + 6 * S);
-      }
-    } else {
-    // blocks that sit inside one DPP row use the one-row code (single-arm models: every subset; two-arm models: the cube block,
-    // dofs NL..NL+5 of the group's second row)
-    constexpr bool onerow = G == 16 || (S == KM_SUB_CUBE && NL >= 16);
-    if constexpr (onerow) {
-      constexpr int BASE = G == 16 ? 0 : 16, ND = SS::D1 - SS::D0;
-      const int sl = sub - BASE;
-      const bool live = G == 16 || sub >= 16;
-      real ut[NV];
-      if constexpr (ND <= 6) {
-        chol_rows1<NV, SS::D0, SS::D1, BASE, true>(h, ut, invd, sl, live, hbad);
-      } else {
-        chol_rows1<NV, SS::D0, SS::D1, BASE, false>(h, ut, invd, sl, live, hbad);
-        chol_transpose<NV, SS::D0, SS::D1, BASE>(w.LT, h, ut, sl);
-      }
-      if (hbad && sub == 0) w.bad = 1;
-      pf.ph(10 + 6 * S);
-      p = chol_solve_rows1<NV, SS::D0, SS::D1, BASE>(h, ut, invd, in ? -grad : 0.0);
-    } else {
-    chol_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, hbad);
-    if (hbad && sub == 0) w.bad = 1;
-    pf.ph(10 + 6 * S);
-    p = chol_solve_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, in ? -grad : 0.0);
-    }
-    pf.ph(11 + 6 * S);
-    }
-    }
-    // ---- exact line search on phi(alpha) = cost(a + alpha p)
-    real Mp;
-    if constexpr (S == KM_SUB_CUBE) Mp = mdiag * p; else Mp = mass_mul<NL, G>(cr, sub, mdiag, p);
-    const real gp = gsum<G>(in ? p * Mr : 0.0), pMp = gsum<G>(p * Mp);
-    // per-contact projections of p, parked next to those of a in the records (den[] slots)
-    real plin[3] = {0, 0, 0}, pangw[3] = {0, 0, 0};
-    if constexpr (S != KM_SUB_ARM) cube_part<NL, G>(w, p, plin, pangw);
-    static_for<0, NC>([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      if constexpr (SS::slot(c)) {
-        if ((act >> c) & 1u) {
-          real y[4] = {0, 0, 0, 0};
-          if constexpr (slot_kind<NL>(c) == 0) plane_proj<NL>(w, c, plin, pangw, y);
-          else {
-#pragma unroll
-            for (int k = 0; k < (slot_kind<NL>(c) == 2 ? 3 : 4); k++) y[k] = gsum<G>(cr.jb[c][k] * p);
-          }
-          if (sub == 0) { w.rec[c].den[0] = y[0]; w.rec[c].den[1] = y[1]; w.rec[c].den[2] = y[2]; w.rec[c].den[3] = y[3]; }
-        }
-      }
-    });
-    GSYNC();
-    // y = J p of this lane's edges from the records
-#pragma unroll
-    for (int q = 0; q < NEQ; q++) {
-      if (lR[q] != 0) {
-        const int t = sub + G * q, c = t / 6, e = t - 6 * c, k = e / 2 + 1;
-        const ConRec& rc = w.rec[c];
-        ly[q] = rc.den[0] + lsm[q] * rc.den[k];
-      }
-    }
-    const real xf = a - cr.areff, xl = cr.sg * a - cr.arefl, yl = cr.sg * p;
-    pf.ph(12 + 6 * S);
-    // phi'(0) = grad . p; p is the exact Newton direction of the current active set, so the first trial is the full step
-    // alpha = 1 (phi''(0) = p^T H p = -grad . p): no evaluation of the rows at alpha = 0
-    real alpha = 0, lo = 0, hi = INFINITY;
-    const real d10 = gsum<G>(in ? p * grad : 0.0);
-    if (d10 < 0) {
-      alpha = 1;
-      for (int it = 0; it < 50; it++) {
-        real e1 = 0, e2 = 0;
-        if (in && cr.fl > 0) row_ls(0, xf + alpha * p, p, cr.Rf, cr.Df, cr.fl, e1, e2);
-        if (in && cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, cr.Dl, 0.0, e1, e2);
-#pragma unroll
-        for (int q = 0; q < NEQ; q++) if (lR[q] != 0) row_ls(1, lx[q] + alpha * ly[q], ly[q], lR[q], lD[q], 0.0, e1, e2);
-        const real d1 = gp + alpha * pMp + gsum<G>(e1);
-        const real d2 = pMp + gsum<G>(e2);
-        if (fabs(d1) <= 1e-8 * fabs(d10)) break;        // MuJoCo's ls_tolerance is 1e-2; the outer Newton absorbs the rest
-        if (d1 < 0) lo = alpha; else hi = alpha;
-        if (hi - lo <= 1e-14 * hi) break;                 // bracket collapsed to roundoff
-        if (it == 49) break;
-        real an = alpha - d1 * frcp(d2);
-        if (!(an > lo && an < hi)) an = isfinite(hi) ? 0.5 * (lo + hi) : 2 * alpha + 1;
-        alpha = an;
-      }
-    }
-    pf.ph(13 + 6 * S);
-    // ---- advance the point and everything linear in it
-    a += alpha * p;
-    Mr += alpha * Mp;
-    const real cost_new = newton_eval_step<NL, G, S, NEQ>(w, m, sub, cr, a, a_s, Mr, lx, ly, lR, lD, alpha, grad, qf, ql, qm);
-#pragma unroll
-    for (int q = 0; q < NEQ; q++) lx[q] += alpha * ly[q];
-    const real g1 = in ? grad : 0.0;
-    const real improvement = scale * (cost - cost_new), gradient = scale * km_sqrt(gsum<G>(g1 * g1));
-    cost = cost_new;
-    pf.ph(14 + 6 * S);
-    if (improvement < tol || gradient < tol || w.bad) break;
-  }
-}
-
 // =============================================================================================
-// Slot-lane Newton (one-row groups, G = 16).  Same mathematics and the same iterates as the edge-distributed code above (which
-// the two-row groups still run); the oracle mirrors neither layout, only the algorithm.
+// Slot-lane Newton (round 3; one- and two-row groups).  Lane c < NC of the group's FIRST DPP row owns contact slot c; what the
+// other lanes need from it arrives as a row broadcast inside an FMA (two-row groups: of the copy v_permlane16_swap makes of the
+// first row's registers, ONE swap pair per broadcast value whatever the number of slots).  Same mathematics and iterates as
+// round 2's edge-distributed layout; the oracle mirrors neither, only the algorithm.
 
 // All six pyramid edges of the slot this lane owns at the shifted projections X (x_e = X_0 +- mu_k X_k): the slot's cost, the
 // force it applies along its four basis rows (F = sum_e f_e (1, +-mu_k)), and the Hessian weights of its active edges
 // W = sum_{x_e < 0} D_e (1, +-mu_k)(1, +-mu_k)^T, stored (W00, W01, W02, W03, W11, W22, W33).  Branch-free; an inactive slot
 // (D = D3 = 0) yields zeros.
+// a register of the group's first DPP row as seen from both rows (one-row groups: itself)
+template <int G> __device__ __forceinline__ real row0(real x) {
+  if constexpr (G == 32) return bsrc<32>(x).e; else return x;
+}
+
 template <bool WEIGHTS>
 __device__ __forceinline__ real slot_eval(const SlotC& sc, const real (&X)[4], real (&F)[4], real (&W)[7]) {
   const real t1 = sc.mu * X[1], t2 = sc.mu * X[2], t3 = sc.mu3 * X[3];
@@ -2122,20 +1651,17 @@ __device__ __forceinline__ void slot_project(const Ws<NL>& w, const CReg<NL>& cr
 template <int NL, int G, int S>
 __device__ __forceinline__ void slot_grad(const CReg<NL>& cr, uint32_t act, const real (&F)[4], real& grad) {
   constexpr int NC = Dim<NL>::NC;
+  static_assert(NC <= 16, "the slot lanes sit in the group's first DPP row");
   using SS = SubSet<NL, S>;
+  const real F0 = row0<G>(F[0]), F1 = row0<G>(F[1]), F2 = row0<G>(F[2]), F3 = row0<G>(F[3]);
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if constexpr (SS::slot(c)) {
       if ((act >> c) & 1u) {
-        if constexpr (slot_kind<NL>(c) == 2) {
-          real g2 = 0;
-          dppfma_acc3<c>(g2, F[0], cr.jb[c][0], F[1], cr.jb[c][1], F[2], cr.jb[c][2]);
-          grad -= g2;
-        } else {
-          real g2 = 0;
-          dppfma_acc4<c>(g2, F[0], cr.jb[c][0], F[1], cr.jb[c][1], F[2], cr.jb[c][2], F[3], cr.jb[c][3]);
-          grad -= g2;
-        }
+        real g2 = 0;
+        if constexpr (slot_kind<NL>(c) == 2) dppfma_acc3<c>(g2, F0, cr.jb[c][0], F1, cr.jb[c][1], F2, cr.jb[c][2]);
+        else dppfma_acc4<c>(g2, F0, cr.jb[c][0], F1, cr.jb[c][1], F2, cr.jb[c][2], F3, cr.jb[c][3]);
+        grad -= g2;
       }
     }
   });
@@ -2202,6 +1728,9 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
 #pragma unroll
     for (int j = 0; j < NV; j++) h[j] = in ? (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0) : 0.0;
   }
+  real Wb[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) Wb[i] = row0<G>(W[i]);
   static_for<0, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if constexpr (SS::slot(c)) {
@@ -2209,19 +1738,23 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
         const real j0 = cr.jb[c][0], j1 = cr.jb[c][1], j2 = cr.jb[c][2], j3 = cr.jb[c][3];
         real t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if constexpr (SS::kind(c) != 2) {
-          dppfma_acc4<c>(t0, W[0], j0, W[1], j1, W[2], j2, W[3], j3);
-          dppfma3<false, c, c, c>(t1, W[1], j0, t2, W[2], j0, t3, W[3], j0);
-          dppfma3<false, c, c, c, false>(t1, W[4], j1, t2, W[5], j2, t3, W[6], j3);
+          dppfma_acc4<c>(t0, Wb[0], j0, Wb[1], j1, Wb[2], j2, Wb[3], j3);
+          dppfma3<false, c, c, c>(t1, Wb[1], j0, t2, Wb[2], j0, t3, Wb[3], j0);
+          dppfma3<false, c, c, c, false>(t1, Wb[4], j1, t2, Wb[5], j2, t3, Wb[6], j3);
         } else {                                                                // (condim-3 pairs have no torsion row)
-          dppfma_acc3<c>(t0, W[0], j0, W[1], j1, W[2], j2);
-          dppfma2<false, c, c>(t1, W[1], j0, t2, W[2], j0);
-          dppfma2<false, c, c, false>(t1, W[4], j1, t2, W[5], j2);
+          dppfma_acc3<c>(t0, Wb[0], j0, Wb[1], j1, Wb[2], j2);
+          dppfma2<false, c, c>(t1, Wb[1], j0, t2, Wb[2], j0);
+          dppfma2<false, c, c, false>(t1, Wb[4], j1, t2, Wb[5], j2);
         }
+        // H[sub][j] += sum_k t_k(sub) * J_k[j]: lane j's basis entries arrive by row broadcast (only the columns the slot's
+        // Jacobian can be nonzero in); DPP sources = the Jacobian columns (or their row copies), written long before: the
+        // first run of a two-row group still waits for the swap that made the copies
+        const BSrc<G> j0s = bsrc<G>(j0), j1s = bsrc<G>(j1), j2s = bsrc<G>(j2), j3s = bsrc<G>(j3);
         static_for<SS::c0(c), SS::c1(c)>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          // (DPP sources = the Jacobian columns, written in the constraint assembly: no wait states)
-          if constexpr (SS::kind(c) != 2) dppfma_acc4<j & 15, false>(h[j], j0, t0, j1, t1, j2, t2, j3, t3);
-          else dppfma_acc3<j & 15, false>(h[j], j0, t0, j1, t1, j2, t2);
+          constexpr bool WT = G == 32 && j == SS::c0(c);
+          if constexpr (SS::kind(c) != 2) dppfma_acc4<j & 15, WT>(h[j], bsel<G, j>(j0s), t0, bsel<G, j>(j1s), t1, bsel<G, j>(j2s), t2, bsel<G, j>(j3s), t3);
+          else dppfma_acc3<j & 15, WT>(h[j], bsel<G, j>(j0s), t0, bsel<G, j>(j1s), t1, bsel<G, j>(j2s), t2);
         });
       }
     }
@@ -2233,7 +1766,6 @@ template <int NL, int G, int S>
 __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, const CReg<NL>& cr,
                                                real mdiag, real a_s, real& a, real& Mr, real cost, real& grad, int& qf, int& ql,
                                                real (&u)[4], real (&W)[7], Prof& pf) {
-  static_assert(G == 16, "slot-lane Newton: one DPP row per env");
   constexpr int NV = Dim<NL>::NV;
   using SS = SubSet<NL, S>;
   const uint32_t act = w.cact;
@@ -2248,16 +1780,28 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
     if (km_sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
   }
   for (int iter = 0; iter < maxit; iter++) {
-    real p;
-    // (Woodbury shortcut of the arm problem: see newton_loop)
+    real p = 0;
+    // The arm problem's quadratic rows are usually just single-dof rows (the two slider friction-loss rows; now and then a
+    // joint at its limit) -- no sphere on the table.  Its Hessian is then M + diag(delta) with at most two nonzero deltas, and
+    // this sub-step already holds M^-1: by the Woodbury identity  p = -(y - M^-1[:,S] z),  y = M^-1 grad,
+    // (diag(1/delta_S) + M^-1[S,S]) z = y_S  -- one row-times-vector product and a 2 x 2 solve instead of a 10-pivot
+    // factorisation and two triangular solves.
     bool plain = false;
     uint32_t rows = 0;
     if constexpr (S == KM_SUB_ARM) {
       const unsigned long long bq = __ballot(slin && W[0] != 0);              // a sphere-table slot with edges in their quadratic zone
       const unsigned long long bal = __ballot(in && (qf | ql));
       const int sh = (threadIdx.x & 63) - sub;
-      rows = (uint32_t)(bal >> sh) & 0xFFFFu;
-      plain = ((uint32_t)(bq >> sh) & 0xFFFFu) == 0 && __popc(rows) <= 2;
+      constexpr uint32_t GM = G == 32 ? 0xFFFFFFFFu : 0xFFFFu;
+      const bool cq = ((uint32_t)(bq >> sh) & GM) != 0;
+      rows = (uint32_t)(bal >> sh) & GM;
+      if constexpr (G == 32) {
+        // two-arm models: M^-1 is block diagonal, so the identity holds per block -- up to two quadratic rows in EACH block,
+        // every lane correcting with the rows of its own block
+        const uint32_t lowm = lm.split ? (1u << lm.split) - 1u : 0xFFFFFFFFu;
+        plain = !cq && __popc(rows & lowm) <= 2 && __popc(rows & ~lowm) <= 2;
+        rows &= (sub < lm.split || !lm.split) ? lowm : ~lowm;
+      } else plain = !cq && __popc(rows) <= 2;
     }
     if (plain) {
       real y = 0;
@@ -2286,18 +1830,69 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
       real h[NV];
       newton_hessian_sl<NL, G, S>(w, sub, cr, mdiag, qf, ql, W, h);
       pf.ph(9 + 6 * S);
-      real invd = 0, ut[NV];
+      // ---- p = -H^-1 grad
       int hbad = 0;
-      constexpr int ND = SS::D1 - SS::D0;
-      if constexpr (ND <= 6) {
-        chol_rows1<NV, SS::D0, SS::D1, 0, true>(h, ut, invd, sub, true, hbad);
+      bool blocks = false;
+      if constexpr (S == KM_SUB_ARM && G == 32) blocks = lm.split != 0;
+      if (blocks) {
+        // Two-arm models: the arm problem's Hessian has the inertia's two diagonal blocks (a finger / link sphere on the table
+        // touches one arm only).  Each DPP row factorises and solves ONE block with the one-row code: lane c of row r takes over
+        // row base_r + c of H (block-local columns) and that dof's gradient from the lane that built them, and hands the
+        // direction back -- 13 wave shuffles around two 11-pivot solves side by side instead of one 20-pivot solve across rows.
+        if constexpr (S == KM_SUB_ARM && G == 32) {
+          constexpr int NB = KM_BLOCK_MAX;
+          const int split = lm.split, lane0 = (threadIdx.x & 63) & ~31;
+          const int row = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+          const int base = row ? split : 0, nb = row ? NL - split : split;
+          const bool on = c < nb;
+          const int src = lane0 + (on ? base + c : 0);
+          real mine[NB], loc[NB];                                  // my dof's row of H in ITS block's column order
+#pragma unroll
+          for (int k = 0; k < NB; k++) {
+            const real lo = h[k], hi = split == 10 ? h[(10 + k) < NL ? 10 + k : NL - 1] : h[(11 + k) < NL ? 11 + k : NL - 1];
+            mine[k] = sub < split ? lo : hi;
+          }
+#pragma unroll
+          for (int k = 0; k < NB; k++) {
+            const real v = __shfl(mine[k], src, 64);
+            loc[k] = (on && k < nb) ? v : ((!on && k == c) ? 1.0 : 0.0);
+          }
+          const real gsrc = __shfl(in ? -grad : 0.0, src, 64);
+          real invl = 0, utl[NB];
+          chol_rows1<NB, 0, NB, 0, true>(loc, utl, invl, c, true, hbad);
+          if (__any(hbad)) { const int gb = gor<G>(hbad); if (gb && sub == 0) w.bad = 1; }
+          pf.ph(10 + 6 * S);
+          const real pl = chol_solve_rows1<NB, 0, NB, 0>(loc, utl, invl, on ? gsrc : 0.0);
+          const int back = lane0 + (sub < split ? sub : 16 + (sub < NL ? sub - split : 0));
+          const real pb = __shfl(pl, back, 64);
+          p = in ? pb : 0.0;
+        }
       } else {
-        chol_rows1<NV, SS::D0, SS::D1, 0, false>(h, ut, invd, sub, true, hbad);
-        chol_transpose<NV, SS::D0, SS::D1, 0>(w.LT, h, ut, sub);
+        // blocks that sit inside one DPP row use the one-row code (single-arm models: every subset; two-arm models: the cube
+        // block, dofs NL..NL+5 of the group's second row)
+        constexpr bool onerow = G == 16 || (S == KM_SUB_CUBE && NL >= 16);
+        real invd = 0;
+        if constexpr (onerow) {
+          constexpr int BASE = G == 16 ? 0 : 16, ND = SS::D1 - SS::D0;
+          const int sl = sub - BASE;
+          const bool live = G == 16 || sub >= 16;
+          real ut[NV];
+          if constexpr (ND <= 6) {
+            chol_rows1<NV, SS::D0, SS::D1, BASE, true>(h, ut, invd, sl, live, hbad);
+          } else {
+            chol_rows1<NV, SS::D0, SS::D1, BASE, false>(h, ut, invd, sl, live, hbad);
+            chol_transpose<NV, SS::D0, SS::D1, BASE>(w.LT, h, ut, sl);
+          }
+          if (hbad && sub == 0) w.bad = 1;
+          pf.ph(10 + 6 * S);
+          p = chol_solve_rows1<NV, SS::D0, SS::D1, BASE>(h, ut, invd, in ? -grad : 0.0);
+        } else {
+          chol_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, hbad);
+          if (hbad && sub == 0) w.bad = 1;
+          pf.ph(10 + 6 * S);
+          p = chol_solve_rows<G, NV, SS::D0, SS::D1>(h, invd, sub, in ? -grad : 0.0);
+        }
       }
-      if (hbad && sub == 0) w.bad = 1;
-      pf.ph(10 + 6 * S);
-      p = chol_solve_rows1<NV, SS::D0, SS::D1, 0>(h, ut, invd, in ? -grad : 0.0);
       pf.ph(11 + 6 * S);
     }
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
@@ -2393,7 +1988,7 @@ __device__ __forceinline__ real solve_newton_sl(Ws<NL>& w, const LModel<NL>& lm,
 template <int NL, int G>
 __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, int actuation,
                                              CReg<NL>& cr, real invm, Prof& pf) {
-  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+  constexpr int NV = Dim<NL>::NV;
   // ---- actuation and smooth acceleration (as in the PGS path)
   if (sub < NV) {
     real rhs = -w.bias[sub];
@@ -2410,34 +2005,7 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
   if (sub < NL) { for (int j = 0; j < NL; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
   else if (sub < NV) a_s = w.tmp[sub] * invm;
   pf.ph(7);
-  if constexpr (G == 16) return solve_newton_sl<NL, G>(w, lm, m, sub, cr, a_s, invm, pf);
-  const uint32_t act = w.cact;
-  const real warm = sub < NV ? w.warm[sub] : 0.0;
-  const real mdiag = (sub >= NL && sub < NV) ? 1.0 / invm : 0.0;
-  real grad; int qf, ql; uint32_t qm[NC];
-  // ---- warm start: the better of qacc_warmstart and qacc_smooth (primal costs of the WHOLE problem, as MuJoCo compares
-  // them).  qacc_smooth first, so that in the usual case (the warm start wins) the state left behind is already the start.
-  real c0, c1, csl;
-  real a = warm;
-  real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
-  newton_eval<NL, G>(w, m, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1, &csl);
-  const real cs = gsum<G>(csl);
-  real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
-  pf.ph(8);
-  if (!(cost0 + cost1 < cs)) {
-    a = a_s; Mr = 0;
-    newton_eval<NL, G>(w, m, sub, cr, a, a_s, Mr, grad, qf, ql, qm, c0, c1);
-    cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
-    pf.ph(38);
-  }
-  constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
-  if (act & FC_MASK) {
-    newton_loop<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, qm, pf);
-  } else {
-    newton_loop<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, qm, pf);
-    newton_loop<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, qm, pf);
-  }
-  return a;
+  return solve_newton_sl<NL, G>(w, lm, m, sub, cr, a_s, invm, pf);
 }
 
 // everything mj_step1 computes that mj_step2 needs, at the state held in w.qpos / w.qvel
