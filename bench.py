@@ -111,11 +111,17 @@ def spawn_ranks(args, argv):
 
 
 # --------------------------------------------------------------------------------------------------------------------
-def algorithmic_bytes_per_env_step(cm, depth=0):
+def camera_bytes_per_env_step(cm):
+    """uint8 RGB camera observations of the *Vision env ids at the reference resolutions (__init__.py:157-161)."""
+    from gym_kmanip_amd.model import CAMERAS
+    return sum(CAMERAS[c].h * CAMERAS[c].w * 3 for c in cm.cameras)
+
+
+def algorithmic_bytes_per_env_step(cm, depth=0, rgb=False):
     """float64 state read once + written once, action read, outputs written (+ the float32 depth image
-    of BASELINE config 5 when rendered in the step)."""
+    of BASELINE config 5 when rendered in the step, + the uint8 camera observations of a *Vision env id)."""
     state = (cm.nq + cm.nv + cm.nu + cm.nv) * 8          # qpos, qvel, ctrl, qacc_warmstart
-    return 2 * state + cm.act_dim * 4 + cm.obs_dim * 8 + 8 + 1 + depth * depth * 4
+    return 2 * state + cm.act_dim * 4 + cm.obs_dim * 8 + 8 + 1 + depth * depth * 4 + (camera_bytes_per_env_step(cm) if rgb else 0)
 
 
 def _committed(name_glob, version=None):
@@ -397,8 +403,20 @@ def run_rank(args):
     # ends by rendering the state it produced, on the same stream
     depth_buf = env.bind_step_depth("grip_r", args.depth, args.depth) if args.depth else None
 
+    # *Vision env ids: the camera branch of get_observation (env_sim.py:140-145) -- every camera of the observation space is
+    # rendered after the step, on the step's stream, at its reference resolution; the render launches are timed with events
+    rgb_bufs = {c: env.render_rgb(c) for c in cm.cameras}
+    rgb_ev = []
+
     def one_step():
         w.step()
+        if rgb_bufs:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for c, buf in rgb_bufs.items():
+                env.render_rgb(c, out=buf)
+            e1.record()
+            rgb_ev.append((e0, e1))
         if gather is not None:
             gather.post(env.reward, env.done)
 
@@ -413,6 +431,7 @@ def run_rank(args):
         one_step()
     barrier()
     env.enable_timing(True)
+    del rgb_ev[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -422,6 +441,8 @@ def run_rank(args):
     dt = time.perf_counter() - t0
     ik_ms, dyn_ms, rnd_ms, nt = env.timing_summary()
     env.enable_timing(False)
+    if rgb_ev:                             # (the library's own third leg covers the bound depth render only)
+        rnd_ms = sum(a.elapsed_time(b) for a, b in rgb_ev[:nt]) if nt else 0.0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -431,7 +452,7 @@ def run_rank(args):
         version = env.L.kmanip_version().decode()
         total_envs = args.envs_total if args.envs_total else world * n
         total_env_steps = total_envs * args.steps
-        bpe = algorithmic_bytes_per_env_step(cm, args.depth)
+        bpe = algorithmic_bytes_per_env_step(cm, args.depth, rgb=bool(rgb_bufs))
         # the launch(es) of one step: k_step, plus k_render when the depth image is rendered in the step (config 5) -- the
         # algorithmic bytes of BOTH over the time of BOTH
         bytes_per_launch = bpe * n
@@ -460,7 +481,8 @@ def run_rank(args):
             "dtype": "f64", "data": "synthetic",
             "timed_window_s": dt,
             "config": {"workload": "%s, %d envs per GPU (%d total), %s, action_space.sample() per step from the Philox stream keyed (seed; env id, episode, step), 64-step episodes with auto-reset, %s"
-                                   % (args.env, n, total_envs, ("%dx%d float32 grip_r depth render in the step" % (args.depth, args.depth)) if args.depth else "no cameras",
+                                   % (args.env, n, total_envs, ("%dx%d float32 grip_r depth render in the step" % (args.depth, args.depth)) if args.depth else
+                                      (("uint8 RGB cameras %s rendered after the step" % "+".join(cm.cameras)) if rgb_bufs else "no cameras"),
                                       "phase-locked envs" if args.no_stagger else "envs desynchronised (episode phase = global env id % 64, one pre-rolled episode)"),
                        "envs_per_gpu": n, "depth_image": ("%dx%d float32 grip_r" % (args.depth, args.depth)) if args.depth else None,
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
@@ -468,7 +490,7 @@ def run_rank(args):
                        "collective": "async all_gather of (reward, done) per step" if gather is not None else "none",
                        "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None, "library": version},
             "roofline": {"bound": "hbm", "bound_note": "the contract's two choices are hbm | mfma; this kernel is bound by FP64 VALU issue and dependent latency (see valu), its HBM fraction is small by construction",
-                         "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)" + (" + k_render (in-step depth image)" if args.depth else ""), "achieved": achieved,
+                         "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)" + (" + k_render (in-step depth image)" if args.depth else (" + k_render_rgb (camera observations)" if rgb_bufs else "")), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": cc["traffic"], "traffic_source": cc["traffic_source"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -481,7 +503,7 @@ def run_rank(args):
             out["warning"] = "timed window %.3f s < 0.25 s: too short for a stable rate (use --steps >= %d)" % (dt, int(0.3 / (dt / args.steps)) + 1)
         if world == 1 and not args.no_variants:
             torch.cuda.synchronize()
-            if not args.depth:
+            if not args.depth and not rgb_bufs:
                 out["seam_variant"] = measure_seam(torch, w)
                 if args.chunk > 1:
                     out["chunked_variant"] = measure_chunked(torch, w, args.chunk)

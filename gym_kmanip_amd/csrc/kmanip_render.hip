@@ -15,11 +15,17 @@
 //           three directional lights of diffuse 0.3), no specular / shadows / fog; background black
 //
 // One workgroup (256 lanes) per env.  Forward kinematics run one link per lane with ceil(log2(depth)) rounds of pointer
-// jumping through LDS (the same scheme as k_step's fk_parallel); then every lane ray-casts pixels p = lane, lane + 256,
-// ... so each wave writes 64 consecutive pixels (coalesced).  The kernel is HBM-write bound: 4 B (depth) or 3 B (rgb) per
-// pixel against ~100 FLOP of ray/primitive tests.  Ray maths stay in float64 like the rest of the path: the depth parity
-// bar against the float64 oracle is 1e-6 m, which float32 intersection arithmetic (cancellation ~1e-5 m) would not meet,
-// and the kernel is bound by its stores, not by FP64 issue.
+// jumping through LDS (the same scheme as k_step's fk_parallel), lane 0 builds the camera frame, then the lanes ray-cast.
+//   depth (k_render_depth): pixels p = lane, lane + 256, ...; float64 ray maths -- the depth parity bar against the float64
+//     oracle is 1e-6 m, which float32 intersection arithmetic (cancellation ~1e-5 m) would not meet.
+//   rgb (k_render_rgb, round 3): the *Vision observations are 480 x 640 x 3 + 40 x 60 x 3 bytes per env-step (__init__.py:
+//     158-161), 929 KB -- the one genuinely HBM-sized output of the path.  Round 2 cast every pixel in float64 (~150 FP64
+//     operations per pixel: 5 x the time the stores need) and wrote three separate bytes per pixel.  Now: (1) float32 ray
+//     maths (the parity bar is one grey level); (2) the cube and the visible spheres are projected to screen-space bounding
+//     rectangles once per env, and a pixel outside all of them can only see the table plane or the background: ~15
+//     operations (most of a head / top image); (3) a lane shades FOUR consecutive pixels of a row and stores their 12 bytes as
+//     three dwords (768 contiguous bytes per wave-instruction group); (4) the per-ray divides of the slab and plane tests are
+//     v_rcp_f32 on quantities that are linear in the pixel coordinates.
 #include "kmanip_device.hpp"
 
 struct RenderScene {
@@ -176,9 +182,8 @@ __device__ __forceinline__ real cast_ray(const KModelDesc* m, const RenderScene&
   return best;
 }
 
-template <bool RGB>
-__global__ __launch_bounds__(256) void k_render(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
-                                                float* __restrict__ depth, uint8_t* __restrict__ rgb) {
+__global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
+                                                      float* __restrict__ depth) {
   __shared__ RenderScene sc;
   const KModelDesc* m = &dm->d;
   const int env = blockIdx.x;
@@ -188,10 +193,6 @@ __global__ __launch_bounds__(256) void k_render(const KDeviceModel* __restrict__
   const real zfar = m->cam_zfar, znear = m->cam_znear;
   const int npix = height * width;
   const real inv_f = 1.0 / sc.focal;
-  // directions TO the three scene lights (scene.xml:11-13: dir = (1,1,-1), (-1,1,-1), (0,-1,-1), normalised)
-  const real r3 = 0.57735026918962576451, r2 = 0.70710678118654752440;
-  const real L[3][3] = {{-r3, -r3, r3}, {r3, -r3, r3}, {0, r2, r2}};
-  const real col[4][3] = {{0, 0, 0}, {0.2, 0.2, 0.2}, {1, 0, 0}, {0.647059, 0.647059, 0.647059}};   // none, table, cube, finger
   for (int p = threadIdx.x; p < npix; p += blockDim.x) {
     const int r = p / width, c = p - r * width;
     const real dx = (c + 0.5 - 0.5 * width) * inv_f, dy = -(r + 0.5 - 0.5 * height) * inv_f;
@@ -200,29 +201,210 @@ __global__ __launch_bounds__(256) void k_render(const KDeviceModel* __restrict__
     real nrm[3];
     int mat;
     const real best = cast_ray(m, sc, d, zfar, nrm, mat);
-    if constexpr (!RGB) {
-      depth[(size_t)env * npix + p] = (float)fmin(fmax(best, znear), zfar);
-    } else {
-      real I = 0;
-      if (mat != 0) {
-        const real dn = 1.0 / sqrt(dot3(d, d));
-        const real head = fmax(0.0, -(nrm[0] * d[0] + nrm[1] * d[1] + nrm[2] * d[2]) * dn);      // headlight at the camera
-        I = 0.4 + 0.4 * head;
+    depth[(size_t)env * npix + p] = (float)fmin(fmax(best, znear), zfar);
+  }
+}
+
+// ---- RGB -----------------------------------------------------------------------------------------------------------
+#define KM_RGB_MAXSPH 4        // visible spheres (the two finger tips per arm)
+struct RgbScene {              // float32 view of the scene for the pixel loop, built by lane 0 from the float64 RenderScene
+  float o[3], X[3], Y[3], Z[3], inv_f, tz, zfar;
+  float ol[3], DX[3], DY[3], DZ[3], half[3], R[9];       // cube: camera origin and the ray basis in the cube frame, half sizes, rotation
+  float oc[KM_RGB_MAXSPH][3], cc[KM_RGB_MAXSPH], ir[KM_RGB_MAXSPH];   // spheres: origin - centre, |oc|^2 - r^2, 1 / r
+  int nsph;
+  int box[4];                  // union of the screen-space bounding rectangles of cube and spheres: r0, r1, c0, c1 (inclusive)
+  float tab_L;                 // directional-light sum on the table's normal
+};
+// pixel (row, col) of the world point P; false if it is not safely in front of the camera
+__device__ __forceinline__ bool rgb_project(const RenderScene& sc, const real* P, int height, int width, real& row, real& col) {
+  const real pc[3] = {P[0] - sc.cam_o[0], P[1] - sc.cam_o[1], P[2] - sc.cam_o[2]};
+  const real zc = -dot3(pc, sc.cam_z);
+  if (!(zc > 1e-3)) return false;
+  const real s = sc.focal / zc;
+  col = dot3(pc, sc.cam_x) * s + 0.5 * width - 0.5;
+  row = -dot3(pc, sc.cam_y) * s + 0.5 * height - 0.5;
+  return true;
+}
+__device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene& sc, int height, int width, RgbScene* g) {
+  for (int c = 0; c < 3; c++) { g->o[c] = (float)sc.cam_o[c]; g->X[c] = (float)sc.cam_x[c]; g->Y[c] = (float)sc.cam_y[c]; g->Z[c] = (float)sc.cam_z[c]; }
+  g->inv_f = (float)(1.0 / sc.focal); g->tz = (float)m->table_z; g->zfar = (float)m->cam_zfar;
+  real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]}, t[3];
+  matT_vec3(t, sc.cube_R, rel); for (int c = 0; c < 3; c++) g->ol[c] = (float)t[c];
+  matT_vec3(t, sc.cube_R, sc.cam_x); for (int c = 0; c < 3; c++) g->DX[c] = (float)t[c];
+  matT_vec3(t, sc.cube_R, sc.cam_y); for (int c = 0; c < 3; c++) g->DY[c] = (float)t[c];
+  matT_vec3(t, sc.cube_R, sc.cam_z); for (int c = 0; c < 3; c++) g->DZ[c] = (float)t[c];
+  for (int c = 0; c < 3; c++) g->half[c] = (float)m->cube_half[c];
+  for (int c = 0; c < 9; c++) g->R[c] = (float)sc.cube_R[c];
+  // bounding rectangle: the cube's eight corners and the spheres' centres +- a conservative projected radius
+  real r0 = 1e30, r1 = -1e30, c0 = 1e30, c1 = -1e30;
+  bool all = false;
+  for (int k = 0; k < 8; k++) {
+    const real loc[3] = {(k & 1 ? 1 : -1) * m->cube_half[0], (k & 2 ? 1 : -1) * m->cube_half[1], (k & 4 ? 1 : -1) * m->cube_half[2]};
+    real P[3], row, col;
+    mat_vec3(P, sc.cube_R, loc);
+    P[0] += sc.cube_p[0]; P[1] += sc.cube_p[1]; P[2] += sc.cube_p[2];
+    if (!rgb_project(sc, P, height, width, row, col)) { all = true; break; }
+    r0 = fmin(r0, row); r1 = fmax(r1, row); c0 = fmin(c0, col); c1 = fmax(c1, col);
+  }
+  int ns = 0;
+  for (int s = 0; s < m->nsphere && !all; s++) {
+    if (!m->sphere_visible[s]) continue;
+    if (ns == KM_RGB_MAXSPH) { all = true; break; }
+    const real rad = m->sphere_radius[s];
+    const real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
+    for (int c = 0; c < 3; c++) g->oc[ns][c] = (float)oc[c];
+    g->cc[ns] = (float)(dot3(oc, oc) - rad * rad); g->ir[ns] = (float)(1.0 / rad);
+    real row, col;
+    const real zc = dot3(oc, sc.cam_z);                                  // depth of the centre along the optical axis
+    if (!rgb_project(sc, sc.sph[s], height, width, row, col) || !(zc - rad > 1e-3)) { all = true; ns++; continue; }
+    const real pr = 1.5 * sc.focal * rad / (zc - rad) + 1.0;             // (off-axis spheres project to ellipses: generous)
+    r0 = fmin(r0, row - pr); r1 = fmax(r1, row + pr); c0 = fmin(c0, col - pr); c1 = fmax(c1, col + pr);
+    ns++;
+  }
+  if (all) {                                                             // finish the sphere list, give up on culling
+    ns = 0;
+    for (int s = 0; s < m->nsphere; s++) {
+      if (!m->sphere_visible[s] || ns == KM_RGB_MAXSPH) continue;
+      const real rad = m->sphere_radius[s];
+      const real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
+      for (int c = 0; c < 3; c++) g->oc[ns][c] = (float)oc[c];
+      g->cc[ns] = (float)(dot3(oc, oc) - rad * rad); g->ir[ns] = (float)(1.0 / rad);
+      ns++;
+    }
+  }
+  g->nsph = ns;
+  if (all) { g->box[0] = 0; g->box[1] = height - 1; g->box[2] = 0; g->box[3] = width - 1; }
+  else {
+    g->box[0] = (int)fmax(floor(r0) - 1, -1.0); g->box[1] = (int)fmin(ceil(r1) + 1, (real)height);
+    g->box[2] = (int)fmax(floor(c0) - 1, -1.0); g->box[3] = (int)fmin(ceil(c1) + 1, (real)width);
+  }
+  g->tab_L = 0.3f * (0.57735026919f + 0.57735026919f + 0.70710678119f);    // sum_l max(0, L_l . (0,0,1)), scene.xml:11-13
+}
+// one pixel, float32: grey level * 255 of the three channels packed r | g << 8 | b << 16
+__device__ __forceinline__ uint32_t rgb_pixel(const RgbScene& g, float dx, float dy, bool full) {
+  const float dz = g.X[2] * dx + g.Y[2] * dy - g.Z[2];
+  const float dd = dx * dx + dy * dy + 1.0f;                   // |d|^2: the camera axes are orthonormal
+  float best = g.zfar;
+  int mat = 0;
+  float n0 = 0, n1 = 0, n2 = 1;
+  if (dz != 0.0f) { const float t = (g.tz - g.o[2]) * __builtin_amdgcn_rcpf(dz); if (t > 0 && t < best) { best = t; mat = 1; } }
+  float d0 = 0, d1 = 0;
+  if (full) {
+    d0 = g.X[0] * dx + g.Y[0] * dy - g.Z[0]; d1 = g.X[1] * dx + g.Y[1] * dy - g.Z[1];
+    // cube box: slab test in the cube frame; the ray direction there is linear in (dx, dy)
+    float t0 = -INFINITY, t1 = INFINITY, s0 = 0, s1 = 0;
+    int a0 = 0, a1 = 0;
+    bool ok = true;
 #pragma unroll
-        for (int l = 0; l < 3; l++) I += 0.3 * fmax(0.0, nrm[0] * L[l][0] + nrm[1] * L[l][1] + nrm[2] * L[l][2]);
-        I = fmin(I, 1.0);
+    for (int a = 0; a < 3; a++) {
+      const float dl = g.DX[a] * dx + g.DY[a] * dy - g.DZ[a], h = g.half[a], o = g.ol[a];
+      if (dl != 0.0f) {
+        const float inv = __builtin_amdgcn_rcpf(dl);
+        float ta = (-h - o) * inv, tb = (h - o) * inv, sa = -1, sb = 1;
+        if (ta > tb) { const float s = ta; ta = tb; tb = s; sa = 1; sb = -1; }
+        if (ta > t0) { t0 = ta; a0 = a; s0 = sa; }
+        if (tb < t1) { t1 = tb; a1 = a; s1 = sb; }
+      } else if (o < -h || o > h) ok = false;
+    }
+    if (ok && t0 <= t1 && t1 > 0) {
+      const bool front = t0 > 0;
+      const float t = front ? t0 : t1;
+      if (t < best) {
+        best = t; mat = 2;
+        const int ax = front ? a0 : a1;
+        const float sg = front ? s0 : s1;
+        n0 = sg * g.R[ax]; n1 = sg * g.R[3 + ax]; n2 = sg * g.R[6 + ax];
       }
-      uint8_t* o = rgb + ((size_t)env * npix + p) * 3;
-      o[0] = (uint8_t)(255.0 * col[mat][0] * I + 0.5); o[1] = (uint8_t)(255.0 * col[mat][1] * I + 0.5); o[2] = (uint8_t)(255.0 * col[mat][2] * I + 0.5);
+    }
+    for (int s = 0; s < g.nsph; s++) {
+      const float b = d0 * g.oc[s][0] + d1 * g.oc[s][1] + dz * g.oc[s][2], disc = b * b - dd * g.cc[s];
+      if (disc >= 0) {
+        const float t = (-b - __builtin_sqrtf(disc)) * __builtin_amdgcn_rcpf(dd);
+        if (t > 0 && t < best) {
+          best = t; mat = 3;
+          n0 = (g.oc[s][0] + t * d0) * g.ir[s]; n1 = (g.oc[s][1] + t * d1) * g.ir[s]; n2 = (g.oc[s][2] + t * dz) * g.ir[s];
+        }
+      }
+    }
+  }
+  if (mat == 0) return 0u;
+  const float rs = __builtin_amdgcn_rsqf(dd);
+  float I;
+  if (mat == 1) I = 0.4f + 0.4f * fmaxf(0.0f, -dz * rs) + g.tab_L;
+  else {
+    const float r3 = 0.57735026919f, r2 = 0.70710678119f;
+    I = 0.4f + 0.4f * fmaxf(0.0f, -(n0 * d0 + n1 * d1 + n2 * dz) * rs)
+        + 0.3f * (fmaxf(0.0f, (-n0 - n1 + n2) * r3) + fmaxf(0.0f, (n0 - n1 + n2) * r3) + fmaxf(0.0f, (n1 + n2) * r2));
+  }
+  I = fminf(I, 1.0f) * 255.0f;
+  if (mat == 1) { const uint32_t v = (uint32_t)(0.2f * I + 0.5f); return v | (v << 8) | (v << 16); }
+  if (mat == 2) return (uint32_t)(I + 0.5f);                                         // cube: rgba 1 0 0
+  const uint32_t v = (uint32_t)(0.647059f * I + 0.5f);
+  return v | (v << 8) | (v << 16);
+}
+
+__global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
+                                                    uint8_t* __restrict__ rgb) {
+  __shared__ RenderScene sc;
+  __shared__ RgbScene g;
+  const KModelDesc* m = &dm->d;
+  const int env = blockIdx.x;
+  render_fk(dm, st, env, &sc);
+  if (threadIdx.x == 0) { render_camera(dm, st, env, cam, height, &sc); rgb_scene(m, sc, height, width, &g); }
+  __syncthreads();
+  const int npix = height * width;
+  const float hw = 0.5f * width, hh = 0.5f * height, inv_f = g.inv_f;
+  uint8_t* out = rgb + (size_t)env * npix * 3;
+  if ((width & 3) == 0) {
+    // four consecutive pixels of a row per lane: 12 bytes = three dwords.  (row, column) advance incrementally with the lane's
+    // stride of 256 quads -- no integer division per iteration
+    const int nq = npix >> 2, wq = width >> 2;
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(out);
+    const int dr = 256 / wq, dq = 256 - dr * wq;
+    int r = threadIdx.x / wq, qc = threadIdx.x - r * wq;
+    const float k0 = g.tz - g.o[2], c1 = 0.4f + g.tab_L, zfar = g.zfar, Xz = g.X[2];
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      const int c = qc << 2;
+      const bool full = r >= g.box[0] && r <= g.box[1] && c + 3 >= g.box[2] && c <= g.box[3];
+      const float dy = -(r + 0.5f - hh) * inv_f;
+      uint32_t px[4];
+      if (full) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = rgb_pixel(g, (c + i + 0.5f - hw) * inv_f, dy, true);
+      } else {
+        // outside the bounding rectangle of cube and spheres a ray can only meet the table plane: branch-free, ~17 operations
+        const float rz = g.Y[2] * dy - g.Z[2], rd = dy * dy + 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float dx = (c + i + 0.5f - hw) * inv_f;
+          const float dz = Xz * dx + rz, dd = dx * dx + rd;
+          const float t = k0 * __builtin_amdgcn_rcpf(dz);
+          const bool hit = dz != 0.0f && t > 0.0f && t < zfar;
+          const float I = fminf(c1 + 0.4f * fmaxf(0.0f, -dz * __builtin_amdgcn_rsqf(dd)), 1.0f);
+          px[i] = hit ? (uint32_t)(51.0f * I + 0.5f) * 0x010101u : 0u;              // table rgba .2 .2 .2: 255 * 0.2 = 51
+        }
+      }
+      out32[3 * q] = px[0] | (px[1] << 24);
+      out32[3 * q + 1] = (px[1] >> 8) | (px[2] << 16);
+      out32[3 * q + 2] = (px[2] >> 16) | (px[3] << 8);
+      qc += dq; r += dr;
+      if (qc >= wq) { qc -= wq; r++; }
+    }
+  } else {
+    for (int p = threadIdx.x; p < npix; p += blockDim.x) {
+      const int r = p / width, c = p - r * width;
+      const bool full = r >= g.box[0] && r <= g.box[1] && c >= g.box[2] && c <= g.box[3];
+      const uint32_t v = rgb_pixel(g, (c + 0.5f - hw) * inv_f, -(r + 0.5f - hh) * inv_f, full);
+      out[3 * (size_t)p] = (uint8_t)v; out[3 * (size_t)p + 1] = (uint8_t)(v >> 8); out[3 * (size_t)p + 2] = (uint8_t)(v >> 16);
     }
   }
 }
 
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
                                 hipStream_t stream) {
-  hipLaunchKernelGGL(k_render<false>, dim3(st.num_envs), dim3(256), 0, stream, dm, st, cam, height, width, depth, (uint8_t*)nullptr);
+  hipLaunchKernelGGL(k_render_depth, dim3(st.num_envs), dim3(256), 0, stream, dm, st, cam, height, width, depth);
 }
 void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, uint8_t* rgb,
                               hipStream_t stream) {
-  hipLaunchKernelGGL(k_render<true>, dim3(st.num_envs), dim3(256), 0, stream, dm, st, cam, height, width, (float*)nullptr, rgb);
+  hipLaunchKernelGGL(k_render_rgb, dim3(st.num_envs), dim3(256), 0, stream, dm, st, cam, height, width, rgb);
 }

@@ -206,3 +206,35 @@ def test_shell_log_h5py_kwargs_and_examples(tmp_path, monkeypatch):
     assert len(os.listdir(d)) == 2
     d = synthetic_data.main(["--num-envs", "64", "--episodes", "1", "--log-envs", "0", "--log-dir", str(tmp_path / "synth")])
     assert len(os.listdir(d)) == 1
+
+
+def test_rgb_render_reference_resolution_vs_oracle():
+    """The camera observations at the reference's own resolutions (head 480 x 640, grip_r 40 x 60: __init__.py:157-161) -- the
+    float32, rectangle-culled, four-pixels-per-lane RGB kernel against the oracle's float64 per-pixel ray caster: equal up to one
+    grey level except silhouette-grazing rays (< 0.1 % of the pixels), and the culled fast path (table / background only) and
+    the full path both occur in the head image."""
+    import torch
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.model import KM_CAM_INDEX, compile_model
+    from oracle.oracle import Oracle
+    cm = compile_model("KManipSoloArmVision")
+    n = 2
+    dev = env_hip.KManipEnvHip(cm, num_envs=n, seed=6); orc = Oracle(cm, n, seed=6)
+    dev.k_reset(); orc.reset()
+    rng = np.random.default_rng(5)
+    for k in range(20):
+        act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
+        dev.step_flat(torch.from_numpy(act).cuda()); orc.step(act)
+    qpos = orc.get_state()[0]
+    for name in cm.cameras:
+        img = dev.render_rgb(name).cpu().numpy()
+        h, w = img.shape[1:3]
+        assert (h, w) == ((480, 640) if name == "head" else (40, 60))
+        for e in range(n):
+            ref = orc.render_rgb(qpos[e], KM_CAM_INDEX[name], h, w)
+            diff = np.abs(img[e].astype(int) - ref.astype(int)).max(axis=-1)
+            assert (diff > 1).mean() < 1e-3, (name, e, int((diff > 1).sum()))
+            if name == "head":
+                red = (ref[..., 0] > 100) & (ref[..., 1] == 0)
+                assert red.any() and (ref[..., 0] == ref[..., 1]).mean() > 0.5      # cube pixels and table / background pixels
+    dev.k_close()
