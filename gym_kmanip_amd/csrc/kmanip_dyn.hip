@@ -705,10 +705,39 @@ __device__ __forceinline__ void gj_cols(real (&upd)[N], const real (&a)[N], real
 // In-place Gauss-Jordan sweep of the SPD matrix whose row `me` this lane holds in a[0..N) (one matrix per DPP row; no
 // pivoting: every pivot of an SPD matrix is a positive Schur complement).  Row k reaches the other lanes through DPP row
 // broadcasts, so there is no LDS traffic and no synchronisation inside the n^2 loop.
+// a[j] -= bcast_K(a[j]) * f IN PLACE for j in [J0, J1), j != K: each instruction reads its own destination register through
+// DPP (lane K's copy, before any lane writes it) -- no second register set, no selects.  Every run spends the two DPP wait
+// states: a source may have been written by a plain select (the loads' masking before the first pivot, the pivot column's
+// update) that the scheduler is free to place directly in front of the run.
+template <int K, int J0, int J1, int N>
+__device__ __forceinline__ void gj_cols_inplace(real (&a)[N], real f) {
+#define KM_GJ1(I) "v_fmac_f64_dpp %" #I ", -%" #I ", %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+  if constexpr (J1 - J0 >= 4 && !(K >= J0 && K < J0 + 4)) {
+    asm volatile("s_nop 1\n\t" KM_GJ1(0) KM_GJ1(1) KM_GJ1(2) KM_GJ1(3) : "+v"(a[J0]), "+v"(a[J0 + 1]), "+v"(a[J0 + 2]), "+v"(a[J0 + 3]) : "v"(f), "n"(K));
+    gj_cols_inplace<K, J0 + 4, J1>(a, f);
+  } else if constexpr (J1 - J0 >= 1) {
+    if constexpr (J0 != K) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a[J0]) : "v"(f), "n"(K));
+    gj_cols_inplace<K, J0 + 1, J1>(a, f);
+  }
+#undef KM_GJ1
+}
 template <int G, int N>
 __device__ __forceinline__ void gj_invert_rows(real (&a)[N], int me_idx, int& bad) {
   static_for<0, N>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
+    if constexpr (G == 16) {
+      // one-row form (round 3): the pivot row scales itself through the same update as the others -- with f = 1 - d on the
+      // pivot's own lane, a_kj - a_kj (1 - d) = a_kj d -- so a pivot costs one select for f and one for the pivot column
+      // instead of two per column, and the update runs in place
+      if constexpr (k > 0) dpp_settle(a[k]);           // (written by the previous pivot's runs: the broadcast below is compiler code)
+      const real pk = gbcast<G, k>(a[k]);
+      bad |= !(pk > 0);
+      const real d = frcp(pk);
+      const bool me = me_idx == k;
+      const real f = me ? 1.0 - d : a[k] * d;
+      gj_cols_inplace<k, 0, N>(a, f);
+      a[k] = me ? d : -f;
+    } else {
     real pk = gbcast<G, k>(a[k]);
     if (!(pk > 0)) { bad = 1; pk = 1; }
     const real d = frcp(pk);
@@ -724,6 +753,7 @@ __device__ __forceinline__ void gj_invert_rows(real (&a)[N], int me_idx, int& ba
 #pragma unroll
     for (int j = 0; j < N; j++) if (j != k) a[j] = me ? a[j] * d : upd[j];
     a[k] = me ? d : -aik * d;
+    }
   });
 }
 
