@@ -21,15 +21,17 @@ for env in ["KManipSoloArm", "KManipDualArm", "KManipTorso"]:
     dev.k_reset(); orc.reset()
     stagger = (np.arange(n) % 64).astype(np.int32)
     dev.set_state(step=stagger); orc.set_state(*dev.get_state())
-    rng = np.random.default_rng(7)
+    rng = None
     worst = dict(q=0.0, v=0.0, r=0.0)
     n_mask = n_done = n_ctrl = n_nfev = 0
     seen = 0
     t0 = time.time()
     for k in range(steps):
-        act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
-        dev.step_flat(torch.from_numpy(act).cuda())
-        oo, ro, do = orc.step(act)
+        a = dev.sample_action()                   # bench.py's counter-based action stream
+        act = a.cpu().numpy()
+        assert np.array_equal(act, orc.sample_action())
+        dev.step_flat(a)
+        oo, ro, do = orc.step(act, nthreads=16)
         sg, so = dev.get_state(), orc.get_state()
         ok = ~(sg[2] != so[2]).any(axis=1)       # a float32 rounding flip of ctrl (1 ulp) legitimately moves that env's step by ~1e-5
         worst["q"] = max(worst["q"], float(np.abs(sg[0] - so[0])[ok].max())); worst["v"] = max(worst["v"], float(np.abs(sg[1] - so[1])[ok].max()))

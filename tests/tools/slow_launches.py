@@ -9,10 +9,12 @@ import torch
 import bench
 
 args = bench.parse_args(["--no-variants", "--no-cpu-baseline"])
-w = bench.Workload(torch, "KManipSoloArm", 4096, 0, 0, 0, "newton", 100, 1234)
+w = bench.Workload(torch, "KManipSoloArm", 4096, 0, 0, 0, "newton", 100)
 env = w.env
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+w.lay_out(steps)                      # bench.py's action stream (Philox keyed (seed; env id, episode, step))
 rows = []
+slow_envs = {}
 for k in range(steps):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); w.step(); e1.record(); torch.cuda.synchronize()
@@ -23,6 +25,8 @@ for k in range(steps):
         j = int(nfev[:, 0].argmax())
         print("step %3d  %.3f ms  max nfev %d (env %d, status %d)  nfev>100: %d envs  contact mask of that env %s" % (
             k, ms, nfev[j, 0], j, st[j, 0], int((nfev[:, 0] > 100).sum()), hex(int(mask[j]))))
+        if ms > 2.0:
+            slow_envs.setdefault(j, []).append(k)
 
 r = np.array(rows, dtype=np.float64)
 print("launch ms: mean %.3f  p50 %.3f  p90 %.3f  p99 %.3f  max %.3f" % (r[:, 0].mean(), *np.percentile(r[:, 0], [50, 90, 99]), r[:, 0].max()))
@@ -32,3 +36,4 @@ for lo, hi in [(0, 100), (100, 200), (200, 400), (400, 10000)]:
     sel = (r[:, 1] >= lo) & (r[:, 1] < hi)
     if sel.any():
         print("  launches with max nfev in [%d, %d): %4d  mean %.3f ms" % (lo, hi, sel.sum(), r[sel, 0].mean()))
+print("  slow launches (> 2 ms) by the env with the largest nfev: %s" % {e: ks for e, ks in sorted(slow_envs.items())})

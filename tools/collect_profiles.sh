@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (via gpurun) from the repo root: bench line + rocprofv3 kernel stats of the SAME command + PMC HBM
 # traffic (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) -> gpurun_out/prof_<tag>/
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 # group of <= 8 SQ counters (never combined with a trace).  Averages the LAST 16 launches of each kernel = the timed,
 # desynchronised steady-state steps of bench.py.  Writes gpurun_out/sq_<tag>/sq.json with _meta.version = kmanip_version().
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/sq_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
