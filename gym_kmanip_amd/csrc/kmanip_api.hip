@@ -132,9 +132,12 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
       bool ok = true;
       for (int i = s; i < d->nlink && ok; i++) ok = (x->anc_mask[i] & ((1u << s) - 1u)) == 0;
       const int big = s > d->nlink - s ? s : d->nlink - s;
-      if (ok && big <= KM_BLOCK_MAX && big < best && (s == 10 || s == 11)) { best = big; x->split = s; }   // (the two layouts the device code selects between: DualArm 10 + 10, Torso 11 + 9)
+      // only the two layouts the device code is written for (its row-per-block paths pick the second block's columns at
+      // compile-time offsets 10 or 11): DualArm 10 + 10, Torso 11 + 9.  Any other forest runs the full two-row code (split = 0).
+      if (ok && big <= KM_BLOCK_MAX && big < best && (s == 10 || s == 11)) { best = big; x->split = s; }
     }
   }
+  if (x->split != 0 && x->split != 10 && x->split != 11) { err = "internal: block split other than 10 / 11"; return -1; }
   for (int a = 0; a < KM_MAX_ARMS; a++) {
     if (!d->arm_present[a]) continue;
     int chain[KM_MAX_LINKS], n = 0;

@@ -165,7 +165,10 @@ class KManipEnvHip:
 
     def k_step(self, action):
         """KManipEnvSim.k_step (env_sim.py:196-200).  `terminated` is always False in the reference
-        (get_termination -> None); the TimeLimit truncation and the divergence flag are in `self.done`."""
+        (get_termination -> None); the TimeLimit truncation and the divergence flag are in `self.done`.
+        ALIASING: the returned reward / terminated / sim_time tensors and the observation dict's values are the handle's live
+        device buffers (views of self.obs), overwritten in place by the next step -- clone() what goes into a rollout list or
+        a replay buffer."""
         torch = _torch()
         act = self.pack_action(action)
         self.last_act = act                      # the flat float32 row this step ran on (episode loggers read it)

@@ -9,6 +9,8 @@ gymnasium is not installed in the build image, so spaces degrade to duck-typed s
 With num_envs == 1 and squeeze=True the return values have the reference's single-env shapes.
 With device_outputs=True nothing crosses PCIe: observations, reward, terminated, truncated are device tensors and the
 step never synchronises (the drop-in path at full speed); the default returns host NumPy like the reference.
+ALIASING (device_outputs=True): the returned tensors are the backend's live device buffers -- the observation values are views of
+its obs matrix -- and the next step overwrites them in place; clone() anything kept across steps (rollout lists, replay buffers).
 log_h5py=True / log_prefix reproduce env_base.py:82-101,231-263: a fresh `<log_prefix>.<uuid6>.<date>` directory under DATA_DIR
 and one episode file per reset (episode_log.EpisodeLogger: device-resident rings, written out at the next reset / close).
 """
