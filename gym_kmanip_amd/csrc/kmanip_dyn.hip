@@ -1746,17 +1746,17 @@ __device__ __forceinline__ void newton_eval_sl(const Ws<NL>& w, int sub, const C
 // from lane c inside the FMAs that build t = W_c J_c[:, sub]
 template <int NL, int G, int S>
 __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, const CReg<NL>& cr, real mdiag, int qf, int ql,
-                                                  const real (&W)[7], real (&h)[Dim<NL>::NV]) {
+                                                  const real (&W)[7], real (&h)[Dim<NL>::NV], bool in, uint32_t act, bool joint) {
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
   using SS = SubSet<NL, S>;
-  const uint32_t act = w.cact;
-  const bool in = sub >= SS::D0 && sub < SS::D1;
   {
     real dg = sub < NL ? 0.0 : mdiag;
     if (qf) dg += cr.Df;
     if (ql) dg += cr.Dl;
+    // dofs outside the problem: zero rows -- or, in the joint loop (whose pivots run over them too), identity rows
+    const real idg = joint ? 1.0 : 0.0;
 #pragma unroll
-    for (int j = 0; j < NV; j++) h[j] = in ? (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0) : 0.0;
+    for (int j = 0; j < NV; j++) h[j] = in ? (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0) : ((j == sub) ? idg : 0.0);
   }
   real Wb[7];
 #pragma unroll
@@ -1792,16 +1792,24 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
 }
 
 // Newton iterations on one dof subset, from the point (a, Mr, grad, qf, ql, u, W) with cost `cost` (all of the subset).
-template <int NL, int G, int S>
+// JOINT (S = KM_SUB_ALL only): the wave holds at least one coupled env.  Its uncoupled wave-mates would otherwise run their cube
+// loops AFTER the coupled env's 16-dof loop (different code paths: SIMD divergence serialises them -- 0.13-0.34 M clocks on top of
+// the slowest waves of a launch); here they run their CUBE problem inside the same instruction stream instead, as a 16-dof problem
+// whose arm dofs are inert (identity rows, zero gradient, no arm slots: `cube_only`), each env with its own iteration count.  The
+// inert pivots and the zero entries they meet change nothing in the cube block's arithmetic: an env's result does not depend on
+// what its wave-mates are (tests compare shards and launch shapes bit for bit).
+template <int NL, int G, int S, bool JOINT = false>
 __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, const CReg<NL>& cr,
                                                real mdiag, real a_s, real& a, real& Mr, real cost, real& grad, int& qf, int& ql,
-                                               real (&u)[4], real (&W)[7], Prof& pf) {
+                                               real (&u)[4], real (&W)[7], Prof& pf, bool cube_only = false) {
+  static_assert(!JOINT || S == KM_SUB_ALL, "the joint loop is the whole-problem loop");
   constexpr int NV = Dim<NL>::NV;
   using SS = SubSet<NL, S>;
-  const uint32_t act = w.cact;
+  const uint32_t act = (JOINT && cube_only) ? (w.cact & 0xFu) : w.cact;
   const SlotC& sc = cr.sc;
-  const bool in = sub >= SS::D0 && sub < SS::D1;
-  const bool slin = slot_lane_in<NL, S>(sub);          // this lane's slot belongs to the subset (its cost counts, its u moves)
+  const bool in = (JOINT && cube_only) ? (sub >= NL && sub < NV) : (sub >= SS::D0 && sub < SS::D1);
+  // this lane's slot belongs to the problem (its cost counts, its u moves)
+  const bool slin = (JOINT && cube_only) ? sub < 4 : slot_lane_in<NL, S>(sub);
   const real scale = lm.scale;
   const real tol = m->solver_tolerance;
   const int maxit = m->solver_iterations;
@@ -1858,7 +1866,7 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
       pf.ph(11 + 6 * S);
     } else {
       real h[NV];
-      newton_hessian_sl<NL, G, S>(w, sub, cr, mdiag, qf, ql, W, h);
+      newton_hessian_sl<NL, G, S>(w, sub, cr, mdiag, qf, ql, W, h, in, act, JOINT);
       pf.ph(9 + 6 * S);
       // ---- p = -H^-1 grad
       int hbad = 0;
@@ -2006,11 +2014,20 @@ __device__ __forceinline__ real solve_newton_sl(Ws<NL>& w, const LModel<NL>& lm,
     pf.ph(38);
   }
   constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
-  if (act & FC_MASK) {
-    newton_loop_sl<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, u, W, pf);
+  const bool coupled = (act & FC_MASK) != 0;                               // (group-uniform)
+  if (!coupled) newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, u, W, pf);
+  if constexpr (G == 16) {
+    if (__any(coupled)) {
+      // a coupled env in the wave: its whole-problem loop and the wave-mates' cube loops share one instruction stream
+      newton_loop_sl<NL, G, KM_SUB_ALL, true>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, coupled ? cost0 + cost1 : cost1, grad, qf, ql, u, W, pf, !coupled);
+    } else {
+      newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, u, W, pf);
+    }
   } else {
-    newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, u, W, pf);
-    newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, u, W, pf);
+    // two-row groups keep the separate loops: their cube block runs the one-row code in the second DPP row while the whole
+    // problem runs the two-row code -- different operation order, so a joint loop would make an env's bits depend on its wave-mates
+    if (coupled) newton_loop_sl<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, u, W, pf);
+    else newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, u, W, pf);
   }
   return a;
 }
