@@ -874,14 +874,34 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
   const int nsph = m->nsphere < NSPH ? m->nsphere : NSPH;
   const int s = sub - 8;
   bool hitc = false, hitt = false;
-  real ctr[3] = {0, 0, 0}, nloc[3] = {0, 0, 0}, d1 = 0, d2 = 0, rad = 0;
+  real ctr[3] = {0, 0, 0}, ctrt[3] = {0, 0, 0}, nloc[3] = {0, 0, 0}, d1 = 0, d2 = 0, rad = 0;
   if (sub >= 8 && sub < 8 + nsph) {
     const int l = m->sphere_link[s];
     real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, rel[3], loc[3], cl[3];
     mat_vec3(ctr, w.k.xmat[l], sl);
 #pragma unroll
-    for (int a = 0; a < 3; a++) { ctr[a] += w.k.xpos[l][a]; rel[a] = ctr[a] - cp[a]; }
+    for (int a = 0; a < 3; a++) ctr[a] += w.k.xpos[l][a];
     rad = m->sphere_radius[s];
+    // table plane (geom1) - sphere (geom2): the end sphere itself (a capsule meets a plane in its end spheres)
+    d2 = ctr[2] - m->table_z - rad;
+    hitt = d2 < 0;
+    ctrt[0] = ctr[0]; ctrt[1] = ctr[1]; ctrt[2] = ctr[2];
+    // capsule section (kmanip.h sphere_seg): against the cube the collider is the point of the link's segment closest to the
+    // cube centre -- a sphere sliding along the link
+    {
+      const real sg[3] = {m->sphere_seg[s][0], m->sphere_seg[s][1], m->sphere_seg[s][2]};
+      real sw[3];
+      mat_vec3(sw, w.k.xmat[l], sg);
+      const real ss = dot3(sw, sw);
+      if (ss > 0) {
+        real t = ((cp[0] - ctr[0]) * sw[0] + (cp[1] - ctr[1]) * sw[1] + (cp[2] - ctr[2]) * sw[2]) / ss;
+        t = fmin(fmax(t, 0.0), 1.0);
+#pragma unroll
+        for (int a = 0; a < 3; a++) ctr[a] += t * sw[a];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) rel[a] = ctr[a] - cp[a];
     // sphere (geom1) - cube box (geom2)
     matT_vec3(loc, w.k.cube_mat, rel);
     bool inside = true;
@@ -900,9 +920,6 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
       d1 = -bd - rad;
     }
     hitc = d1 < 0;
-    // table plane (geom1) - sphere (geom2)
-    d2 = ctr[2] - m->table_z - rad;
-    hitt = d2 < 0;
   }
   // the first NSS penetrating spheres of each kind (sphere order) get the slots: rank = penetrating spheres on lower lanes
   const uint32_t below_me = (1u << sub) - 1u;
@@ -927,7 +944,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
 #pragma unroll
     for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
     w.c_dist[n] = d2;
-    w.c_pos[n][0] = ctr[0]; w.c_pos[n][1] = ctr[1]; w.c_pos[n][2] = ctr[2] - (rad + 0.5 * d2);
+    w.c_pos[n][0] = ctrt[0]; w.c_pos[n][1] = ctrt[1]; w.c_pos[n][2] = ctrt[2] - (rad + 0.5 * d2);
     w.slot_sph[n] = s;
     mask |= KM_CON_SPHERE_TABLE(s); act |= 1u << n;
   }

@@ -118,6 +118,11 @@ typedef struct KModelDesc {
   int32_t sphere_visible[KM_MAX_SPHERES];       /* 1: drawn by the camera renders (fingers); 0: collision only    */
   double  sphere_pos[KM_MAX_SPHERES][3];
   double  sphere_radius[KM_MAX_SPHERES];
+  /* Capsule sections: a non-zero sphere_seg[s] makes candidate s, AGAINST THE CUBE, the closest point of the link-fixed segment
+   * [sphere_pos, sphere_pos + sphere_seg] to the cube centre (a sphere of the same radius sliding along the link): the forearm /
+   * elbow housings are the ends of capsules between consecutive joint origins.  Against the table plane a capsule touches in
+   * its end spheres, which are candidates of their own, so that test stays on sphere_pos. */
+  double  sphere_seg[KM_MAX_SPHERES][3];
   double  table_z;
 
   /* ---- cube (free body), scene.xml:17-21 */

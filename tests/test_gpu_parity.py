@@ -724,3 +724,56 @@ def test_seam_k_step_device_dict_no_host_roundtrip():
     assert list(obs.keys()) == ["q_pos", "q_vel", "cube_pos", "cube_orn"]
     assert torch.cuda.current_device() == 0
     a.k_close(); b.k_close()
+
+
+@pytest.mark.parametrize("env", ["KManipSoloArmQPos", "KManipDualArmQPos"])
+def test_forearm_cylinder_section_on_the_cube(env):
+    """Capsule sections (KModelDesc.sphere_seg): the forearm / elbow housings are the ends of capsules, and against the cube the
+    collider is the closest point of the link's segment -- the CYLINDER SECTION between two housings touches the cube, not only
+    its end spheres.  The cube is put 2.5 cm beside the MIDDLE of the forearm segment (radius 3 cm, cube half size 2 cm: the
+    section overlaps it, both end spheres are 5 cm and more away): the device and the oracle report the same contact bit -- the
+    forearm candidate's -- and the same step; with sphere_seg zeroed there is no contact at all."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    import copy
+    cm = compile_model(env, auto_reset=False)
+    names = [s["name"] for s in cm.asset["spheres"]]
+    s_fore = names.index("forearm_r")
+    seg = np.array(cm.asset["spheres"][s_fore]["seg"])
+    assert np.linalg.norm(seg) > 0.08                                   # a real section between the two housings
+    nl = cm.nlink
+    orc = Oracle(cm, 1, seed=0); orc.reset()
+    qpos, qvel, ctrl, warm, step = orc.get_state()
+    xpos, xquat, _, _ = orc.fk(qpos[0])
+    l = cm.asset["spheres"][s_fore]["link"]
+    w, x, y, z = xquat[l]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    mid = xpos[l] + R @ (0.5 * seg)
+    axis = R @ seg / np.linalg.norm(seg)
+    side = np.cross(axis, [0.0, 0.0, 1.0]); side /= np.linalg.norm(side)
+    cube = mid + 0.045 * side                                            # 3 cm radius + 2 cm half size - 0.5 cm of penetration
+    qpos[0, nl:nl + 3] = cube; qpos[0, nl + 3:] = [1, 0, 0, 0]
+    for end in (xpos[l], xpos[l] + R @ seg):                            # the end spheres alone do not reach the cube
+        assert np.linalg.norm(cube - end) > 0.03 + 0.02 * np.sqrt(3) + 1e-3
+    dev = env_hip.KManipEnvHip(cm, num_envs=1, seed=0); dev.k_reset()
+    dev.set_state(qpos=qpos, qvel=qvel, ctrl=ctrl, warm=warm, step=step); orc.set_state(qpos, qvel, ctrl, warm, step)
+    act = np.zeros((1, cm.act_dim), dtype=np.float32)
+    dev.step_flat(torch.from_numpy(act).cuda()); orc.step(act)
+    bit = 1 << (8 + s_fore)
+    mg, mo = int(dev.get_diag()[0][0]), int(orc.get_diag()[0][0])
+    assert mg == mo and (mg & bit), (hex(mg), hex(mo))
+    sg, so = dev.get_state(), orc.get_state()
+    assert np.abs(sg[0] - so[0]).max() < TOL_Q and np.abs(sg[1] - so[1]).max() < TOL_V
+    assert np.abs(sg[1][0, nl:nl + 3]).max() > 1e-3                     # the section pushed the cube
+    dev.k_close()
+    # the same state without the section: nothing touches
+    cm0 = copy.deepcopy(cm)
+    for s in range(cm0.desc.nsphere):
+        for k in range(3):
+            cm0.desc.sphere_seg[s][k] = 0.0
+    o0 = Oracle(cm0, 1, seed=0); o0.reset(); o0.set_state(qpos, qvel, ctrl, warm, step)
+    o0.step(act)
+    assert (int(o0.get_diag()[0][0]) & 0xFFF00) == 0

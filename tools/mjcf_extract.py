@@ -315,14 +315,20 @@ def build(env_xml, name):
     for par, side, sp, site in hands:
         spheres.append({"name": "palm_" + side, "link": par, "pos": (0.5 * sp).tolist(), "radius": PALM_RADIUS,
                         "site": site, "visible": 0})
+    # The forearm and elbow housings are the ends of CAPSULES: "seg" is the vector, in the link's own frame, from the link's
+    # origin to the origin of its child on the way to the hand (= that child's body position).  Against the table a capsule
+    # touches in its two end spheres (the housings); against the cube the collider is the closest point of the segment (a
+    # sphere sliding along the link), so the cylinder section between two housings is covered too.  wrist: a plain sphere.
     for tier, tname in enumerate(["wrist", "forearm", "elbow"]):
         for par, side, sp, site in hands:
-            lk = par
+            lk, child = par, None
             for _ in range(tier):
+                child = lk
                 lk = links[lk]["parent"]
                 assert lk >= 0
+            seg = [0.0, 0.0, 0.0] if child is None else list(links[child]["pos"])
             spheres.append({"name": tname + "_" + side, "link": lk, "pos": [0.0, 0.0, 0.0], "radius": LINK_RADIUS,
-                            "site": site, "visible": 0})
+                            "site": site, "visible": 0, "seg": seg})
 
     spec = {
         "name": name,

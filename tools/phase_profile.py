@@ -73,6 +73,11 @@ if "B" in dir():
         g = B[wv]
         print("  wave %4d  %8.0f | IK %7.0f  ALL %7.0f  ARM %7.0f  CUBE %7.0f  fixed %7.0f" % (
             wv, tot_b[wv], g[:, ik].sum(1).max(), g[:, allp].sum(1).max(), g[:, armp].sum(1).min(), g[:, cubep].sum(1).max(), g[:, fixed].sum(1).max()))
+    print("ALL-loop slots of the ALL-heaviest group of the 6 waves with the longest ALL loops: H build | chol | tri-solve | ls setup | ls loop | eval")
+    allsum = B[:, :, allp].sum(2).max(1)
+    for wv in np.argsort(allsum)[-6:][::-1]:
+        g = B[wv]; gi = g[:, allp].sum(1).argmax()
+        print("  wave %4d group %d  " % (wv, gi) + "  ".join("%8.0f" % g[gi, i] for i in allp) + "   (wave total %.0f)" % tot_b[wv])
     print("IK slots of the IK-heaviest group of the 4 slowest waves: before_step | res+jac | normal matrix | TR solve | select_step | ratio/tests")
     for wv in order[-4:][::-1]:
         g = B[wv]; gi = g[:, ik].sum(1).argmax()
