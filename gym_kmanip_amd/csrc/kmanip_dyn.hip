@@ -102,8 +102,6 @@ struct Ws {
     // ... then the same bytes hold the per-edge Gram rows Ge[c][e][l] = J_l . M^-1 (J_0 + sm J_k)^T for PGS
     struct { real Ge[NC][6][4]; } p;
 #endif
-    // ... and, before any of that, the per-arm scratch of the fused decode + IK (before_step)
-    CoopLds<7> ik[NL > 10 ? 2 : 1];
   };
   real Minv[NL][NL];       // joint-space inertia, overwritten by its inverse
   union {
@@ -2334,9 +2332,8 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     if (sub % GS < GI && arm < KM_MAX_ARMS && (NL > 10 || arm == 0) && m->arm_present[arm]) {
       LdsIO<NL> io{w, st, env};
       const float* arow = act + ((size_t)kc * NE + env) * m->act_dim;
-      CoopLds<7>* L = &w.ik[NL > 10 ? arm : 0];
-      if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, L, arm, sub % GS, arow, io, &pf);
-      else coop_before_step<6>(dm, reinterpret_cast<CoopLds<6>*>(L), arm, sub % GS, arow, io, &pf);
+      if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, arm, sub % GS, arow, io, &pf);
+      else coop_before_step<6>(dm, arm, sub % GS, arow, io, &pf);
     }
     GSYNC();
     pf.ph(30);

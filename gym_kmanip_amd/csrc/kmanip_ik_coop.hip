@@ -20,7 +20,6 @@ struct GlobalIO {
 template <int N, int PPB>
 __global__ __launch_bounds__(64) void k_before_step_coop(const KDeviceModel* __restrict__ dm, KDeviceState st,
                                                          const float* __restrict__ act, int nprob) {
-  __shared__ CoopLds<N> lds[PPB];
   const KModelDesc* m = &dm->d;
   const int NE = st.num_envs;
   const int slot = threadIdx.x / GS, c = threadIdx.x % GS;
@@ -30,7 +29,7 @@ __global__ __launch_bounds__(64) void k_before_step_coop(const KDeviceModel* __r
   if (!m->arm_present[arm]) return;
   GlobalIO io{st, env};
   Prof pf;
-  coop_before_step<N>(dm, &lds[slot], arm, c, act + (size_t)env * m->act_dim, io, &pf);
+  coop_before_step<N>(dm, arm, c, act + (size_t)env * m->act_dim, io, &pf);
 }
 
 __global__ void k_prepare_coop(const KDeviceModel* __restrict__ dm, KDeviceState st) {
@@ -64,7 +63,6 @@ template <int N>
 __global__ __launch_bounds__(64) void k_ik_coop_standalone(const KDeviceModel* __restrict__ dm, int arm, int n, int nq,
                                                            double* qpos, const double* goal_pos, const double* goal_quat,
                                                            double* q_out, int32_t* nfev_o, int32_t* status_o) {
-  __shared__ CoopLds<N> lds[PPW];
   const KModelDesc* m = &dm->d;
   const int slot = threadIdx.x / GS, c = threadIdx.x % GS;
   const int e = blockIdx.x * PPW + slot;
@@ -72,7 +70,7 @@ __global__ __launch_bounds__(64) void k_ik_coop_standalone(const KDeviceModel* _
   double* qp = qpos + (size_t)e * nq;
   CoopCtx<N> P;
   Prof pf;
-  P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N; P.pf = &pf;
+  P.m = m; P.ax = &dm->x; P.arm = arm; P.c = c; P.on = c < N; P.pf = &pf;
   coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? qp[q] : 0.0;
@@ -104,7 +102,6 @@ void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& 
 template <int N>
 __global__ __launch_bounds__(64) void k_ik_eval_coop(const KDeviceModel* __restrict__ dm, int arm, int n, int nq, const double* qpos,
                                                      const double* goal_pos, const double* goal_quat, double* res, double* jac) {
-  __shared__ CoopLds<N> lds[PPW];
   const KModelDesc* m = &dm->d;
   const int slot = threadIdx.x / GS, c = threadIdx.x % GS;
   const int e = blockIdx.x * PPW + slot;
@@ -112,7 +109,7 @@ __global__ __launch_bounds__(64) void k_ik_eval_coop(const KDeviceModel* __restr
   const double* qp = qpos + (size_t)e * nq;
   CoopCtx<N> P;
   Prof pf;
-  P.m = m; P.ax = &dm->x; P.L = &lds[slot]; P.arm = arm; P.c = c; P.on = c < N; P.pf = &pf;
+  P.m = m; P.ax = &dm->x; P.arm = arm; P.c = c; P.on = c < N; P.pf = &pf;
   coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? qp[q] : 0.0;

@@ -5,15 +5,16 @@
 //
 //   8 lanes per IK problem (env, arm), 8 problems per wave.  Lane c owns unknown c: x_c, its bounds, its
 //   Coleman-Li scaling v_c / d_c, gradient g_c, step components, and COLUMN c of the 6 x n task Jacobian.
-//   * forward kinematics: the n sincos run in parallel (one per lane) and are all-gathered through LDS; the
-//     chain product (a 3x3 constant rotation + a planar rotation per link) is then redundant on every lane,
-//     each lane keeping the anchor/axis of ITS joint on the way.
+//   * forward kinematics: the n sincos run in parallel (one per lane), an inclusive prefix product over the lanes (three DPP
+//     row-shift rounds) turns each lane's local transform into its link's world transform, the site link's reaches the others
+//     by row broadcast.
 //   * J^T f, costs, norms, step-to-bound ratios: per-lane scalars + 3-step DPP reductions over 8 lanes
 //     (row_half_mirror, quad_perm, quad_perm) -- every lane gets the bitwise-identical result, so all control
 //     flow (TRF branches, More iterations, termination tests) is uniform inside a problem.
-//   * the 7x7 normal matrix J_h^T J_h + C is built row-per-lane into LDS (one copy per problem); its
-//     Cholesky factor and the triangular solves are redundant per lane in registers (28 doubles).
-// Nothing of the TRF state is a 7-vector in one lane any more, which is what pushed the one-lane-per-problem
+//   * the 7x7 normal matrix J_h^T J_h + C lives one row per lane in registers; its Cholesky factor and both triangular
+//     solves are cooperative (column broadcasts folded into the FMAs).  No LDS anywhere in the IK.
+// Divisions are reciprocal (hardware estimate + two Newton steps: correctly rounded in 1 M samples) times numerator -- at most one
+// ulp from an IEEE divide, 6 instructions instead of ~14.  Nothing of the TRF state is a 7-vector in one lane any more, which is what pushed the one-lane-per-problem
 // kernel into 0.5-1.5 KB of scratch per lane.
 #pragma once
 #include "kmanip_device.hpp"
@@ -55,17 +56,10 @@ template <int K> __device__ __forceinline__ real bcast8(real v) { return __built
 // acc += bcast8<K>(x) * t with the broadcast folded into the FMA
 template <int K> __device__ __forceinline__ void fmac_bcast8(real& acc, real x, real t) { fmac_bcast16<K>(acc, x, t); }
 
-// per-problem LDS scratch: the site link's world transform, published by the lane that ends the chain product
-template <int N>
-struct CoopLds {
-  real pub[12];
-};
-
 template <int N>
 struct CoopCtx {
   const KModelDesc* m;
   const KModelAux* ax;
-  CoopLds<N>* L;
   int arm, c;                 // arm index, lane index inside the problem (unknown index)
   bool on;                    // c < N
   real goal_pos[3], goal_quat[4];
@@ -276,11 +270,12 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], const real 
     pn = km_sqrt(gsum8(p * p));
     if (pn <= Delta) { alpha = 0.0; return; }
   }
-  real alpha_upper = km_sqrt(gsum8(g_h * g_h)) / Delta, alpha_lower = 0.0;
+  const real iDelta = frcp(Delta);
+  real alpha_upper = km_sqrt(gsum8(g_h * g_h)) * iDelta, alpha_lower = 0.0;
   if (full_rank) {
     const real q = tr_fwd<N>(F, p);
-    const real phi = pn - Delta, phip = -gsum8(q * q) / pn;
-    alpha_lower = -phi / phip;
+    const real phi = pn - Delta, phip = -gsum8(q * q) * frcp(pn);
+    alpha_lower = -phi * frcp(phip);
   }
   if (!full_rank && alpha == 0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
   for (int it = 0; it < 10; it++) {
@@ -289,16 +284,16 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], const real 
     p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
     pn = km_sqrt(gsum8(p * p));
     const real q = tr_fwd<N>(F, p);
-    const real phi = pn - Delta, phip = -gsum8(q * q) / pn;
+    const real phi = pn - Delta, phip = -gsum8(q * q) * frcp(pn);
     if (phi < 0) alpha_upper = alpha;
-    const real ratio = phi / phip;
+    const real ratio = phi * frcp(phip);
     alpha_lower = fmax(alpha_lower, alpha - ratio);
-    alpha -= (phi + Delta) * ratio / Delta;
+    alpha -= (phi + Delta) * ratio * iDelta;
     if (fabs(phi) < 0.01 * Delta) break;
   }
   chol_coop<N>(arow, e, alpha, c, F);
   p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
-  p *= Delta / km_sqrt(gsum8(p * p));
+  p *= Delta * rsqrt_nr(gsum8(p * p));
 }
 
 __device__ __forceinline__ void min_quad_1d_c(real a, real b, real lo, real hi, real c, real& t_out, real& y_out) {
@@ -322,7 +317,8 @@ __device__ __forceinline__ real arow_dot(const real (&arow)[N], real v) {
 // step size to the bound along s for this lane (INF if none)
 template <int N>
 __device__ __forceinline__ real lane_step_to_bound(const CoopCtx<N>& P, real x, real s) {
-  return (P.on && s != 0) ? fmax((P.lb - x) / s, (P.ub - x) / s) : INFINITY;
+  const real is = frcp(s);
+  return (P.on && s != 0) ? fmax((P.lb - x) * is, (P.ub - x) * is) : INFINITY;
 }
 
 // scipy trf.py select_step in per-lane form.  Inputs: this lane's x, d, p_h, g_h and its row of the normal matrix.
@@ -348,7 +344,7 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, const real
     const real a = gsum8(rh * rh), b = gsum8(phs * rh), c = gsum8(phs * phs) - Delta * Delta;
     const real dd = sqrt(b * b - a * c);
     const real q = -(b + copysign(dd, b));
-    const real t1 = q / a, t2 = c / q;
+    const real t1 = q * frcp(a), t2 = c * frcp(q);
     to_tr = t1 < t2 ? t2 : t1;
   }
   const real to_bound = gmin8(lane_step_to_bound<N>(P, xb, d * rh));
@@ -368,7 +364,7 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, const real
   const real pht = phs * theta;              // strictly interior version of the restricted step
   const real p_value = 0.5 * gsum8(pht * (Aphs * theta)) + gsum8(gh * pht);
   real agh = -gh;
-  const real to_tr2 = Delta / km_sqrt(gsum8(agh * agh));
+  const real to_tr2 = Delta * rsqrt_nr(gsum8(agh * agh));
   const real to_bound2 = gmin8(lane_step_to_bound<N>(P, x, d * agh));
   real ag_stride = (to_bound2 < to_tr2) ? theta * to_bound2 : to_tr2;
   real ag_value;
@@ -471,7 +467,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       cost_new = coop_cost<N>(P, x_new, ft_new);
       actual = cost - cost_new;
       real ratio, Delta_new = Delta;
-      if (predicted > 0) ratio = actual / predicted;
+      if (predicted > 0) ratio = actual * frcp(predicted);
       else if (predicted == 0 && actual == 0) ratio = 1;
       else ratio = 0;
       if (ratio < 0.25) Delta_new = 0.25 * shn;
@@ -481,7 +477,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       const bool xt_ok = sn < xtol * (xtol + xn);
       if (ft_ok && xt_ok) status = 4; else if (ft_ok) status = 2; else if (xt_ok) status = 3;
       if (status != -1) break;
-      alpha *= Delta / Delta_new;
+      alpha *= Delta * frcp(Delta_new);
       Delta = Delta_new;
       P.pf->ph(37);
     }
@@ -519,7 +515,7 @@ __device__ __forceinline__ real f32r_c(real x) { return (real)(float)x; }
 // stand-alone kernel, the LDS workspace when fused into k_step):
 //   real IO::qpos(int i); void IO::set_ctrl(int i, real v); void IO::set_qpos_ik(int i, real v); void IO::set_diag(int arm, int nfev, int status)
 template <int N, class IO>
-__device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds<N>* L, int arm, int c, const float* a, IO& io, Prof* pf) {
+__device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, int arm, int c, const float* a, IO& io, Prof* pf) {
   const KModelDesc* m = &dm->d;
   const int grip_key[2] = {KM_ACT_GRIP_R, KM_ACT_GRIP_L};
   const int pos_key[2] = {KM_ACT_EER_POS, KM_ACT_EEL_POS};
@@ -536,7 +532,7 @@ __device__ __forceinline__ void coop_before_step(const KDeviceModel* dm, CoopLds
     io.set_ctrl(g1, (double)g);
   }
   CoopCtx<N> P;
-  P.m = m; P.ax = &dm->x; P.L = L; P.arm = arm; P.c = c; P.on = c < N; P.pf = pf;
+  P.m = m; P.ax = &dm->x; P.arm = arm; P.c = c; P.on = c < N; P.pf = pf;
   coop_chain_setup<N>(P);
   const int q = m->arm_q_id[arm][P.on ? c : 0];
   const real x0 = P.on ? io.qpos(q) : 0.0;
