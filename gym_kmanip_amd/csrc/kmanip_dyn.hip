@@ -200,9 +200,19 @@ template <int G> __device__ __forceinline__ real gsum(real v) {
   }
   return v;
 }
+// OR over the G lanes of a group, every lane receiving it: the same four DPP steps as gsum (round 3; round 2 went through
+// four or five dependent ds_bpermute round trips -- 12 of them per sub-step for the contact masks and the divergence flag)
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <int G> __device__ __forceinline__ int gor(int v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v |= __shfl_xor(v, o, G);
+  static_assert(G == 16 || G == 32, "lane group must be one or two DPP rows");
+  v |= dpp_i32<0x140>(v);   // row_mirror
+  v |= dpp_i32<0x141>(v);   // row_half_mirror
+  v |= dpp_i32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v |= dpp_i32<0x4E>(v);    // quad_perm [2,3,0,1]
+  if constexpr (G == 32) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)(r[0] | r[1]);
+  }
   return v;
 }
 
