@@ -1,0 +1,47 @@
+"""CPU check (no GPU needed: hipcc cross-compiles) of the hazard class DESIGN.md 3.4 records: the kernels fold DPP row broadcasts
+into FMAs with inline asm, LLVM's hazard recogniser does not look inside inline asm, and a DPP read of a VGPR less than two wait
+states after a VALU write of it returns stale data on some lanes.  tools/check_dpp_hazard.py scans the FINAL ISA of the shipped
+kernel variants for that pattern."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gym_kmanip_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def test_checker_finds_a_planted_hazard(tmp_path):
+    import check_dpp_hazard as chk
+    s = tmp_path / "t.s"
+    s.write_text("k:\n"
+                 "\tv_fmac_f64_dpp v[2:3], -v[4:5], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                 "\tv_mov_b64_dpp v[8:9], v[2:3] row_newbcast:5 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"      # 0 wait states: hazard
+                 "\tv_add_f64 v[10:11], v[0:1], v[2:3]\n\ts_nop 0\n"
+                 "\tv_mov_b32_dpp v12, v10 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"               # 1 wait state: hazard
+                 "\tv_mul_f64 v[20:21], v[0:1], v[2:3]\n\ts_nop 1\n"
+                 "\tv_fmac_f64_dpp v[2:3], v[20:21], v[6:7] row_newbcast:3 row_mask:0xf bank_mask:0xf\n")       # 2 wait states: fine
+    assert chk.check(str(s)) == 2
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_shipped_kernels_have_no_dpp_read_after_write_hazard(tmp_path):
+    import check_dpp_hazard as chk
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast-honor-pragmas", "-S", "--cuda-device-only"]
+    jobs = [("kmanip_dyn.hip", ["-DKM_VAR_NL=10", "-DKM_VAR_G=16", "-DKM_VAR_SOLVER=1"], "dyn_10_16_1.s"),
+            ("kmanip_dyn.hip", ["-DKM_VAR_NL=20", "-DKM_VAR_G=32", "-DKM_VAR_SOLVER=1"], "dyn_20_32_1.s"),
+            ("kmanip_ik_coop.hip", [], "ik_coop.s")]
+
+    def build(job):
+        src, defs, out = job
+        path = str(tmp_path / out)
+        subprocess.check_call([HIPCC] + flags + defs + [os.path.join(CSRC, src), "-o", path], stderr=subprocess.DEVNULL)
+        return path
+    with ThreadPoolExecutor(3) as ex:
+        listings = list(ex.map(build, jobs))
+    for p in listings:
+        assert chk.check(p) == 0, p
