@@ -212,7 +212,8 @@ struct RgbScene {              // float32 view of the scene for the pixel loop, 
   float ol[3], DX[3], DY[3], DZ[3], half[3], R[9];       // cube: camera origin and the ray basis in the cube frame, half sizes, rotation
   float oc[KM_RGB_MAXSPH][3], cc[KM_RGB_MAXSPH], ir[KM_RGB_MAXSPH];   // spheres: origin - centre, |oc|^2 - r^2, 1 / r
   int nsph;
-  int box[4];                  // union of the screen-space bounding rectangles of cube and spheres: r0, r1, c0, c1 (inclusive)
+  int ubox[4];                     // union of the rectangles below
+  int box[1 + KM_RGB_MAXSPH][4];   // screen-space bounding rectangle of the cube [0] and of every visible sphere: r0, r1, c0, c1 (inclusive)
   float tab_L;                 // directional-light sum on the table's normal
 };
 // pixel (row, col) of the world point P; false if it is not safely in front of the camera
@@ -235,62 +236,58 @@ __device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene
   matT_vec3(t, sc.cube_R, sc.cam_z); for (int c = 0; c < 3; c++) g->DZ[c] = (float)t[c];
   for (int c = 0; c < 3; c++) g->half[c] = (float)m->cube_half[c];
   for (int c = 0; c < 9; c++) g->R[c] = (float)sc.cube_R[c];
-  // bounding rectangle: the cube's eight corners and the spheres' centres +- a conservative projected radius
-  real r0 = 1e30, r1 = -1e30, c0 = 1e30, c1 = -1e30;
-  bool all = false;
-  for (int k = 0; k < 8; k++) {
-    const real loc[3] = {(k & 1 ? 1 : -1) * m->cube_half[0], (k & 2 ? 1 : -1) * m->cube_half[1], (k & 4 ? 1 : -1) * m->cube_half[2]};
-    real P[3], row, col;
-    mat_vec3(P, sc.cube_R, loc);
-    P[0] += sc.cube_p[0]; P[1] += sc.cube_p[1]; P[2] += sc.cube_p[2];
-    if (!rgb_project(sc, P, height, width, row, col)) { all = true; break; }
-    r0 = fmin(r0, row); r1 = fmax(r1, row); c0 = fmin(c0, col); c1 = fmax(c1, col);
+  // bounding rectangles, one per object (an object that is not safely in front of the camera gets the whole image): the cube's
+  // eight corners; a sphere's centre +- a conservative projected radius
+  auto put = [&](int o, bool ok, real r0, real r1, real c0, real c1) {
+    if (!ok) { g->box[o][0] = 0; g->box[o][1] = height - 1; g->box[o][2] = 0; g->box[o][3] = width - 1; return; }
+    g->box[o][0] = (int)fmax(floor(r0) - 1, -1.0); g->box[o][1] = (int)fmin(ceil(r1) + 1, (real)height);
+    g->box[o][2] = (int)fmax(floor(c0) - 1, -1.0); g->box[o][3] = (int)fmin(ceil(c1) + 1, (real)width);
+  };
+  {
+    real r0 = 1e30, r1 = -1e30, c0 = 1e30, c1 = -1e30;
+    bool ok = true;
+    for (int k = 0; k < 8 && ok; k++) {
+      const real loc[3] = {(k & 1 ? 1 : -1) * m->cube_half[0], (k & 2 ? 1 : -1) * m->cube_half[1], (k & 4 ? 1 : -1) * m->cube_half[2]};
+      real P[3], row, col;
+      mat_vec3(P, sc.cube_R, loc);
+      P[0] += sc.cube_p[0]; P[1] += sc.cube_p[1]; P[2] += sc.cube_p[2];
+      ok = rgb_project(sc, P, height, width, row, col);
+      if (ok) { r0 = fmin(r0, row); r1 = fmax(r1, row); c0 = fmin(c0, col); c1 = fmax(c1, col); }
+    }
+    put(0, ok, r0, r1, c0, c1);
   }
   int ns = 0;
-  for (int s = 0; s < m->nsphere && !all; s++) {
-    if (!m->sphere_visible[s]) continue;
-    if (ns == KM_RGB_MAXSPH) { all = true; break; }
+  for (int s = 0; s < m->nsphere; s++) {
+    if (!m->sphere_visible[s] || ns == KM_RGB_MAXSPH) continue;      // (kmanip_create refuses models with more visible spheres)
     const real rad = m->sphere_radius[s];
     const real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
     for (int c = 0; c < 3; c++) g->oc[ns][c] = (float)oc[c];
     g->cc[ns] = (float)(dot3(oc, oc) - rad * rad); g->ir[ns] = (float)(1.0 / rad);
-    real row, col;
+    real row = 0, col = 0;
     const real zc = dot3(oc, sc.cam_z);                                  // depth of the centre along the optical axis
-    if (!rgb_project(sc, sc.sph[s], height, width, row, col) || !(zc - rad > 1e-3)) { all = true; ns++; continue; }
-    const real pr = 1.5 * sc.focal * rad / (zc - rad) + 1.0;             // (off-axis spheres project to ellipses: generous)
-    r0 = fmin(r0, row - pr); r1 = fmax(r1, row + pr); c0 = fmin(c0, col - pr); c1 = fmax(c1, col + pr);
+    const bool ok = rgb_project(sc, sc.sph[s], height, width, row, col) && zc - rad > 1e-3;
+    const real pr = ok ? 1.5 * sc.focal * rad / (zc - rad) + 1.0 : 0.0;  // (off-axis spheres project to ellipses: generous)
+    put(1 + ns, ok, row - pr, row + pr, col - pr, col + pr);
     ns++;
   }
-  if (all) {                                                             // finish the sphere list, give up on culling
-    ns = 0;
-    for (int s = 0; s < m->nsphere; s++) {
-      if (!m->sphere_visible[s] || ns == KM_RGB_MAXSPH) continue;
-      const real rad = m->sphere_radius[s];
-      const real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
-      for (int c = 0; c < 3; c++) g->oc[ns][c] = (float)oc[c];
-      g->cc[ns] = (float)(dot3(oc, oc) - rad * rad); g->ir[ns] = (float)(1.0 / rad);
-      ns++;
-    }
-  }
   g->nsph = ns;
-  if (all) { g->box[0] = 0; g->box[1] = height - 1; g->box[2] = 0; g->box[3] = width - 1; }
-  else {
-    g->box[0] = (int)fmax(floor(r0) - 1, -1.0); g->box[1] = (int)fmin(ceil(r1) + 1, (real)height);
-    g->box[2] = (int)fmax(floor(c0) - 1, -1.0); g->box[3] = (int)fmin(ceil(c1) + 1, (real)width);
+  for (int k = 0; k < 4; k++) {
+    int u = g->box[0][k];
+    for (int o = 1; o <= ns; o++) u = (k & 1) ? max(u, g->box[o][k]) : min(u, g->box[o][k]);
+    g->ubox[k] = u;
   }
   g->tab_L = 0.3f * (0.57735026919f + 0.57735026919f + 0.70710678119f);    // sum_l max(0, L_l . (0,0,1)), scene.xml:11-13
 }
 // one pixel, float32: grey level * 255 of the three channels packed r | g << 8 | b << 16
-__device__ __forceinline__ uint32_t rgb_pixel(const RgbScene& g, float dx, float dy, bool full) {
+__device__ __forceinline__ uint32_t rgb_pixel(const RgbScene& g, float dx, float dy, uint32_t objs) {
   const float dz = g.X[2] * dx + g.Y[2] * dy - g.Z[2];
   const float dd = dx * dx + dy * dy + 1.0f;                   // |d|^2: the camera axes are orthonormal
   float best = g.zfar;
   int mat = 0;
   float n0 = 0, n1 = 0, n2 = 1;
   if (dz != 0.0f) { const float t = (g.tz - g.o[2]) * __builtin_amdgcn_rcpf(dz); if (t > 0 && t < best) { best = t; mat = 1; } }
-  float d0 = 0, d1 = 0;
-  if (full) {
-    d0 = g.X[0] * dx + g.Y[0] * dy - g.Z[0]; d1 = g.X[1] * dx + g.Y[1] * dy - g.Z[1];
+  const float d0 = g.X[0] * dx + g.Y[0] * dy - g.Z[0], d1 = g.X[1] * dx + g.Y[1] * dy - g.Z[1];
+  if (objs & 1u) {
     // cube box: slab test in the cube frame; the ray direction there is linear in (dx, dy)
     float t0 = -INFINITY, t1 = INFINITY, s0 = 0, s1 = 0;
     int a0 = 0, a1 = 0;
@@ -316,7 +313,9 @@ __device__ __forceinline__ uint32_t rgb_pixel(const RgbScene& g, float dx, float
         n0 = sg * g.R[ax]; n1 = sg * g.R[3 + ax]; n2 = sg * g.R[6 + ax];
       }
     }
-    for (int s = 0; s < g.nsph; s++) {
+  }
+  for (int s = 0; s < g.nsph; s++) {
+    if (objs >> (1 + s) & 1u) {
       const float b = d0 * g.oc[s][0] + d1 * g.oc[s][1] + dz * g.oc[s][2], disc = b * b - dd * g.cc[s];
       if (disc >= 0) {
         const float t = (-b - __builtin_sqrtf(disc)) * __builtin_amdgcn_rcpf(dd);
@@ -356,45 +355,59 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
   const float hw = 0.5f * width, hh = 0.5f * height, inv_f = g.inv_f;
   uint8_t* out = rgb + (size_t)env * npix * 3;
   if ((width & 3) == 0) {
-    // four consecutive pixels of a row per lane: 12 bytes = three dwords.  (row, column) advance incrementally with the lane's
-    // stride of 256 quads -- no integer division per iteration
-    const int nq = npix >> 2, wq = width >> 2;
+    // four consecutive pixels of a row per lane: 12 bytes = three dwords.  A wave covers a 64 x 4 pixel tile (16 quads x 4 rows:
+    // 192 contiguous bytes a row) rather than 256 pixels of one row, so that fewer waves straddle the objects' rectangles and
+    // run both the full and the table-only path; the block walks 64 x 16 pixel tiles, tile row and column advancing
+    // incrementally (no integer division)
+    const int wq = width >> 2, tcols = (wq + 15) >> 4, ntile = tcols * ((height + 15) >> 4);
     uint32_t* out32 = reinterpret_cast<uint32_t*>(out);
-    const int dr = 256 / wq, dq = 256 - dr * wq;
-    int r = threadIdx.x / wq, qc = threadIdx.x - r * wq;
-    const float k0 = g.tz - g.o[2], c1 = 0.4f + g.tab_L, zfar = g.zfar, Xz = g.X[2];
-    for (int q = threadIdx.x; q < nq; q += 256) {
-      const int c = qc << 2;
-      const bool full = r >= g.box[0] && r <= g.box[1] && c + 3 >= g.box[2] && c <= g.box[3];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    int tr = 0, tc = 0;
+    // Outside every bounding rectangle a ray can only meet the table plane, and the shaded grey needs no hit distance: with
+    // s = sign(tz - o_z), the hit test 0 < (tz - o_z) / dz < zfar is  s dz > |tz - o_z| / zfar, and the Lambert term
+    // 0.4 max(0, -dz / |d|) is clamp(s dz * rsq(|d|^2) * (-0.4 s)).  ~14 operations a pixel, one of them transcendental
+    const float k0 = g.tz - g.o[2], sg = k0 < 0.0f ? -1.0f : 1.0f, thr = k0 != 0.0f ? fabsf(k0) / g.zfar : INFINITY;
+    const float Xzs = sg * g.X[2], Yzs = sg * g.Y[2], Zzs = sg * g.Z[2], lam = -0.4f * sg, c1 = 0.4f + g.tab_L;
+    const int nobj = g.nsph;
+    for (int tile = 0; tile < ntile; tile++) {
+      const int r = (tr << 4) + ty, qc = (tc << 4) + tx, c = qc << 2, q = r * wq + qc;
+      if (++tc == tcols) { tc = 0; tr++; }
+      if (r >= height || qc >= wq) continue;
       const float dy = -(r + 0.5f - hh) * inv_f;
-      uint32_t px[4];
-      if (full) {
+      uint32_t w0, w1, w2;
+      if (r >= g.ubox[0] && r <= g.ubox[1] && c + 3 >= g.ubox[2] && c <= g.ubox[3]) {
+        uint32_t objs = 0;                                  // objects whose bounding rectangle this quad touches
+        for (int o = 0; o <= nobj; o++)
+          objs |= (uint32_t)(r >= g.box[o][0] && r <= g.box[o][1] && c + 3 >= g.box[o][2] && c <= g.box[o][3]) << o;
+        uint32_t px[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) px[i] = rgb_pixel(g, (c + i + 0.5f - hw) * inv_f, dy, true);
+        for (int i = 0; i < 4; i++) px[i] = rgb_pixel(g, (c + i + 0.5f - hw) * inv_f, dy, objs);
+        w0 = px[0] | (px[1] << 24); w1 = (px[1] >> 8) | (px[2] << 16); w2 = (px[2] >> 16) | (px[3] << 8);
       } else {
-        // outside the bounding rectangle of cube and spheres a ray can only meet the table plane: branch-free, ~17 operations
-        const float rz = g.Y[2] * dy - g.Z[2], rd = dy * dy + 1.0f;
+        const float rz = Yzs * dy - Zzs, rd = dy * dy + 1.0f;
+        uint32_t v[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const float dx = (c + i + 0.5f - hw) * inv_f;
-          const float dz = Xz * dx + rz, dd = dx * dx + rd;
-          const float t = k0 * __builtin_amdgcn_rcpf(dz);
-          const bool hit = dz != 0.0f && t > 0.0f && t < zfar;
-          const float I = fminf(c1 + 0.4f * fmaxf(0.0f, -dz * __builtin_amdgcn_rsqf(dd)), 1.0f);
-          px[i] = hit ? (uint32_t)(51.0f * I + 0.5f) * 0x010101u : 0u;              // table rgba .2 .2 .2: 255 * 0.2 = 51
+          const float sdz = Xzs * dx + rz, dd = dx * dx + rd;
+          const float a = __builtin_amdgcn_fmed3f(sdz * __builtin_amdgcn_rsqf(dd) * lam, 0.0f, 1.0f);
+          const float I = __builtin_amdgcn_fmed3f(a + c1, 0.0f, 1.0f);
+          v[i] = sdz > thr ? (uint32_t)(51.0f * I + 0.5f) : 0u;                     // table rgba .2 .2 .2: 255 * 0.2 = 51
         }
+        // grey pixels: the three dwords are byte replications of the four values
+        w0 = __builtin_amdgcn_perm(v[1], v[0], 0x04000000u);                         // v0 v0 v0 v1
+        w1 = __builtin_amdgcn_perm(v[2], v[1], 0x04040000u);                         // v1 v1 v2 v2
+        w2 = __builtin_amdgcn_perm(v[3], v[2], 0x04040400u);                         // v2 v3 v3 v3
       }
-      out32[3 * q] = px[0] | (px[1] << 24);
-      out32[3 * q + 1] = (px[1] >> 8) | (px[2] << 16);
-      out32[3 * q + 2] = (px[2] >> 16) | (px[3] << 8);
-      qc += dq; r += dr;
-      if (qc >= wq) { qc -= wq; r++; }
+      out32[3 * q] = w0; out32[3 * q + 1] = w1; out32[3 * q + 2] = w2;
     }
   } else {
     for (int p = threadIdx.x; p < npix; p += blockDim.x) {
       const int r = p / width, c = p - r * width;
-      const bool full = r >= g.box[0] && r <= g.box[1] && c >= g.box[2] && c <= g.box[3];
-      const uint32_t v = rgb_pixel(g, (c + 0.5f - hw) * inv_f, -(r + 0.5f - hh) * inv_f, full);
+      uint32_t objs = 0;
+      for (int o = 0; o <= g.nsph; o++)
+        objs |= (uint32_t)(r >= g.box[o][0] && r <= g.box[o][1] && c >= g.box[o][2] && c <= g.box[o][3]) << o;
+      const uint32_t v = rgb_pixel(g, (c + 0.5f - hw) * inv_f, -(r + 0.5f - hh) * inv_f, objs);
       out[3 * (size_t)p] = (uint8_t)v; out[3 * (size_t)p + 1] = (uint8_t)(v >> 8); out[3 * (size_t)p + 2] = (uint8_t)(v >> 16);
     }
   }
