@@ -337,7 +337,7 @@ template <int K0, int N, class F> __device__ __forceinline__ void static_for(F&&
 
 // ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
 // their own and never feed an output; the shipped library compiles every call away.
-#define KM_NPH 40
+#define KM_NPH 44
 #ifdef KM_PROFILE
 static __device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
 #define KM_PROF_BLOCKS 4096
@@ -351,6 +351,7 @@ struct Prof {
     acc[i] += t - t0; t0 = t;
     __builtin_amdgcn_sched_barrier(0);
   }
+  __device__ __forceinline__ void cnt(int i, unsigned n) { acc[i] += n; }      // event counters share the stamp slots (40..)
   __device__ __forceinline__ void flush() {
     if (threadIdx.x == 0) for (int i = 0; i < KM_NPH; i++) atomicAdd(&g_prof[i], acc[i]);
     if ((threadIdx.x & 15) == 0 && blockIdx.x < KM_PROF_BLOCKS) for (int i = 0; i < KM_NPH; i++) g_prof_blk[blockIdx.x][threadIdx.x >> 4][i] = acc[i];
@@ -360,6 +361,7 @@ struct Prof {
 struct Prof {
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void ph(int) {}
+  __device__ __forceinline__ void cnt(int, unsigned) {}
   __device__ __forceinline__ void flush() {}
 };
 #endif

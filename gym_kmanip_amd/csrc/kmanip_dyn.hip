@@ -1838,6 +1838,7 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
   const real scale = lm.scale;
   const real tol = m->solver_tolerance;
   const int maxit = m->solver_iterations;
+  pf.ph(40);       // (what a group waited for wave-mates that ran a loop it does not -- SIMD divergence -- lands here)
   {
     const real g0 = in ? grad : 0.0;
     if (km_sqrt(gsum<G>(g0 * g0)) * scale < tol) return;

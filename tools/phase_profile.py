@@ -6,13 +6,14 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("KMANIP_LIB", os.path.join(ROOT, "gym_kmanip_amd", "libkmanip_hip_prof.so"))
 import numpy as np, torch
 from gym_kmanip_amd import env_hip
-NPH = 40
+NPH = 44
 names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mass", "build_constraints", "solve (PGS)", "newton: a_s",
          "newton: start evals"] + ["newton %s: %s" % (sb, ph) for sb in ("ALL", "ARM", "CUBE") for ph in ("H build", "chol", "tri-solve", "ls setup", "ls loop", "eval")] + [
          "integrate", "post-solve (sibling wait)", "load state", "before_step (decode + IK)", "tail (reward/obs/store)", "auto-reset",
          "IK: residual + Jacobian", "IK: normal matrix", "IK: trust-region solve", "IK: select_step", "IK: ratio / radius / tests",
          "newton: start eval at qacc_smooth (when it beats the warm start)", "invert_mass: row loads (two-arm block path)"]
-names += ["-"] * (NPH - len(names))
+names += ["-"] * (40 - len(names))
+names += ["newton: waiting for wave-mates in a loop this env does not run (divergence)", "-", "-", "-"]
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 env_id = sys.argv[2] if len(sys.argv) > 2 else "KManipSoloArm"          # 20-link ids: totals only (no per-workgroup view)
 n = 4096
@@ -53,7 +54,7 @@ if env.cm.nlink == 10 and hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_
     print("last launch: wave totals  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
         tot_b.mean(), np.median(tot_b), np.percentile(tot_b, 90), np.percentile(tot_b, 99), tot_b.max()))
     newton = list(range(9, 27))
-    work = B.copy(); work[:, :, 28] = 0; work[:, :, 31] = 0     # drop the wait / tail slots: a group's OWN work
+    work = B.copy(); work[:, :, 28] = 0; work[:, :, 31] = 0; work[:, :, 40] = 0     # drop the wait / tail slots: a group's OWN work
     own = work.sum(2)                                            # [nb, 4]
     slow_g = own.argmax(1)
     slow = order[-10:]
@@ -68,11 +69,11 @@ if env.cm.nlink == 10 and hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_
 if "B" in dir():
     ik = [30, 33, 34, 35, 36, 37]; allp = list(range(9, 15)); armp = list(range(15, 21)); cubep = list(range(21, 27))
     fixed = [0, 1, 2, 3, 4, 5, 7, 8, 27, 38, 39]
-    print("slowest waves: total | per-group max of: IK, ALL loop, ARM loop, CUBE loop, fixed per-sub-step work")
+    print("slowest waves: total | per-group max of: IK, ALL loop, ARM loop, CUBE loop, fixed per-sub-step work, waiting for the mates' loops")
     for wv in order[-16:][::-1]:
         g = B[wv]
-        print("  wave %4d  %8.0f | IK %7.0f  ALL %7.0f  ARM %7.0f  CUBE %7.0f  fixed %7.0f" % (
-            wv, tot_b[wv], g[:, ik].sum(1).max(), g[:, allp].sum(1).max(), g[:, armp].sum(1).min(), g[:, cubep].sum(1).max(), g[:, fixed].sum(1).max()))
+        print("  wave %4d  %8.0f | IK %7.0f  ALL %7.0f  ARM %7.0f  CUBE %7.0f  fixed %7.0f  wait %7.0f" % (
+            wv, tot_b[wv], g[:, ik].sum(1).max(), g[:, allp].sum(1).max(), g[:, armp].sum(1).min(), g[:, cubep].sum(1).max(), g[:, fixed].sum(1).max(), g[:, 40].max()))
     print("ALL-loop slots of the ALL-heaviest group of the 6 waves with the longest ALL loops: H build | chol | tri-solve | ls setup | ls loop | eval")
     allsum = B[:, :, allp].sum(2).max(1)
     for wv in np.argsort(allsum)[-6:][::-1]:
