@@ -851,6 +851,11 @@ __device__ __forceinline__ void make_frame(real* fr) {
 // table -> slots 0..3 in corner order), sphere-box (slots 4.., the first NSS penetrating spheres), plane-sphere (slots 4 + NSS..).
 // One candidate per lane: lanes 0..7 test the cube corners (slot = rank among the penetrating corners, from the
 // group's ballot bits), lanes 8..8+NSPH-1 their collision sphere against cube and table.
+// the table top is a rectangle (kmanip.h table_rect): a point is over it while its x, y lie inside
+__device__ __forceinline__ bool over_table(const KModelDesc* m, const real* p) {
+  return p[0] >= m->table_rect[0] && p[0] <= m->table_rect[1] && p[1] >= m->table_rect[2] && p[1] <= m->table_rect[3];
+}
+
 template <int NL, int G>
 __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub) {
   constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS, NST = Dim<NL>::NST;
@@ -864,7 +869,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     mat_vec3(c, w.k.cube_mat, loc);
     c[0] += cp[0]; c[1] += cp[1]; c[2] += cp[2];
     dist = c[2] - m->table_z;
-    below = dist < 0;
+    below = dist < 0 && over_table(m, c);
   }
   const unsigned long long bal = __ballot(below);
   const uint32_t m8 = (uint32_t)(bal >> ((threadIdx.x & 63) - sub)) & 0xFFu;
@@ -892,7 +897,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     rad = m->sphere_radius[s];
     // table plane (geom1) - sphere (geom2): the end sphere itself (a capsule meets a plane in its end spheres)
     d2 = ctr[2] - m->table_z - rad;
-    hitt = d2 < 0;
+    hitt = d2 < 0 && over_table(m, ctr);
     ctrt[0] = ctr[0]; ctrt[1] = ctr[1]; ctrt[2] = ctr[2];
     // capsule section (kmanip.h sphere_seg): against the cube the collider is the point of the link's segment closest to the
     // cube centre -- a sphere sliding along the link

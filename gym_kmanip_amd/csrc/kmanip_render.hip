@@ -131,8 +131,12 @@ __device__ __forceinline__ real cast_ray(const KModelDesc* m, const RenderScene&
   real best = zfar;
   mat = 0;
   nrm[0] = 0; nrm[1] = 0; nrm[2] = 1;
-  // table plane z = table_z
-  if (d[2] != 0) { real t = (m->table_z - sc.cam_o[2]) / d[2]; if (t > 0 && t < best) { best = t; mat = 1; } }
+  // table top: the rectangle table_rect at z = table_z (kmanip.h)
+  if (d[2] != 0) {
+    const real t = (m->table_z - sc.cam_o[2]) / d[2];
+    const real hx = sc.cam_o[0] + t * d[0], hy = sc.cam_o[1] + t * d[1];
+    if (t > 0 && t < best && hx >= m->table_rect[0] && hx <= m->table_rect[1] && hy >= m->table_rect[2] && hy <= m->table_rect[3]) { best = t; mat = 1; }
+  }
   // cube box (slab test in the cube frame)
   {
     real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]}, ol[3], dl[3];
@@ -212,6 +216,10 @@ struct RgbScene {              // float32 view of the scene for the pixel loop, 
   float ol[3], DX[3], DY[3], DZ[3], half[3], R[9];       // cube: camera origin and the ray basis in the cube frame, half sizes, rotation
   float oc[KM_RGB_MAXSPH][3], cc[KM_RGB_MAXSPH], ir[KM_RGB_MAXSPH];   // spheres: origin - centre, |oc|^2 - r^2, 1 / r
   int nsph;
+  // the table top seen from the camera: a ray direction d = X dx + Y dy - Z passes through the rectangle iff the four edge functions
+  // te_a[i] dx + te_b[i] dy + te_c[i] (triple products of d with consecutive corners as seen from the camera, oriented so that the
+  // rectangle's centre is positive) are all positive; te_i[i] = -1 / te_a[i] turns a row's values into its column span
+  float te_a[4], te_b[4], te_c[4], te_i[4];
   int ubox[4];                     // union of the rectangles below
   int box[1 + KM_RGB_MAXSPH][4];   // screen-space bounding rectangle of the cube [0] and of every visible sphere: r0, r1, c0, c1 (inclusive)
   float tab_L;                 // directional-light sum on the table's normal
@@ -276,16 +284,53 @@ __device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene
     for (int o = 1; o <= ns; o++) u = (k & 1) ? max(u, g->box[o][k]) : min(u, g->box[o][k]);
     g->ubox[k] = u;
   }
+  {
+    const real* tr = m->table_rect;
+    if (isfinite(tr[0]) && isfinite(tr[1]) && isfinite(tr[2]) && isfinite(tr[3])) {
+      const real P[4][2] = {{tr[0], tr[2]}, {tr[1], tr[2]}, {tr[1], tr[3]}, {tr[0], tr[3]}};
+      real V[4][3], Vc[3] = {0.5 * (tr[0] + tr[1]) - sc.cam_o[0], 0.5 * (tr[2] + tr[3]) - sc.cam_o[1], m->table_z - sc.cam_o[2]};
+      for (int i = 0; i < 4; i++) { V[i][0] = P[i][0] - sc.cam_o[0]; V[i][1] = P[i][1] - sc.cam_o[1]; V[i][2] = m->table_z - sc.cam_o[2]; }
+      for (int i = 0; i < 4; i++) {
+        real n[3];
+        cross3(n, V[i], V[(i + 1) & 3]);
+        const real sgn = dot3(n, Vc) < 0 ? -1.0 : 1.0;
+        const real a = sgn * dot3(n, sc.cam_x), b = sgn * dot3(n, sc.cam_y), c = -sgn * dot3(n, sc.cam_z);
+        g->te_a[i] = (float)a; g->te_b[i] = (float)b; g->te_c[i] = (float)c;
+        g->te_i[i] = g->te_a[i] != 0.0f ? -1.0f / g->te_a[i] : 0.0f;
+      }
+    } else {
+      for (int i = 0; i < 4; i++) { g->te_a[i] = 0; g->te_b[i] = 0; g->te_c[i] = 1; g->te_i[i] = 0; }   // the infinite plane: always inside
+    }
+  }
   g->tab_L = 0.3f * (0.57735026919f + 0.57735026919f + 0.70710678119f);    // sum_l max(0, L_l . (0,0,1)), scene.xml:11-13
 }
 // one pixel, float32: grey level * 255 of the three channels packed r | g << 8 | b << 16
-__device__ __forceinline__ uint32_t rgb_pixel(const RgbScene& g, float dx, float dy, uint32_t objs) {
+// does the ray direction (dx, dy) pass through the table top?
+__device__ __forceinline__ bool rgb_over_table(const RgbScene& g, float dx, float dy) {
+  bool in = true;
+#pragma unroll
+  for (int i = 0; i < 4; i++) in = in && (g.te_a[i] * dx + (g.te_b[i] * dy + g.te_c[i])) > 0.0f;
+  return in;
+}
+// the open interval of dx over which a row (dy) crosses the table top: lo >= hi = not at all
+__device__ __forceinline__ void rgb_table_span(const RgbScene& g, float dy, float& lo, float& hi) {
+  lo = -INFINITY; hi = INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float e = g.te_b[i] * dy + g.te_c[i], a = g.te_a[i], x = e * g.te_i[i];
+    if (a > 0.0f) lo = fmaxf(lo, x);
+    else if (a < 0.0f) hi = fminf(hi, x);
+    else if (!(e > 0.0f)) lo = INFINITY;
+  }
+}
+
+__device__ __forceinline__ uint32_t rgb_pixel(const RgbScene& g, float dx, float dy, uint32_t objs, bool tab) {
   const float dz = g.X[2] * dx + g.Y[2] * dy - g.Z[2];
   const float dd = dx * dx + dy * dy + 1.0f;                   // |d|^2: the camera axes are orthonormal
   float best = g.zfar;
   int mat = 0;
   float n0 = 0, n1 = 0, n2 = 1;
-  if (dz != 0.0f) { const float t = (g.tz - g.o[2]) * __builtin_amdgcn_rcpf(dz); if (t > 0 && t < best) { best = t; mat = 1; } }
+  if (tab && dz != 0.0f) { const float t = (g.tz - g.o[2]) * __builtin_amdgcn_rcpf(dz); if (t > 0 && t < best) { best = t; mat = 1; } }
   const float d0 = g.X[0] * dx + g.Y[0] * dy - g.Z[0], d1 = g.X[1] * dx + g.Y[1] * dy - g.Z[1];
   if (objs & 1u) {
     // cube box: slab test in the cube frame; the ray direction there is linear in (dx, dy)
@@ -373,7 +418,9 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
       const int r = (tr << 4) + ty, qc = (tc << 4) + tx, c = qc << 2, q = r * wq + qc;
       if (++tc == tcols) { tc = 0; tr++; }
       if (r >= height || qc >= wq) continue;
-      const float dy = -(r + 0.5f - hh) * inv_f;
+      const float dy = -(r + 0.5f - hh) * inv_f, dx0 = (c + 0.5f - hw) * inv_f;
+      float lo, hi;
+      rgb_table_span(g, dy, lo, hi);
       uint32_t w0, w1, w2;
       if (r >= g.ubox[0] && r <= g.ubox[1] && c + 3 >= g.ubox[2] && c <= g.ubox[3]) {
         uint32_t objs = 0;                                  // objects whose bounding rectangle this quad touches
@@ -381,8 +428,10 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
           objs |= (uint32_t)(r >= g.box[o][0] && r <= g.box[o][1] && c + 3 >= g.box[o][2] && c <= g.box[o][3]) << o;
         uint32_t px[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) px[i] = rgb_pixel(g, (c + i + 0.5f - hw) * inv_f, dy, objs);
+        for (int i = 0; i < 4; i++) { const float dx = (c + i + 0.5f - hw) * inv_f; px[i] = rgb_pixel(g, dx, dy, objs, dx > lo && dx < hi); }
         w0 = px[0] | (px[1] << 24); w1 = (px[1] >> 8) | (px[2] << 16); w2 = (px[2] >> 16) | (px[3] << 8);
+      } else if (!(dx0 + 3.0f * inv_f > lo && dx0 < hi)) {
+        w0 = 0; w1 = 0; w2 = 0;                                                        // beside the table: background
       } else {
         const float rz = Yzs * dy - Zzs, rd = dy * dy + 1.0f;
         uint32_t v[4];
@@ -392,7 +441,7 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
           const float sdz = Xzs * dx + rz, dd = dx * dx + rd;
           const float a = __builtin_amdgcn_fmed3f(sdz * __builtin_amdgcn_rsqf(dd) * lam, 0.0f, 1.0f);
           const float I = __builtin_amdgcn_fmed3f(a + c1, 0.0f, 1.0f);
-          v[i] = sdz > thr ? (uint32_t)(51.0f * I + 0.5f) : 0u;                     // table rgba .2 .2 .2: 255 * 0.2 = 51
+          v[i] = (sdz > thr && dx > lo && dx < hi) ? (uint32_t)(51.0f * I + 0.5f) : 0u;   // table rgba .2 .2 .2: 255 * 0.2 = 51
         }
         // grey pixels: the three dwords are byte replications of the four values
         w0 = __builtin_amdgcn_perm(v[1], v[0], 0x04000000u);                         // v0 v0 v0 v1
@@ -407,7 +456,8 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
       uint32_t objs = 0;
       for (int o = 0; o <= g.nsph; o++)
         objs |= (uint32_t)(r >= g.box[o][0] && r <= g.box[o][1] && c >= g.box[o][2] && c <= g.box[o][3]) << o;
-      const uint32_t v = rgb_pixel(g, (c + 0.5f - hw) * inv_f, -(r + 0.5f - hh) * inv_f, objs);
+      const float dx = (c + 0.5f - hw) * inv_f, dy = -(r + 0.5f - hh) * inv_f;
+      const uint32_t v = rgb_pixel(g, dx, dy, objs, rgb_over_table(g, dx, dy));
       out[3 * (size_t)p] = (uint8_t)v; out[3 * (size_t)p + 1] = (uint8_t)(v >> 8); out[3 * (size_t)p + 2] = (uint8_t)(v >> 16);
     }
   }

@@ -148,7 +148,7 @@ class KModelDesc(C.Structure):
         ("arm_has_grip", C.c_int32 * KM_MAX_ARMS), ("pad2_", C.c_int32 * 2),
         ("arm_site_pos", (C.c_double * 3) * KM_MAX_ARMS), ("arm_site_quat", (C.c_double * 4) * KM_MAX_ARMS),
         ("sphere_link", C.c_int32 * KM_MAX_SPHERES), ("sphere_visible", C.c_int32 * KM_MAX_SPHERES), ("sphere_pos", (C.c_double * 3) * KM_MAX_SPHERES),
-        ("sphere_radius", C.c_double * KM_MAX_SPHERES), ("sphere_seg", (C.c_double * 3) * KM_MAX_SPHERES), ("table_z", C.c_double),
+        ("sphere_radius", C.c_double * KM_MAX_SPHERES), ("sphere_seg", (C.c_double * 3) * KM_MAX_SPHERES), ("table_z", C.c_double), ("table_rect", C.c_double * 4),
         ("cube_mass", C.c_double), ("cube_inertia", C.c_double * 3), ("cube_half", C.c_double * 3),
         ("cube_frictionloss", C.c_double), ("cube_quat0", C.c_double * 4),
         ("cube_spawn_lo", C.c_double * 3), ("cube_spawn_hi", C.c_double * 3),
@@ -361,6 +361,8 @@ def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool
             d.sphere_pos[i][k] = s["pos"][k]
             d.sphere_seg[i][k] = s.get("seg", (0.0, 0.0, 0.0))[k]
     d.table_z = asset["table"]["plane_z"]
+    for k, v in enumerate(asset["table"].get("rect", (-np.inf, np.inf, -np.inf, np.inf))):    # x_lo, x_hi, y_lo, y_hi of the table top
+        d.table_rect[k] = v
     cube = asset["cube"]
     d.cube_mass = cube["mass"]
     d.cube_frictionloss = cube["frictionloss"]

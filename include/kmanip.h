@@ -113,7 +113,7 @@ typedef struct KModelDesc {
   double  arm_site_pos[KM_MAX_ARMS][3];         /* site pose in its link frame                     */
   double  arm_site_quat[KM_MAX_ARMS][4];
 
-  /* ---- colliders (surrogates): finger + link spheres, table plane z, cube box */
+  /* ---- colliders (surrogates): finger + link spheres, table top (height + rectangle), cube box */
   int32_t sphere_link[KM_MAX_SPHERES];
   int32_t sphere_visible[KM_MAX_SPHERES];       /* 1: drawn by the camera renders (fingers); 0: collision only    */
   double  sphere_pos[KM_MAX_SPHERES][3];
@@ -124,6 +124,12 @@ typedef struct KModelDesc {
    * its end spheres, which are candidates of their own, so that test stays on sphere_pos. */
   double  sphere_seg[KM_MAX_SPHERES][3];
   double  table_z;
+  /* The table top is the rectangle x_lo..x_hi, y_lo..y_hi at height table_z (world frame): 0.8 m x 0.4 m centred on the table body
+   * -- the plane primitive the reference itself puts in the mesh's place (examples/4_teleop.py:82-84: "table is easier to construct
+   * from base vuer plane primitive than load from stl", TABLE_SIZE 0.4 x 0.8 at body "table"; the long side lies along x: the cube
+   * spawns at x up to 0.3, __init__.py:164-170).  A cube corner or a sphere touches the table only while its centre line meets the
+   * rectangle; beside it, it falls.  +-INFINITY = the round-2 infinite plane. */
+  double  table_rect[4];
 
   /* ---- cube (free body), scene.xml:17-21 */
   double  cube_mass;

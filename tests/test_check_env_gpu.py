@@ -59,7 +59,7 @@ def test_time_limit_truncation_and_cameras_see_the_scene():
     head = obs["camera/head"]
     red = (head[..., 0] > 150) & (head[..., 1] < 60) & (head[..., 2] < 60)        # the cube (rgba 1 0 0, scene.xml:20)
     grey = (np.abs(head[..., 0].astype(int) - head[..., 1]) < 3) & (head[..., 0] > 20)   # the table (rgba .2 .2 .2)
-    assert red.sum() > 20 and grey.mean() > 0.5
+    assert red.sum() > 20 and 0.05 < grey.mean() < 0.3            # the 0.8 x 0.4 m table top fills a tenth of the head image, background around it
     assert obs["camera/grip_r"].shape == (40, 60, 3)
     env.close()
 
@@ -237,4 +237,37 @@ def test_rgb_render_reference_resolution_vs_oracle():
             if name == "head":
                 red = (ref[..., 0] > 100) & (ref[..., 1] == 0)
                 assert red.any() and (ref[..., 0] == ref[..., 1]).mean() > 0.5      # cube pixels and table / background pixels
+    dev.k_close()
+
+
+def test_render_shows_the_table_rectangle():
+    """The table top is a finite rectangle in the camera images too: the fixed `top` camera (0 0 1.3 looking at the table body, fovy
+    78: _env_solo_arm.xml:14) sees the whole 0.8 m x 0.4 m top with background around it -- the grey region's bounding box is what the
+    pinhole model predicts for the rectangle's corners (within two pixels), and depth beside the table is zfar."""
+    import torch
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.model import compile_model
+    cm = compile_model("KManipSoloArmVision")
+    d = cm.desc
+    dev = env_hip.KManipEnvHip(cm, num_envs=1, seed=0); dev.k_reset()
+    h, w = 240, 320
+    img = dev.render_rgb("top", h, w).cpu().numpy()[0]
+    grey = (img[..., 0] == img[..., 1]) & (img[..., 0] > 20)
+    black = img.max(axis=-1) == 0
+    assert 0.04 < grey.mean() < 0.3 and black.mean() > 0.3
+    rows, cols = np.where(grey)
+    # pinhole prediction: camera at (0, 0, 1.3) looking at (0, .6, .5); z = (cam - target) normalised, x = up x z, y = z x x
+    co = np.array([0.0, 0.0, 1.3]); to = np.array([0.0, 0.6, 0.5])
+    z = (co - to) / np.linalg.norm(co - to); x = np.cross([0, 0, 1.0], z); x /= np.linalg.norm(x); y = np.cross(z, x)
+    f = 0.5 * h / np.tan(np.radians(78.0) / 2)
+    rr, cc = [], []
+    for px in (d.table_rect[0], d.table_rect[1]):
+        for py in (d.table_rect[2], d.table_rect[3]):
+            v = np.array([px, py, d.table_z]) - co
+            zc = -v @ z
+            cc.append(v @ x * f / zc + 0.5 * w - 0.5); rr.append(-(v @ y) * f / zc + 0.5 * h - 0.5)
+    assert abs(rows.min() - max(min(rr), 0)) <= 2 and abs(rows.max() - min(max(rr), h - 1)) <= 2
+    assert abs(cols.min() - max(min(cc), 0)) <= 2 and abs(cols.max() - min(max(cc), w - 1)) <= 2
+    dep = dev.render_depth("top", 48, 64).cpu().numpy()[0]
+    assert (dep >= d.cam_zfar - 1e-6).mean() > 0.3 and (dep < 2.0).mean() > 0.04
     dev.k_close()

@@ -43,15 +43,20 @@ def _cmp_state(g, o, k="", resync=None):
     float32 rounding boundary.  With `resync` (a one-element list used as a counter) such a flip -- every mismatching entry
     within one float32 ulp -- re-synchronises the oracle to the device state instead of failing; callers bound the count."""
     sg, so = g.get_state(), o.get_state()
-    assert np.abs(sg[0] - so[0]).max() < TOL_Q, ("qpos", k, np.abs(sg[0] - so[0]).max())
-    assert np.abs(sg[1] - so[1]).max() < TOL_V, ("qvel", k, np.abs(sg[1] - so[1]).max())
-    assert np.array_equal(sg[4], so[4]), ("step_idx", k)
-    if not np.array_equal(sg[2], so[2]):
+    flip = not np.array_equal(sg[2], so[2])
+    if flip:
         bad = sg[2] != so[2]
         ulp = np.spacing(np.abs(so[2][bad]).astype(np.float32)).astype(np.float64)
         assert resync is not None and (np.abs(sg[2][bad] - so[2][bad]) <= ulp).all(), ("ctrl", k, sg[2][bad], so[2][bad])
+    # (the step that follows a flipped ctrl entry was driven by targets 1.2e-7 apart: ten times the bars for that one step)
+    tq, tv = (10 * TOL_Q, 10 * TOL_V) if flip else (TOL_Q, TOL_V)
+    assert np.abs(sg[0] - so[0]).max() < tq, ("qpos", k, np.abs(sg[0] - so[0]).max())
+    assert np.abs(sg[1] - so[1]).max() < tv, ("qvel", k, np.abs(sg[1] - so[1]).max())
+    assert np.array_equal(sg[4], so[4]), ("step_idx", k)
+    if flip:
         resync[0] += 1
         o.set_state(*sg)
+    return flip
 
 
 @pytest.mark.parametrize("env", ENVS3)
@@ -133,16 +138,16 @@ def test_step_parity_vs_oracle(env, n, steps, solver):
         act = rng.uniform(-1, 1, (n, cm.act_dim)).astype(np.float32)
         dev.step_flat(torch.from_numpy(act).cuda())
         oo, ro, do = orc.step(act)
-        _cmp_state(dev, orc, k, resync)
-        assert np.abs(dev.obs.cpu().numpy() - oo).max() < TOL_Q, k
-        assert np.abs(dev.reward.cpu().numpy() - ro).max() < TOL_R, k
+        flip = _cmp_state(dev, orc, k, resync)                     # (a flipped float32 ctrl entry: the observation's velocity part moves with qvel)
+        assert np.abs(dev.obs.cpu().numpy() - oo).max() < (10 * TOL_V if flip else TOL_Q), k
+        assert np.abs(dev.reward.cpu().numpy() - ro).max() < (10 * TOL_R if flip else TOL_R), k
         assert np.array_equal(dev.done.cpu().numpy(), do), k
         mg, nfg, stg = dev.get_diag(); mo, nfo, sto = orc.get_diag()
         assert np.array_equal(mg, mo), (k, mg, mo)
         assert np.array_equal(stg == -2, sto == -2) and np.abs(nfg - nfo).max() <= 1, k
         saw_contact |= bool(mg.any()); saw_reset |= bool(do.any())
     assert saw_contact and saw_reset
-    assert resync[0] <= (2 if solver == "pgs" else 0), resync      # float32 ctrl flips: none with the converging solver
+    assert resync[0] <= (2 if solver == "pgs" else 1), resync      # float32 ctrl flips (a handful in 799 k samples: profiles/r03_parity_soak.txt)
     dev.k_close()
 
 
@@ -362,7 +367,10 @@ def test_full_size_properties_4096():
     obs = a.obs.cpu().numpy()
     assert np.isfinite(obs).all() and (np.abs(obs[:, :2 * nl + 3]) <= 1).all()
     assert (sa[4] == 12).all() and not a.done.cpu().numpy().any()
-    assert (sa[0][:, nl + 2] > 0.5).all()                         # no cube centre below the table plane
+    rect = env_hip.make("KManipSoloArm", num_envs=1).cm.desc.table_rect
+    cx, cy = sa[0][:, nl], sa[0][:, nl + 1]
+    over = (cx > rect[0]) & (cx < rect[1]) & (cy > rect[2]) & (cy < rect[3])
+    assert over.mean() > 0.99 and (sa[0][over, nl + 2] > 0.5).all()      # no cube centre below the table top while over it
     for e in (a, b, c):
         e.k_close()
 
@@ -777,3 +785,32 @@ def test_forearm_cylinder_section_on_the_cube(env):
     o0 = Oracle(cm0, 1, seed=0); o0.reset(); o0.set_state(qpos, qvel, ctrl, warm, step)
     o0.step(act)
     assert (int(o0.get_diag()[0][0]) & 0xFFF00) == 0
+
+
+def test_table_rectangle_gpu():
+    """The finite table top (kmanip.h table_rect; oracle side: test_the_table_is_a_rectangle): a cube on the table, one straddling its
+    edge and one beside it, stepped on the device and in the oracle -- contact masks bit for bit every step, states within the parity
+    bars; the cube beside the table falls."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from oracle.oracle import Oracle
+    from test_oracle_dynamics import table_edge_states
+    cm = compile_model("KManipSoloArmQPos", auto_reset=False)
+    nl = cm.nlink
+    orc = Oracle(cm, 3, seed=0); orc.reset()
+    st = table_edge_states(cm, orc)
+    orc.set_state(*st)
+    dev = env_hip.KManipEnvHip(cm, num_envs=3, seed=0); dev.k_reset()
+    dev.set_state(qpos=st[0], qvel=st[1], ctrl=st[2], warm=st[3], step=st[4])
+    act = np.zeros((3, cm.act_dim), dtype=np.float32)
+    seen = set()
+    for k in range(30):
+        dev.step_flat(torch.from_numpy(act).cuda()); orc.step(act)
+        mg, mo = dev.get_diag()[0], orc.get_diag()[0]
+        assert (mg == mo).all(), (k, [hex(int(x)) for x in mg], [hex(int(x)) for x in mo])
+        seen.add(tuple(bin(int(x) & 0xFF).count("1") for x in mg))
+        sg, so = dev.get_state(), orc.get_state()
+        assert np.abs(sg[0] - so[0]).max() < TOL_Q and np.abs(sg[1] - so[1]).max() < TOL_V, k
+    assert (4, 2, 0) in seen
+    assert dev.get_state()[0][2, nl + 2] < cm.desc.table_z - 0.5
+    dev.k_close()

@@ -320,7 +320,49 @@ def test_cube_free_fall_and_rest():
     assert straight.sum() >= 2                                             # it fell straight down (a spawn may brush the home-pose gripper)
 
 
-FOREARM_DOWN = [-1.003, 1.609, 2.408, 0.15, -0.821, 0.563, 0.223, 2.946, -0.002, -0.005]   # only the forearm sphere is below the table (5 mm)
+def table_edge_states(cm, orc):
+    """Three cube placements around the table's +x edge (x_hi = 0.4, kmanip.h table_rect), the arm at home: 0 well on the table,
+    1 straddling the edge (centre 5 mm inside: the two corners at x = centre + 2 cm hang over), 2 beside the table."""
+    nl = cm.nlink
+    qpos, qvel, ctrl, warm, step = orc.get_state()
+    x_hi = cm.desc.table_rect[1]
+    for e, x in enumerate((x_hi - 0.10, x_hi - 0.005, x_hi + 0.05)):
+        qpos[e, nl:nl + 3] = [x, 0.7, cm.desc.table_z + cm.desc.cube_half[2] - 2e-4]
+        qpos[e, nl + 3:] = [1, 0, 0, 0]
+    qvel[:, nl:] = 0
+    return qpos, qvel, ctrl, warm, step
+
+
+def test_the_table_is_a_rectangle():
+    """The table top is the 0.8 m x 0.4 m rectangle the reference's own primitive stand-in for tabletop.stl has
+    (examples/4_teleop.py:82-84; x -0.4..0.4, y 0.4..0.8 around the table body, scene.xml:14), not an infinite plane: every cube spawn
+    (__init__.py:164-170) lies on it; a cube on it rests with its four lower corners in the mask; a cube straddling the edge is held
+    by the two corners that are over the table (and stays: the tipping moment m g h = 0.05 * 9.81 * 0.02 = 9.8e-3 N m is just under the
+    free joint's friction loss of 0.01, scene.xml:17); a cube beside the table has no table contact and falls."""
+    from gym_kmanip_amd.model import CUBE_SPAWN_RANGE
+    cm = compile_model("KManipSoloArmQPos", auto_reset=False)
+    d = cm.desc
+    assert (d.table_rect[0], d.table_rect[1]) == (-0.4, 0.4) and abs(d.table_rect[2] - 0.4) < 1e-12 and d.table_rect[3] == 0.8
+    h = d.cube_half[0]
+    assert d.table_rect[0] + h < CUBE_SPAWN_RANGE[0, 0] and CUBE_SPAWN_RANGE[0, 1] < d.table_rect[1] - h
+    assert d.table_rect[2] + h < CUBE_SPAWN_RANGE[1, 0] and CUBE_SPAWN_RANGE[1, 1] < d.table_rect[3] - h
+    nl = cm.nlink
+    orc = Oracle(cm, 3, seed=0); orc.reset()
+    orc.set_state(*table_edge_states(cm, orc))
+    act = np.zeros((3, cm.act_dim), dtype=np.float32)
+    orc.step(act)
+    mask = orc.get_diag()[0] & 0xFF
+    assert bin(int(mask[0])).count("1") == 4 and int(mask[2]) == 0
+    assert bin(int(mask[1])).count("1") == 2 and all(not (int(mask[1]) >> c) & 1 for c in range(8) if c & 1)   # the -x corners (bit 0 of the corner index clear)
+    for _ in range(40):
+        orc.step(act)
+    qpos = orc.get_state()[0]
+    assert abs(qpos[0, nl + 2] - (d.table_z + d.cube_half[2])) < 1e-3                  # resting
+    assert qpos[2, nl + 2] < d.table_z - 1.0                                            # fell past the table top (nothing below it)
+    assert abs(qpos[1, nl + 2] - (d.table_z + d.cube_half[2])) < 1e-3 and bin(int(orc.get_diag()[0][1]) & 0xFF).count("1") == 2   # held by two corners
+
+
+FOREARM_DOWN = [-0.726, 1.7465, 2.948, -0.096, -1.21, 0.892, 0.287, 3.092, -0.002, -0.005]   # only the forearm sphere is below the table top (5 mm), at x 0.13, y 0.46: inside its rectangle
 
 
 def forearm_on_table(cm, nsphere, make):

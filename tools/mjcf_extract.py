@@ -124,6 +124,10 @@ FINGER_OPEN_OFFSET = 0.035  # finger centre sits this far (along +slide axis) fr
 PALM_RADIUS = 0.030         # link colliders (see build()): the palm sphere; the joint-housing spheres use LINK_RADIUS -- the
                             # reference's link meshes all collide with table and cube (contype = conaffinity = 1)
 TABLE_TOP_Z = 0.5           # table body origin z (scene.xml:14); surrogate = plane z = 0.5
+# The table top's extent: the reference's own stand-in for tabletop.stl (examples/4_teleop.py:82-84, a 0.4 x 0.8 plane primitive at the
+# table body's position).  The long side lies along x: the cube spawns at x in [0.1, 0.3], y in [0.5, 0.7] (__init__.py:164-170) and
+# the table body sits at x = 0, y = 0.6, so only 0.8 along x puts every spawn on the table.
+TABLE_SIZE_XY = (0.8, 0.4)
 
 
 def link_mass(joint_name):
@@ -295,8 +299,8 @@ def build(env_xml, name):
     # ---- surrogate link colliders, after the fingers (sphere order = priority for the solver's contact slots, so the
     # distal ones come first): per hand link H (the parent of a pair of finger sliders) the palm, half way between H's
     # origin and the EE site, then the joint housings at the origins of H and of its two ancestors (wrist, forearm,
-    # elbow).  Links nearer the shoulder stay collider-free: the surrogate table is an infinite plane at the table-top
-    # height and the arms are mounted at (solo / dual) or next to (torso) that height.  Collision only (visible = 0):
+    # elbow).  Links nearer the shoulder stay collider-free: the arms are mounted at (solo / dual) or next to (torso) the
+    # table top's height and those links could only meet the table at its edge.  Collision only (visible = 0):
     # the wrist cameras sit inside / behind these spheres, where the reference's camera sees past its gripper mesh.
     for s in spheres:
         s["visible"] = 1
@@ -339,7 +343,9 @@ def build(env_xml, name):
         "targets": targets,
         "cameras": cameras,
         "cube": cube,
-        "table": {"pos": table["pos"], "plane_z": TABLE_TOP_Z},
+        "table": {"pos": table["pos"], "plane_z": TABLE_TOP_Z,
+                  "rect": [table["pos"][0] - 0.5 * TABLE_SIZE_XY[0], table["pos"][0] + 0.5 * TABLE_SIZE_XY[0],
+                           table["pos"][1] - 0.5 * TABLE_SIZE_XY[1], table["pos"][1] + 0.5 * TABLE_SIZE_XY[1]]},
         "spheres": spheres,
         "option": {"timestep": 0.002, "gravity": [0, 0, -9.81]},
         "surrogate_note": "link inertials, finger / link spheres and the table plane are build-owned "
