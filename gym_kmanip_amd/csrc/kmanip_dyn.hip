@@ -851,9 +851,10 @@ __device__ __forceinline__ void make_frame(real* fr) {
 // table -> slots 0..3 in corner order), sphere-box (slots 4.., the first NSS penetrating spheres), plane-sphere (slots 4 + NSS..).
 // One candidate per lane: lanes 0..7 test the cube corners (slot = rank among the penetrating corners, from the
 // group's ballot bits), lanes 8..8+NSPH-1 their collision sphere against cube and table.
-// the table top is a rectangle (kmanip.h table_rect): a point is over it while its x, y lie inside
-__device__ __forceinline__ bool over_table(const KModelDesc* m, const real* p) {
-  return p[0] >= m->table_rect[0] && p[0] <= m->table_rect[1] && p[1] >= m->table_rect[2] && p[1] <= m->table_rect[3];
+// the table top is a rectangle (kmanip.h table_rect): a point is over it while its x, y lie inside.  tr = the four bounds, fetched
+// ONCE by the caller (one scalar load); `&` not `&&`: four compares, no branch per bound
+__device__ __forceinline__ bool over_table(const real (&tr)[4], const real* p) {
+  return (p[0] >= tr[0]) & (p[0] <= tr[1]) & (p[1] >= tr[2]) & (p[1] <= tr[3]);
 }
 
 template <int NL, int G>
@@ -862,6 +863,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
   static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
   const real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
+  const real tr[4] = {m->table_rect[0], m->table_rect[1], m->table_rect[2], m->table_rect[3]};
   bool below = false;
   real c[3] = {0, 0, 0}, dist = 0;
   if (sub < 8) {
@@ -869,7 +871,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     mat_vec3(c, w.k.cube_mat, loc);
     c[0] += cp[0]; c[1] += cp[1]; c[2] += cp[2];
     dist = c[2] - m->table_z;
-    below = dist < 0 && over_table(m, c);
+    below = (dist < 0) & over_table(tr, c);
   }
   const unsigned long long bal = __ballot(below);
   const uint32_t m8 = (uint32_t)(bal >> ((threadIdx.x & 63) - sub)) & 0xFFu;
@@ -897,7 +899,7 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     rad = m->sphere_radius[s];
     // table plane (geom1) - sphere (geom2): the end sphere itself (a capsule meets a plane in its end spheres)
     d2 = ctr[2] - m->table_z - rad;
-    hitt = d2 < 0 && over_table(m, ctr);
+    hitt = (d2 < 0) & over_table(tr, ctr);
     ctrt[0] = ctr[0]; ctrt[1] = ctr[1]; ctrt[2] = ctr[2];
     // capsule section (kmanip.h sphere_seg): against the cube the collider is the point of the link's segment closest to the
     // cube centre -- a sphere sliding along the link

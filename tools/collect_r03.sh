@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: every measurement profiles/r03_* is made from, into gpurun_out/r03/.
-# Usage: bash tools/collect_r03.sh [part ...]   parts: main sq phase slow configs short soak misc (default: all)
+# Usage: bash tools/collect_r03.sh [part ...]   parts: main sq final phase slow configs short soak misc (default: all)
 set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/r03
 mkdir -p $OUT
-PARTS=${@:-main sq phase slow configs short soak misc}
+PARTS=${@:-main sq final phase slow configs short soak misc}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 stats() {  # <dir> <prefix>: copy the kernel-stats CSV of a rocprofv3 --kernel-trace --stats run
   f=$(find $1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/$2
@@ -18,6 +18,12 @@ if has main; then
 fi
 if has sq; then
   bash tools/collect_sq.sh r03 > $OUT/collect_sq.log 2>&1; cp gpurun_out/sq_r03/sq.json $OUT/sq_counters.json; echo "sq done"
+fi
+if has final; then
+  # the default bench line once more, now that the counter files of THIS library version exist (bench.py reads roofline.traffic /
+  # roofline.valu from profiles/r03_pmc_hbm.json / r03_sq_counters.json and refuses files of another version)
+  cp $OUT/pmc_hbm.json profiles/r03_pmc_hbm.json; cp $OUT/sq_counters.json profiles/r03_sq_counters.json
+  python3 bench.py > $OUT/bench.json 2> $OUT/bench_final.err; echo "final done"
 fi
 if has phase; then
   L=gym_kmanip_amd/libkmanip_hip_prof.so

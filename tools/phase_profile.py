@@ -17,7 +17,13 @@ names += ["newton: waiting for wave-mates in a loop this env does not run (diver
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 env_id = sys.argv[2] if len(sys.argv) > 2 else "KManipSoloArm"          # 20-link ids: totals only (no per-workgroup view)
 n = 4096
-env = env_hip.make(env_id, num_envs=n, seed=0, solver=solver)
+if os.environ.get("KM_PHASE_INFINITE_TABLE"):        # A/B: the round-2 infinite table plane (what does the rectangle change in this scenario?)
+    from gym_kmanip_amd.model import compile_model, ENV_SPECS
+    _cm = compile_model(ENV_SPECS[env_id], solver=solver)
+    _cm.desc.table_rect[0] = -np.inf; _cm.desc.table_rect[1] = np.inf; _cm.desc.table_rect[2] = -np.inf; _cm.desc.table_rect[3] = np.inf
+    env = env_hip.KManipEnvHip(_cm, num_envs=n, seed=0)
+else:
+    env = env_hip.make(env_id, num_envs=n, seed=0, solver=solver)
 import numpy as _np
 env.k_reset(); env.set_state(step=(_np.arange(n) % 64).astype(_np.int32))   # desynchronised episode phases (as bench.py)
 L = env.L
