@@ -495,7 +495,8 @@ def run_rank(args):
                          "traffic": cc["traffic"], "traffic_source": cc["traffic_source"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_env_step": bpe,
-                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launch_gap": ik_ms / max(nt, 1), "launches_timed": nt},
+                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launch_gap": max(dt / args.steps * 1e3 - (dyn_ms + rnd_ms + ik_ms) / max(nt, 1), 0.0),   # ms per step outside the timed kernels: launch overhead + the two event records
+                                           "launches_timed": nt},
                          "valu": valu,
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }

@@ -244,13 +244,15 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   hipStream_t s = (hipStream_t)stream;
   const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
   hipEvent_t* ev = tm ? &h->ev[4 * (size_t)h->timed_steps] : nullptr;
-  if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
   // product path: ONE launch, before_step (decode + IK) fused into k_step so that no device-wide barrier sits between
   // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1)
   const bool split = h->ik_unfused;
   if (split && nchunk != 1) { h->err = "kmanip_step_chunk needs the fused path (unset KMANIP_IK_UNFUSED)"; return -1; }
-  if (h->ik_unfused) kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
-  if (tm) HIPCHK(h, hipEventRecord(ev[1], s));
+  if (split) {
+    if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
+    kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
+  }
+  if (tm) HIPCHK(h, hipEventRecord(ev[1], s));        // (fused path: two events per step, each costs the stream a barrier packet)
   kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);
   if (tm) HIPCHK(h, hipEventRecord(ev[2], s));
   const bool render = h->step_depth && nchunk == 1;
@@ -340,7 +342,7 @@ int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, doub
   double a = 0, b = 0, c = 0;
   for (int k = 0; k < h->timed_steps; k++) {
     float m1 = 0, m2 = 0, m3 = 0;
-    HIPCHK(h, hipEventElapsedTime(&m1, h->ev[4 * k], h->ev[4 * k + 1]));
+    if (h->ik_unfused) HIPCHK(h, hipEventElapsedTime(&m1, h->ev[4 * k], h->ev[4 * k + 1]));
     HIPCHK(h, hipEventElapsedTime(&m2, h->ev[4 * k + 1], h->ev[4 * k + 2]));
     if (h->ev_render[k]) HIPCHK(h, hipEventElapsedTime(&m3, h->ev[4 * k + 2], h->ev[4 * k + 3]));
     a += m1; b += m2; c += m3;
