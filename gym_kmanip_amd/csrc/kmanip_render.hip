@@ -234,16 +234,12 @@ __device__ __forceinline__ bool rgb_project(const RenderScene& sc, const real* P
   row = -dot3(pc, sc.cam_y) * s + 0.5 * height - 0.5;
   return true;
 }
-__device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene& sc, int height, int width, RgbScene* g) {
-  for (int c = 0; c < 3; c++) { g->o[c] = (float)sc.cam_o[c]; g->X[c] = (float)sc.cam_x[c]; g->Y[c] = (float)sc.cam_y[c]; g->Z[c] = (float)sc.cam_z[c]; }
-  g->inv_f = (float)(1.0 / sc.focal); g->tz = (float)m->table_z; g->zfar = (float)m->cam_zfar;
-  real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]}, t[3];
-  matT_vec3(t, sc.cube_R, rel); for (int c = 0; c < 3; c++) g->ol[c] = (float)t[c];
-  matT_vec3(t, sc.cube_R, sc.cam_x); for (int c = 0; c < 3; c++) g->DX[c] = (float)t[c];
-  matT_vec3(t, sc.cube_R, sc.cam_y); for (int c = 0; c < 3; c++) g->DY[c] = (float)t[c];
-  matT_vec3(t, sc.cube_R, sc.cam_z); for (int c = 0; c < 3; c++) g->DZ[c] = (float)t[c];
-  for (int c = 0; c < 3; c++) g->half[c] = (float)m->cube_half[c];
-  for (int c = 0; c < 9; c++) g->R[c] = (float)sc.cube_R[c];
+// The per-env set-up of the pixel loop, spread over the first 17 lanes of the workgroup (one lane did all of it in ~22 us, a tenth of
+// a 2048-image launch at two residency rounds): lanes 0-7 project one cube corner each, lanes 8-11 one visible sphere each (its ray
+// constants and rectangle), lanes 12-15 one table edge each, lane 16 the camera / cube-frame scalars; lane 0 then folds the corners
+// into the cube's rectangle and the rectangles into their union.
+struct RgbTmp { real row[8], col[8]; int ok[8]; };
+__device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene& sc, int height, int width, RgbScene* g, RgbTmp* tmp, int t) {
   // bounding rectangles, one per object (an object that is not safely in front of the camera gets the whole image): the cube's
   // eight corners; a sphere's centre +- a conservative projected radius
   auto put = [&](int o, bool ok, real r0, real r1, real c0, real c1) {
@@ -251,58 +247,77 @@ __device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene
     g->box[o][0] = (int)fmax(floor(r0) - 1, -1.0); g->box[o][1] = (int)fmin(ceil(r1) + 1, (real)height);
     g->box[o][2] = (int)fmax(floor(c0) - 1, -1.0); g->box[o][3] = (int)fmin(ceil(c1) + 1, (real)width);
   };
-  {
-    real r0 = 1e30, r1 = -1e30, c0 = 1e30, c1 = -1e30;
-    bool ok = true;
-    for (int k = 0; k < 8 && ok; k++) {
-      const real loc[3] = {(k & 1 ? 1 : -1) * m->cube_half[0], (k & 2 ? 1 : -1) * m->cube_half[1], (k & 4 ? 1 : -1) * m->cube_half[2]};
-      real P[3], row, col;
-      mat_vec3(P, sc.cube_R, loc);
-      P[0] += sc.cube_p[0]; P[1] += sc.cube_p[1]; P[2] += sc.cube_p[2];
-      ok = rgb_project(sc, P, height, width, row, col);
-      if (ok) { r0 = fmin(r0, row); r1 = fmax(r1, row); c0 = fmin(c0, col); c1 = fmax(c1, col); }
+  if (t < 8) {
+    const real loc[3] = {(t & 1 ? 1 : -1) * m->cube_half[0], (t & 2 ? 1 : -1) * m->cube_half[1], (t & 4 ? 1 : -1) * m->cube_half[2]};
+    real P[3], row = 0, col = 0;
+    mat_vec3(P, sc.cube_R, loc);
+    P[0] += sc.cube_p[0]; P[1] += sc.cube_p[1]; P[2] += sc.cube_p[2];
+    tmp->ok[t] = rgb_project(sc, P, height, width, row, col);
+    tmp->row[t] = row; tmp->col[t] = col;
+  } else if (t < 8 + KM_RGB_MAXSPH) {
+    // the (t - 8)-th visible sphere (kmanip_create refuses models with more than KM_RGB_MAXSPH of them)
+    int s = -1, seen = 0;
+    for (int k = 0; k < m->nsphere; k++)
+      if (m->sphere_visible[k]) { if (seen == t - 8) s = k; seen++; }
+    if (s >= 0) {
+      const int ns = t - 8;
+      const real rad = m->sphere_radius[s];
+      const real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
+      for (int c = 0; c < 3; c++) g->oc[ns][c] = (float)oc[c];
+      g->cc[ns] = (float)(dot3(oc, oc) - rad * rad); g->ir[ns] = (float)(1.0 / rad);
+      real row = 0, col = 0;
+      const real zc = dot3(oc, sc.cam_z);                                  // depth of the centre along the optical axis
+      const bool ok = rgb_project(sc, sc.sph[s], height, width, row, col) && zc - rad > 1e-3;
+      const real pr = ok ? 1.5 * sc.focal * rad / (zc - rad) + 1.0 : 0.0;  // (off-axis spheres project to ellipses: generous)
+      put(1 + ns, ok, row - pr, row + pr, col - pr, col + pr);
     }
-    put(0, ok, r0, r1, c0, c1);
-  }
-  int ns = 0;
-  for (int s = 0; s < m->nsphere; s++) {
-    if (!m->sphere_visible[s] || ns == KM_RGB_MAXSPH) continue;      // (kmanip_create refuses models with more visible spheres)
-    const real rad = m->sphere_radius[s];
-    const real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
-    for (int c = 0; c < 3; c++) g->oc[ns][c] = (float)oc[c];
-    g->cc[ns] = (float)(dot3(oc, oc) - rad * rad); g->ir[ns] = (float)(1.0 / rad);
-    real row = 0, col = 0;
-    const real zc = dot3(oc, sc.cam_z);                                  // depth of the centre along the optical axis
-    const bool ok = rgb_project(sc, sc.sph[s], height, width, row, col) && zc - rad > 1e-3;
-    const real pr = ok ? 1.5 * sc.focal * rad / (zc - rad) + 1.0 : 0.0;  // (off-axis spheres project to ellipses: generous)
-    put(1 + ns, ok, row - pr, row + pr, col - pr, col + pr);
-    ns++;
-  }
-  g->nsph = ns;
-  for (int k = 0; k < 4; k++) {
-    int u = g->box[0][k];
-    for (int o = 1; o <= ns; o++) u = (k & 1) ? max(u, g->box[o][k]) : min(u, g->box[o][k]);
-    g->ubox[k] = u;
-  }
-  {
+  } else if (t < 16) {
+    const int i = t - 12;
     const real* tr = m->table_rect;
     if (isfinite(tr[0]) && isfinite(tr[1]) && isfinite(tr[2]) && isfinite(tr[3])) {
-      const real P[4][2] = {{tr[0], tr[2]}, {tr[1], tr[2]}, {tr[1], tr[3]}, {tr[0], tr[3]}};
-      real V[4][3], Vc[3] = {0.5 * (tr[0] + tr[1]) - sc.cam_o[0], 0.5 * (tr[2] + tr[3]) - sc.cam_o[1], m->table_z - sc.cam_o[2]};
-      for (int i = 0; i < 4; i++) { V[i][0] = P[i][0] - sc.cam_o[0]; V[i][1] = P[i][1] - sc.cam_o[1]; V[i][2] = m->table_z - sc.cam_o[2]; }
-      for (int i = 0; i < 4; i++) {
-        real n[3];
-        cross3(n, V[i], V[(i + 1) & 3]);
-        const real sgn = dot3(n, Vc) < 0 ? -1.0 : 1.0;
-        const real a = sgn * dot3(n, sc.cam_x), b = sgn * dot3(n, sc.cam_y), c = -sgn * dot3(n, sc.cam_z);
-        g->te_a[i] = (float)a; g->te_b[i] = (float)b; g->te_c[i] = (float)c;
-        g->te_i[i] = g->te_a[i] != 0.0f ? -1.0f / g->te_a[i] : 0.0f;
-      }
-    } else {
-      for (int i = 0; i < 4; i++) { g->te_a[i] = 0; g->te_b[i] = 0; g->te_c[i] = 1; g->te_i[i] = 0; }   // the infinite plane: always inside
+      // corner i and its successor, counter-clockwise from (x_lo, y_lo)
+      const real ax = (i == 0 || i == 3) ? tr[0] : tr[1], ay = i < 2 ? tr[2] : tr[3];
+      const real bx = (i == 3 || i == 2) ? tr[0] : tr[1], by = (i == 0 || i == 3) ? tr[2] : tr[3];
+      const real dz = m->table_z - sc.cam_o[2];
+      const real Va[3] = {ax - sc.cam_o[0], ay - sc.cam_o[1], dz}, Vb[3] = {bx - sc.cam_o[0], by - sc.cam_o[1], dz};
+      const real Vc[3] = {0.5 * (tr[0] + tr[1]) - sc.cam_o[0], 0.5 * (tr[2] + tr[3]) - sc.cam_o[1], dz};
+      real n[3];
+      cross3(n, Va, Vb);
+      const real sgn = dot3(n, Vc) < 0 ? -1.0 : 1.0;
+      const real a = sgn * dot3(n, sc.cam_x), b = sgn * dot3(n, sc.cam_y), c = -sgn * dot3(n, sc.cam_z);
+      g->te_a[i] = (float)a; g->te_b[i] = (float)b; g->te_c[i] = (float)c;
+      g->te_i[i] = g->te_a[i] != 0.0f ? -1.0f / g->te_a[i] : 0.0f;
+    } else { g->te_a[i] = 0; g->te_b[i] = 0; g->te_c[i] = 1; g->te_i[i] = 0; }   // the infinite plane: always inside
+  } else if (t == 16) {
+    for (int c = 0; c < 3; c++) { g->o[c] = (float)sc.cam_o[c]; g->X[c] = (float)sc.cam_x[c]; g->Y[c] = (float)sc.cam_y[c]; g->Z[c] = (float)sc.cam_z[c]; }
+    g->inv_f = (float)(1.0 / sc.focal); g->tz = (float)m->table_z; g->zfar = (float)m->cam_zfar;
+    real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]}, v[3];
+    matT_vec3(v, sc.cube_R, rel); for (int c = 0; c < 3; c++) g->ol[c] = (float)v[c];
+    matT_vec3(v, sc.cube_R, sc.cam_x); for (int c = 0; c < 3; c++) g->DX[c] = (float)v[c];
+    matT_vec3(v, sc.cube_R, sc.cam_y); for (int c = 0; c < 3; c++) g->DY[c] = (float)v[c];
+    matT_vec3(v, sc.cube_R, sc.cam_z); for (int c = 0; c < 3; c++) g->DZ[c] = (float)v[c];
+    for (int c = 0; c < 3; c++) g->half[c] = (float)m->cube_half[c];
+    for (int c = 0; c < 9; c++) g->R[c] = (float)sc.cube_R[c];
+    int ns = 0;
+    for (int k = 0; k < m->nsphere; k++) ns += m->sphere_visible[k] ? 1 : 0;
+    g->nsph = ns < KM_RGB_MAXSPH ? ns : KM_RGB_MAXSPH;
+    g->tab_L = 0.3f * (0.57735026919f + 0.57735026919f + 0.70710678119f);    // sum_l max(0, L_l . (0,0,1)), scene.xml:11-13
+  }
+  __syncthreads();
+  if (t == 0) {
+    real r0 = 1e30, r1 = -1e30, c0 = 1e30, c1 = -1e30;
+    bool ok = true;
+    for (int k = 0; k < 8; k++) {
+      ok = ok && tmp->ok[k];
+      r0 = fmin(r0, tmp->row[k]); r1 = fmax(r1, tmp->row[k]); c0 = fmin(c0, tmp->col[k]); c1 = fmax(c1, tmp->col[k]);
+    }
+    put(0, ok, r0, r1, c0, c1);
+    for (int k = 0; k < 4; k++) {
+      int u = g->box[0][k];
+      for (int o = 1; o <= g->nsph; o++) u = (k & 1) ? max(u, g->box[o][k]) : min(u, g->box[o][k]);
+      g->ubox[k] = u;
     }
   }
-  g->tab_L = 0.3f * (0.57735026919f + 0.57735026919f + 0.70710678119f);    // sum_l max(0, L_l . (0,0,1)), scene.xml:11-13
 }
 // one pixel, float32: grey level * 255 of the three channels packed r | g << 8 | b << 16
 // does the ray direction (dx, dy) pass through the table top?
@@ -391,10 +406,13 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
                                                     uint8_t* __restrict__ rgb) {
   __shared__ RenderScene sc;
   __shared__ RgbScene g;
+  __shared__ RgbTmp tmp;
   const KModelDesc* m = &dm->d;
   const int env = blockIdx.x;
   render_fk(dm, st, env, &sc);
-  if (threadIdx.x == 0) { render_camera(dm, st, env, cam, height, &sc); rgb_scene(m, sc, height, width, &g); }
+  if (threadIdx.x == 0) render_camera(dm, st, env, cam, height, &sc);
+  __syncthreads();
+  rgb_scene(m, sc, height, width, &g, &tmp, threadIdx.x);
   __syncthreads();
   const int npix = height * width;
   const float hw = 0.5f * width, hh = 0.5f * height, inv_f = g.inv_f;
