@@ -2322,7 +2322,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   Prof pf;
   pf.start();
   const bool fused = act != nullptr;
-#ifdef KM_DEBUG_NANFILL
+#ifdef KM_DEBUG_NANFILL   // diagnostic build (-DKM_DEBUG_NANFILL=<value>): poison the workspace, so that a read of LDS this launch did not write shows
   { double* wp = reinterpret_cast<double*>(&w); for (int i = sub; i < (int)(sizeof(Ws<NL>) / 8); i += G) wp[i] = KM_DEBUG_NANFILL; GSYNC(); }
 #endif
   init_ws<NL>(w, sub);
