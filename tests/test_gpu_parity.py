@@ -671,6 +671,9 @@ def test_raw_step_rejects_malformed_tensors():
     with pytest.raises(KManipError):
         e.step_chunk(torch.zeros((3, 8, 7), dtype=torch.float32, device="cuda"), obs=torch.zeros((3, 8, 27), dtype=torch.float32, device="cuda"))
     e.k_close()
+    for n in (0, -3):                                            # an empty / negative batch is refused at create
+        with pytest.raises(KManipError):
+            env_hip.make("KManipSoloArm", num_envs=n)
 
 
 def test_checkpoint_restores_the_spawn_stream():
