@@ -1824,33 +1824,46 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
 }
 
 // Newton iterations on one dof subset, from the point (a, Mr, grad, qf, ql, u, W) with cost `cost` (all of the subset).
-// JOINT (S = KM_SUB_ALL only): the wave holds at least one coupled env.  Its uncoupled wave-mates would otherwise run their cube
-// loops AFTER the coupled env's 16-dof loop (different code paths: SIMD divergence serialises them -- 0.13-0.34 M clocks on top of
-// the slowest waves of a launch); here they run their CUBE problem inside the same instruction stream instead, as a 16-dof problem
-// whose arm dofs are inert (identity rows, zero gradient, no arm slots: `cube_only`), each env with its own iteration count.  The
-// inert pivots and the zero entries they meet change nothing in the cube block's arithmetic: an env's result does not depend on
-// what its wave-mates are (tests compare shards and launch shapes bit for bit).
+// JOINT (S = KM_SUB_ALL only): the wave holds at least one coupled env.  Its uncoupled wave-mates would otherwise run their arm
+// loops BEFORE and their cube loops AFTER the coupled env's 16-dof loop (different code paths: SIMD divergence serialises them --
+// 0.1-0.2 M and 0.13-0.34 M clocks on top of the slowest waves of a launch); here every group runs ITS problems inside one
+// instruction stream: the coupled env its whole problem, an uncoupled env (`two`) first its arm problem (cost `cost`), then its
+// cube problem (`cost_b`), each as a 16-dof problem whose other dofs are inert (identity rows, zero gradient, no slots), with its
+// own iteration counts; the arm problem's Woodbury direction is the one part that stays a branch of its own.  The inert pivots and
+// the zero entries they meet change nothing in a block's arithmetic: an env's result does not depend on what its wave-mates
+// are (tests compare shards and launch shapes bit for bit).
 template <int NL, int G, int S, bool JOINT = false>
 __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, const CReg<NL>& cr,
                                                real mdiag, real a_s, real& a, real& Mr, real cost, real& grad, int& qf, int& ql,
-                                               real (&u)[4], real (&W)[7], Prof& pf, bool cube_only = false) {
-  static_assert(!JOINT || S == KM_SUB_ALL, "the joint loop is the whole-problem loop");
-  constexpr int NV = Dim<NL>::NV;
+                                               real (&u)[4], real (&W)[7], Prof& pf, bool two = false, real cost_b = 0) {
+  static_assert(!JOINT || (S == KM_SUB_ALL && G == 16), "the joint loop is the whole-problem loop of the one-row groups");
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC, NSS = Dim<NL>::NSS;
   using SS = SubSet<NL, S>;
-  const uint32_t act = (JOINT && cube_only) ? (w.cact & 0xFu) : w.cact;
   const SlotC& sc = cr.sc;
-  const bool in = (JOINT && cube_only) ? (sub >= NL && sub < NV) : (sub >= SS::D0 && sub < SS::D1);
-  // this lane's slot belongs to the problem (its cost counts, its u moves)
-  const bool slin = (JOINT && cube_only) ? sub < 4 : slot_lane_in<NL, S>(sub);
+  // the problem this group is on (JOINT: run-time and per group), its slots, its dofs, the slot lanes that belong to it (their
+  // cost counts, their u moves)
+  int prob = (JOINT && two) ? (int)KM_SUB_ARM : S;
+  uint32_t act = w.cact;
+  bool in = sub >= SS::D0 && sub < SS::D1, slin = slot_lane_in<NL, S>(sub);
+  auto enter = [&](int pr) {
+    constexpr uint32_t ARM_SLOTS = ((1u << NC) - 1u) & ~((1u << (4 + NSS)) - 1u);
+    prob = pr;
+    act = pr == KM_SUB_ARM ? (w.cact & ARM_SLOTS) : (w.cact & 0xFu);
+    in = pr == KM_SUB_ARM ? sub < NL : (sub >= NL && sub < NV);
+    slin = pr == KM_SUB_ARM ? (sub >= 4 + NSS && sub < NC) : sub < 4;
+  };
+  if (JOINT && two) enter(KM_SUB_ARM);
   const real scale = lm.scale;
   const real tol = m->solver_tolerance;
   const int maxit = m->solver_iterations;
   pf.ph(40);       // (what a group waited for wave-mates that ran a loop it does not -- SIMD divergence -- lands here)
-  {
-    const real g0 = in ? grad : 0.0;
-    if (km_sqrt(gsum<G>(g0 * g0)) * scale < tol) return;
+  auto small = [&]() { const real g0 = in ? grad : 0.0; return km_sqrt(gsum<G>(g0 * g0)) * scale < tol; };
+  if (small()) {
+    if (!(JOINT && prob == KM_SUB_ARM)) return;
+    enter(KM_SUB_CUBE); cost = cost_b;
+    if (small()) return;
   }
-  for (int iter = 0; iter < maxit; iter++) {
+  for (int iter = 0; ; iter++) {
     real p = 0;
     // The arm problem's quadratic rows are usually just single-dof rows (the two slider friction-loss rows; now and then a
     // joint at its limit) -- no sphere on the table.  Its Hessian is then M + diag(delta) with at most two nonzero deltas, and
@@ -1859,7 +1872,7 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
     // factorisation and two triangular solves.
     bool plain = false;
     uint32_t rows = 0;
-    if constexpr (S == KM_SUB_ARM) {
+    if (S == KM_SUB_ARM || (JOINT && prob == KM_SUB_ARM)) {
       const unsigned long long bq = __ballot(slin && W[0] != 0);              // a sphere-table slot with edges in their quadratic zone
       const unsigned long long bal = __ballot(in && (qf | ql));
       const int sh = (threadIdx.x & 63) - sub;
@@ -2019,7 +2032,12 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
     const real improvement = scale * (cost - cost_new), gradient = scale * km_sqrt(gsum<G>(g1 * g1));
     cost = cost_new;
     pf.ph(14 + 6 * S);
-    if (improvement < tol || gradient < tol || w.bad) break;
+    if (improvement < tol || gradient < tol || w.bad || iter + 1 >= maxit) {
+      if (!(JOINT && prob == KM_SUB_ARM)) break;
+      enter(KM_SUB_CUBE); cost = cost_b;        // an uncoupled env of the joint loop: on to its cube problem
+      if (small()) break;
+      iter = -1;
+    }
   }
 }
 
@@ -2048,17 +2066,18 @@ __device__ __forceinline__ real solve_newton_sl(Ws<NL>& w, const LModel<NL>& lm,
   }
   constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
   const bool coupled = (act & FC_MASK) != 0;                               // (group-uniform)
-  if (!coupled) newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, u, W, pf);
   if constexpr (G == 16) {
     if (__any(coupled)) {
-      // a coupled env in the wave: its whole-problem loop and the wave-mates' cube loops share one instruction stream
-      newton_loop_sl<NL, G, KM_SUB_ALL, true>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, coupled ? cost0 + cost1 : cost1, grad, qf, ql, u, W, pf, !coupled);
+      // a coupled env in the wave: its whole-problem loop and the wave-mates' arm and cube loops share one instruction stream
+      newton_loop_sl<NL, G, KM_SUB_ALL, true>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, coupled ? cost0 + cost1 : cost0, grad, qf, ql, u, W, pf, !coupled, cost1);
     } else {
+      newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, u, W, pf);
       newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, u, W, pf);
     }
   } else {
     // two-row groups keep the separate loops: their cube block runs the one-row code in the second DPP row while the whole
     // problem runs the two-row code -- different operation order, so a joint loop would make an env's bits depend on its wave-mates
+    if (!coupled) newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, u, W, pf);
     if (coupled) newton_loop_sl<NL, G, KM_SUB_ALL>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0 + cost1, grad, qf, ql, u, W, pf);
     else newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, u, W, pf);
   }
