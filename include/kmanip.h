@@ -242,11 +242,11 @@ int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes);
 int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status);
 
 /* Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).  While enabled, every kmanip_step
- * records four events (before the step, after the stand-alone decode/IK launches of the KMANIP_IK_UNFUSED=1 A/B path -- the
- * product path has none, so that leg is the gap between two event records --, after k_step, after the bound in-step render)
- * into a ring of `KM_TIMING_SLOTS` steps.  kmanip_timing_summary synchronises the device and returns the summed durations in
- * milliseconds of the three legs (IK / launch gap, k_step, k_render of kmanip_bind_step_depth: 0 when nothing is bound) over
- * the recorded steps, then clears the ring.  Any output pointer may be NULL. */
+ * records an event before and after k_step, one more after the bound in-step render, and -- only on the KMANIP_IK_UNFUSED=1 A/B
+ * path -- one before its stand-alone decode/IK launches (an event record costs the stream about 5 us, so the product path takes
+ * the two it needs), into a ring of `KM_TIMING_SLOTS` steps.  kmanip_timing_summary synchronises the device and returns the
+ * summed durations in milliseconds of the three legs (stand-alone IK: 0 on the product path; k_step; k_render of
+ * kmanip_bind_step_depth: 0 when nothing is bound) over the recorded steps, then clears the ring.  Any output pointer may be NULL. */
 #define KM_TIMING_SLOTS 1024
 int kmanip_enable_timing(KHandle h, int enable);
 int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, double* render_ms_sum, int32_t* nsteps);
