@@ -200,6 +200,33 @@ template <int G> __device__ __forceinline__ real gsum(real v) {
   }
   return v;
 }
+// N group sums at once, step by step: the SAME operations per value as N gsum calls (bitwise the same results), but the chains
+// interleave -- with one wave per SIMD a lone chain waits out every add's latency and the two wait states in front of each DPP read
+template <int G, int N> __device__ __forceinline__ void gsum_n(real (&v)[N]) {
+#pragma clang fp contract(off)
+  static_assert(G == 16 || G == 32, "lane group must be one or two DPP rows");
+  real t[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = dpp_f64<0x140>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = dpp_f64<0x141>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = dpp_f64<0xB1>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = dpp_f64<0x4E>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += t[i];
+  if (G == 32) {
+#pragma unroll
+    for (int i = 0; i < N; i++) { const BSrc<32> r = bsrc<32>(v[i]); v[i] = r.e + r.o; }
+  }
+}
 // OR over the G lanes of a group, every lane receiving it: the same four DPP steps as gsum (round 3; round 2 went through
 // four or five dependent ds_bpermute round trips -- 12 of them per sub-step for the contact masks and the divergence flag)
 template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
@@ -1607,8 +1634,13 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   static_for<4, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if ((act >> c) & 1u) {
+      constexpr int NK = slot_kind<NL>(c) == 2 ? 3 : 4;
+      real pj[NK];
 #pragma unroll
-      for (int k = 0; k < (slot_kind<NL>(c) == 2 ? 3 : 4); k++) { const real v = gsum<G>(cr.jb[c][k] * qv); vb[k] = sub == c ? v : vb[k]; }
+      for (int k = 0; k < NK; k++) pj[k] = cr.jb[c][k] * qv;
+      gsum_n<G, NK>(pj);
+#pragma unroll
+      for (int k = 0; k < NK; k++) vb[k] = sub == c ? pj[k] : vb[k];
       if (slot_kind<NL>(c) == 2) vb[3] = sub == c ? 0.0 : vb[3];
     }
   });
@@ -1702,8 +1734,13 @@ __device__ __forceinline__ void slot_project(const Ws<NL>& w, const CReg<NL>& cr
     constexpr int c = decltype(cc)::value;
     if constexpr (SS::slot(c)) {
       if ((act >> c) & 1u) {
+        constexpr int NK = slot_kind<NL>(c) == 2 ? 3 : 4;
+        real pj[NK];
 #pragma unroll
-        for (int k = 0; k < (slot_kind<NL>(c) == 2 ? 3 : 4); k++) { const real s = gsum<G>(cr.jb[c][k] * v); u[k] = sub == c ? s : u[k]; }
+        for (int k = 0; k < NK; k++) pj[k] = cr.jb[c][k] * v;
+        gsum_n<G, NK>(pj);
+#pragma unroll
+        for (int k = 0; k < NK; k++) u[k] = sub == c ? pj[k] : u[k];
         if (slot_kind<NL>(c) == 2) u[3] = sub == c ? 0.0 : u[3];
       }
     }
@@ -1982,7 +2019,9 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
     // ---- exact line search on phi(alpha) = cost(a + alpha p)
     real Mp;
     if constexpr (S == KM_SUB_CUBE) Mp = mdiag * p; else Mp = mass_mul<NL, G>(cr, sub, mdiag, p);
-    const real gp = gsum<G>(in ? p * Mr : 0.0), pMp = gsum<G>(p * Mp), d10 = gsum<G>(in ? p * grad : 0.0);
+    real s3[3] = {in ? p * Mr : 0.0, p * Mp, in ? p * grad : 0.0};
+    gsum_n<G, 3>(s3);
+    const real gp = s3[0], pMp = s3[1], d10 = s3[2];
     real y[4];
     slot_project<NL, G, S>(w, cr, act, sub, p, y);
     if (!slin) { y[0] = 0; y[1] = 0; y[2] = 0; y[3] = 0; }     // slots outside the subset do not move
@@ -1997,8 +2036,10 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
         if (in && cr.sg != 0) row_ls(1, xl + alpha * yl, yl, cr.Rl, cr.Dl, 0.0, e1, e2);
         const real X[4] = {u[0] + alpha * y[0], u[1] + alpha * y[1], u[2] + alpha * y[2], u[3] + alpha * y[3]};
         slot_ls(sc, X, y, e1, e2);
-        const real d1 = gp + alpha * pMp + gsum<G>(e1);
-        const real d2 = pMp + gsum<G>(e2);
+        real e12[2] = {e1, e2};
+        gsum_n<G, 2>(e12);
+        const real d1 = gp + alpha * pMp + e12[0];
+        const real d2 = pMp + e12[1];
         if (fabs(d1) <= 1e-8 * fabs(d10)) break;        // MuJoCo's ls_tolerance is 1e-2; the outer Newton absorbs the rest
         if (d1 < 0) lo = alpha; else hi = alpha;
         if (hi - lo <= 1e-14 * hi) break;                 // bracket collapsed to roundoff
@@ -2027,9 +2068,11 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
     real gsl = grad;
     slot_grad<NL, G, S>(cr, act, F, gsl);
     if (in) grad = gsl;
-    const real cost_new = gsum<G>(cl);
     const real g1 = in ? grad : 0.0;
-    const real improvement = scale * (cost - cost_new), gradient = scale * km_sqrt(gsum<G>(g1 * g1));
+    real cg[2] = {cl, g1 * g1};
+    gsum_n<G, 2>(cg);
+    const real cost_new = cg[0];
+    const real improvement = scale * (cost - cost_new), gradient = scale * km_sqrt(cg[1]);
     cost = cost_new;
     pf.ph(14 + 6 * S);
     if (improvement < tol || gradient < tol || w.bad || iter + 1 >= maxit) {
@@ -2054,14 +2097,18 @@ __device__ __forceinline__ real solve_newton_sl(Ws<NL>& w, const LModel<NL>& lm,
   real a = warm;
   real Mr = mass_mul<NL, G>(cr, sub, mdiag, warm - a_s);
   newton_eval_sl<NL, G, true>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1, csl);
-  const real cs = gsum<G>(csl);
-  real cost0 = gsum<G>(c0), cost1 = gsum<G>(c1);
+  real c3[3] = {csl, c0, c1};
+  gsum_n<G, 3>(c3);
+  const real cs = c3[0];
+  real cost0 = c3[1], cost1 = c3[2];
   pf.ph(8);
   if (!(cost0 + cost1 < cs)) {
     a = a_s; Mr = 0;
     real dummy;
     newton_eval_sl<NL, G, false>(w, sub, cr, a, a_s, Mr, grad, qf, ql, u, W, c0, c1, dummy);
-    cost0 = gsum<G>(c0); cost1 = gsum<G>(c1);
+    real c2[2] = {c0, c1};
+    gsum_n<G, 2>(c2);
+    cost0 = c2[0]; cost1 = c2[1];
     pf.ph(38);
   }
   constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
