@@ -36,6 +36,23 @@ __device__ __forceinline__ real gsum8(real v) {
   v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
   return v;
 }
+// N sums at once, step by step: the same operations per value as N gsum8 calls, the chains interleaved (see gsum_n)
+template <int N> __device__ __forceinline__ void gsum8_n(real (&v)[N]) {
+#pragma clang fp contract(off)
+  real t[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = dpp_f64<0x141>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = dpp_f64<0xB1>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += t[i];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = dpp_f64<0x4E>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] += t[i];
+}
 __device__ __forceinline__ real gmin8(real v) {
   v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v));
   return v;
@@ -329,7 +346,9 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, const real
   const real Aph = arow_dot<N>(arow, ph);
   const real xp = x + d * ph;
   if (gall8(!P.on || (xp >= P.lb && xp <= P.ub))) {
-    const real pv = 0.5 * gsum8(ph * Aph) + gsum8(gh * ph);
+    real s2[2] = {ph * Aph, gh * ph};
+    gsum8_n<2>(s2);
+    const real pv = 0.5 * s2[0] + s2[1];
     step_h = ph;
     return -pv;
   }
@@ -341,7 +360,9 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, const real
   const real xb = x + d * phs;
   real to_tr;
   {
-    const real a = gsum8(rh * rh), b = gsum8(phs * rh), c = gsum8(phs * phs) - Delta * Delta;
+    real s3[3] = {rh * rh, phs * rh, phs * phs};
+    gsum8_n<3>(s3);
+    const real a = s3[0], b = s3[1], c = s3[2] - Delta * Delta;
     const real dd = sqrt(b * b - a * c);
     const real q = -(b + copysign(dd, b));
     const real t1 = q * frcp(a), t2 = c * frcp(q);
@@ -355,22 +376,28 @@ __device__ __forceinline__ real coop_select_step(const CoopCtx<N>& P, const real
   const real Aphs = Aph * p_stride;          // A (p_h * stride) row value
   if (rl <= ru) {
     const real Arh = arow_dot<N>(arow, rh);
-    const real a = 0.5 * gsum8(rh * Arh);
-    const real b = gsum8(gh * rh) + gsum8(phs * Arh);
-    const real c = 0.5 * gsum8(phs * Aphs) + gsum8(gh * phs);
+    real s5[5] = {rh * Arh, gh * rh, phs * Arh, phs * Aphs, gh * phs};
+    gsum8_n<5>(s5);
+    const real a = 0.5 * s5[0];
+    const real b = s5[1] + s5[2];
+    const real c = 0.5 * s5[3] + s5[4];
     min_quad_1d_c(a, b, rl, ru, c, r_stride, r_value);
     rh = rh * r_stride + phs;
   }
   const real pht = phs * theta;              // strictly interior version of the restricted step
-  const real p_value = 0.5 * gsum8(pht * (Aphs * theta)) + gsum8(gh * pht);
   real agh = -gh;
-  const real to_tr2 = Delta * rsqrt_nr(gsum8(agh * agh));
+  real s3b[3] = {pht * (Aphs * theta), gh * pht, agh * agh};
+  gsum8_n<3>(s3b);
+  const real p_value = 0.5 * s3b[0] + s3b[1];
+  const real to_tr2 = Delta * rsqrt_nr(s3b[2]);
   const real to_bound2 = gmin8(lane_step_to_bound<N>(P, x, d * agh));
   real ag_stride = (to_bound2 < to_tr2) ? theta * to_bound2 : to_tr2;
   real ag_value;
   {
     const real Aag = arow_dot<N>(arow, agh);
-    const real a = 0.5 * gsum8(agh * Aag), b = gsum8(gh * agh);
+    real s2b[2] = {agh * Aag, gh * agh};
+    gsum8_n<2>(s2b);
+    const real a = 0.5 * s2b[0], b = s2b[1];
     min_quad_1d_c(a, b, 0, ag_stride, 0, ag_stride, ag_value);
   }
   agh *= ag_stride;
@@ -459,7 +486,9 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       P.pf->ph(33);
       x_last = x_new;
       nfev++;
-      const real shn = km_sqrt(gsum8(step_h * step_h));
+      real n3[3] = {step_h * step_h, step * step, P.on ? x * x : 0.0};
+      gsum8_n<3>(n3);
+      const real shn = km_sqrt(n3[0]);
       bool fin = true;
 #pragma unroll
       for (int r = 0; r < 6; r++) fin = fin && isfinite(ft_new[r]);
@@ -472,7 +501,7 @@ __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_ou
       else ratio = 0;
       if (ratio < 0.25) Delta_new = 0.25 * shn;
       else if (ratio > 0.75 && shn > 0.95 * Delta) Delta_new = Delta * 2.0;
-      const real sn = km_sqrt(gsum8(step * step)), xn = km_sqrt(gsum8(P.on ? x * x : 0.0));
+      const real sn = km_sqrt(n3[1]), xn = km_sqrt(n3[2]);
       const bool ft_ok = (actual < ftol * cost) && (ratio > 0.25);
       const bool xt_ok = sn < xtol * (xtol + xn);
       if (ft_ok && xt_ok) status = 4; else if (ft_ok) status = 2; else if (xt_ok) status = 3;
