@@ -1925,25 +1925,33 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
       } else plain = !cq && __popc(rows) <= 2;
     }
     if (plain) {
-      real y = 0;
+      // everything the direction reads from LDS or from other lanes that does not depend on y is requested FIRST and together --
+      // the row of M^-1, the 2 x 2 system's entries, the correction's two column entries, the two rows' weights -- so that the
+      // path waits for one LDS round trip here and one more for y's two entries, not for eleven in a row
       const BSrc<G> gs = bsrc<G>(in ? grad : 0.0);
       const int row = sub < NL ? sub : 0;
-      fmac_rowvec<G, 0, NL>(y, gs, [&](int j) { return w.Minv[row][j]; });
+      real mi[NL];
+#pragma unroll
+      for (int j = 0; j < NL; j++) mi[j] = w.Minv[row][j];
+      const int i1 = rows ? __ffs(rows) - 1 : 0, i2 = (rows & (rows - 1)) ? __ffs(rows & (rows - 1)) - 1 : i1;
+      const real m11 = w.Minv[i1][i1], m22 = w.Minv[i2][i2], a12 = w.Minv[i1][i2], r1 = w.Minv[row][i1], r2 = w.Minv[row][i2];
+      const real dl = (qf ? cr.Df : 0.0) + (ql ? cr.Dl : 0.0);
+      const real d1 = __shfl(dl, i1, G), d2 = __shfl(dl, i2, G);
+      real y = 0;
+      fmac_rowvec<G, 0, NL>(y, gs, [&](int j) { return mi[j]; });
       real corr = 0;
       if (rows) {
-        const int i1 = __ffs(rows) - 1, i2 = (rows & (rows - 1)) ? __ffs(rows & (rows - 1)) - 1 : i1;
-        const real dl = (qf ? cr.Df : 0.0) + (ql ? cr.Dl : 0.0);
         const real y1 = __shfl(y, i1, G), y2 = __shfl(y, i2, G);
-        const real a11 = frcp(__shfl(dl, i1, G)) + w.Minv[i1][i1];
+        const real a11 = frcp(d1) + m11;
         real z1, z2 = 0;
         if (i2 == i1) z1 = y1 * frcp(a11);
         else {
-          const real a22 = frcp(__shfl(dl, i2, G)) + w.Minv[i2][i2], a12 = w.Minv[i1][i2];
+          const real a22 = frcp(d2) + m22;
           const real idet = frcp(a11 * a22 - a12 * a12);
           z1 = (a22 * y1 - a12 * y2) * idet;
           z2 = (a11 * y2 - a12 * y1) * idet;
         }
-        corr = w.Minv[row][i1] * z1 + (i2 == i1 ? 0.0 : w.Minv[row][i2] * z2);
+        corr = r1 * z1 + (i2 == i1 ? 0.0 : r2 * z2);
       }
       p = in ? -(y - corr) : 0.0;
       pf.ph(11 + 6 * S);
