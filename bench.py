@@ -375,6 +375,13 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The one collective is a 64 KB all-gather per step.  k_step fills every SIMD with exactly one wave (366 of the 512
+        # registers of a lane), so a collective kernel that takes whole compute units pushes some of k_step's workgroups behind
+        # it; one channel of one wave can sit BESIDE k_step's wave on a SIMD instead.  (RCCL reads the NCCL_* names; setdefault:
+        # the caller's choice wins.  Unverified on hardware -- DESIGN.md section 7.)
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "1")
+        os.environ.setdefault("NCCL_NTHREADS", "64")
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
