@@ -425,7 +425,7 @@ def run_rank(args):
             e1.record()
             rgb_ev.append((e0, e1))
         if gather is not None:
-            gather.post(env.reward, env.done)
+            gather.post(env.reward, env.done)                 # (bound below: the step wrote the record, nothing is packed here)
 
     def barrier():
         torch.cuda.synchronize()
@@ -434,6 +434,8 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     w.lay_out(args.warmup + args.steps)
+    if gather is not None:
+        gather.bind(env)          # from here on every step writes its packed (reward, done) record itself: one step, one post
     for _ in range(args.warmup):
         one_step()
     barrier()

@@ -28,6 +28,8 @@ struct KHandle_ {
   std::vector<hipEvent_t> ev;   // 4 events per timed step
   std::vector<char> ev_render;  // the step rendered in the step (its fourth event was recorded)
   bool timing = false;
+  double* rd_rec[2] = {nullptr, nullptr};   // kmanip_bind_reward_done_record: the two record buffers, used alternately
+  int rd_next = 0;
   int timed_steps = 0;
   // render target bound to the step (BASELINE config 5: "depth render in the step"): kmanip_step then also renders
   int step_cam = -1, step_h = 0, step_w = 0;
@@ -209,6 +211,7 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.env_id_offset = env_id_offset;
   h->st.seed = seed;
   h->st.sim_time = nullptr;
+  h->st.rd_rec = nullptr;
   h->st.control_dt = desc->n_sub_steps * desc->timestep;
   { const char* e = getenv("KMANIP_IK_UNFUSED"); h->ik_unfused = e && e[0] == '1'; }
   // the initialisation above ran on the null stream; the caller's (non-blocking) streams must not start before it
@@ -247,6 +250,8 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   // product path: ONE launch, before_step (decode + IK) fused into k_step so that no device-wide barrier sits between
   // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1)
   const bool split = h->ik_unfused;
+  h->st.rd_rec = nullptr;
+  if (nchunk == 1 && h->rd_rec[0]) { h->st.rd_rec = h->rd_rec[h->rd_next]; h->rd_next ^= 1; }
   if (split && nchunk != 1) { h->err = "kmanip_step_chunk needs the fused path (unset KMANIP_IK_UNFUSED)"; return -1; }
   if (split) {
     if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
@@ -421,6 +426,13 @@ int kmanip_set_episode(KHandle h, const int32_t* episode) {
 int kmanip_bind_sim_time(KHandle h, double* sim_time_dev) {
   if (!h) return -1;
   h->st.sim_time = sim_time_dev;
+  return 0;
+}
+
+int kmanip_bind_reward_done_record(KHandle h, double* rec0_dev, double* rec1_dev) {
+  if (!h) return -1;
+  if ((rec0_dev == nullptr) != (rec1_dev == nullptr)) { h->err = "kmanip_bind_reward_done_record: two buffers or none"; return -1; }
+  h->rd_rec[0] = rec0_dev; h->rd_rec[1] = rec1_dev; h->rd_next = 0;
   return 0;
 }
 

@@ -401,6 +401,7 @@ struct KDeviceState {
   int32_t* ik_nfev;   // [2][N]
   int32_t* ik_status; // [2][N]
   double* sim_time;   // [N] caller-owned (kmanip_bind_sim_time), may be NULL: data.time of every env = step_idx * control_dt
+  double* rd_rec;     // [N][2] caller-owned (kmanip_bind_reward_done_record), may be NULL: this step's packed (reward, done) record
   double control_dt;  // n_sub_steps * timestep
   int num_envs;
   int64_t env_id_offset;

@@ -2495,7 +2495,10 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     write_obs<NL, G>(w, lm, m, sub, obs_row);
     pf.ph(32);
   }
-  if (sub == 0) { reward[(size_t)kc * NE + env] = rew; done[(size_t)kc * NE + env] = dn; }
+  if (sub == 0) {
+    reward[(size_t)kc * NE + env] = rew; done[(size_t)kc * NE + env] = dn;
+    if (!CHUNK && st.rd_rec) { st.rd_rec[2 * (size_t)env] = rew; st.rd_rec[2 * (size_t)env + 1] = (real)dn; }
+  }
   GSYNC();
   }   // chunk
   if (sub == 0) {

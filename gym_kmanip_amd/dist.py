@@ -39,14 +39,22 @@ class RewardDoneGather:
             self.h_rec = torch.zeros((n_local, 2), dtype=torch.float64)
             self.h_all = torch.zeros((world * n_local, 2), dtype=torch.float64)
 
-    def post(self, reward, done):
-        """Pack this step's local results and start the collective; returns the buffer index."""
+    def bind(self, env):
+        """Let the engine write the packed records itself (KManipEnvHip.bind_reward_done_record -> kmanip_bind_reward_done_record):
+        post() then skips its two packing kernels.  Call before the first step; the engine alternates the buffers in step with
+        post()'s own counter."""
+        env.bind_reward_done_record(self.rec[0], self.rec[1])
+        self.bound = True
+
+    def post(self, reward=None, done=None):
+        """Start the collective on this step's local results (packed here unless the engine is bound); returns the buffer index."""
         b = self.k & 1
         self.k += 1
         if self.pending[b] is not None:
             self.pending[b].wait()
-        self.rec[b][:, 0].copy_(reward)
-        self.rec[b][:, 1].copy_(done)
+        if not getattr(self, "bound", False):
+            self.rec[b][:, 0].copy_(reward)
+            self.rec[b][:, 1].copy_(done)
         if self.host_stage:
             self.h_rec.copy_(self.rec[b])
             self.dist.all_gather_into_tensor(self.h_all, self.h_rec)

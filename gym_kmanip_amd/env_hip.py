@@ -139,6 +139,20 @@ class KManipEnvHip:
                                        self._stream()), "kmanip_step")
         return self.obs, self.reward, self.done
 
+    def bind_reward_done_record(self, rec0=None, rec1=None):
+        """kmanip_bind_reward_done_record: every step_flat / k_step then also writes the packed (reward, done) record of the
+        multi-GPU exchange (gym_kmanip_amd/dist.py) into rec0 / rec1 -- float64 [num_envs, 2] device tensors, used alternately
+        starting with rec0 -- so that the all-gather needs no packing kernel on the step's stream.  None, None unbinds."""
+        torch = _torch()
+        if (rec0 is None) != (rec1 is None):
+            raise _libmod.KManipError("bind_reward_done_record: two buffers or none")
+        for t in (rec0, rec1):
+            if t is not None:
+                self._check_buf(t, (self.num_envs, 2), torch.float64, "record")
+        self._rd_rec = (rec0, rec1)                          # (keeps the tensors alive while bound)
+        p = [C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0) for t in (rec0, rec1)]
+        self._check(self.L.kmanip_bind_reward_done_record(self.h, p[0], p[1]), "kmanip_bind_reward_done_record")
+
     def step_chunk(self, acts, obs=None, reward=None, done=None):
         """K control steps in one launch (kmanip_step_chunk): acts float32 [K, num_envs, act_dim] on the device ->
         (obs [K, N, obs_dim] f64, reward [K, N] f64, done [K, N] u8).  Same results as K step_flat calls; self.obs /

@@ -232,6 +232,14 @@ int kmanip_get_counters(KHandle h, int32_t* step_idx_dev, int32_t* episode_dev, 
  * steps since the env's last reset x control_timestep.  NULL unbinds.  The buffer must outlive the binding. */
 int kmanip_bind_sim_time(KHandle h, double* sim_time_dev);
 
+/* The multi-GPU learner's per-step exchange is one packed record per env, (reward, done as a double), all-gathered across the
+ * ranks (gym_kmanip_amd/dist.py).  Bound here, every kmanip_step writes that record itself -- rec0_dev / rec1_dev are
+ * caller-owned double[num_envs, 2] buffers used alternately, call by call, starting with rec0 (a collective still reading one
+ * buffer while the next step fills the other) -- so that the exchange costs the step's stream no packing kernel.  reward_dev /
+ * done_dev are written as always.  NULL, NULL unbinds; kmanip_step_chunk does not write records.  Returns the index (0 / 1) of the
+ * buffer the NEXT kmanip_step will fill, or -1. */
+int kmanip_bind_reward_done_record(KHandle h, double* rec0_dev, double* rec1_dev);
+
 /* KManipEnv.reset(seed=...) (env_base.py:219-220): re-key the cube-spawn stream.  restart_episodes != 0 also rewinds every
  * env's episode counter so that the next kmanip_reset draws episode 0 of the new seed (reset(seed=s) is then reproducible). */
 int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes);

@@ -817,3 +817,32 @@ def test_table_rectangle_gpu():
     assert (4, 2, 0) in seen
     assert dev.get_state()[0][2, nl + 2] < cm.desc.table_z - 0.5
     dev.k_close()
+
+
+def test_bound_reward_done_record():
+    """kmanip_bind_reward_done_record: every step also writes the packed (reward, done) record of the multi-GPU exchange into the
+    two bound buffers alternately, starting with the first; reward / done themselves are written as always; unbinding stops it; a
+    chunked launch writes no record."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.lib import KManipError
+    n = 37
+    e = env_hip.make("KManipSoloArm", num_envs=n, seed=2)
+    e.k_reset(); e.set_state(step=(57 + np.arange(n) % 7).astype(np.int32))      # some envs time out during the test
+    rec = [torch.full((n, 2), -7.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+    with pytest.raises(KManipError):
+        e.bind_reward_done_record(rec[0], None)
+    e.bind_reward_done_record(rec[0], rec[1])
+    saw_done = False
+    for k in range(5):
+        e.step_flat(e.sample_action())
+        r = rec[k & 1].cpu().numpy()
+        assert np.array_equal(r[:, 0], e.reward.cpu().numpy()) and np.array_equal(r[:, 1], e.done.cpu().numpy().astype(np.float64)), k
+        saw_done |= bool(e.done.cpu().numpy().any())
+    assert saw_done
+    keep = [t.clone() for t in rec]
+    e.step_chunk(torch.stack([e.sample_action().clone() for _ in range(2)]))
+    e.bind_reward_done_record(None, None)
+    e.step_flat(e.sample_action())
+    assert all(torch.equal(a, b) for a, b in zip(rec, keep))
+    e.k_close()

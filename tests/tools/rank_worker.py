@@ -36,6 +36,7 @@ def main():
     env = env_hip.make(a.env, num_envs=n, device=dev, seed=a.seed, env_id_offset=lo)
     env.k_reset()
     g = RewardDoneGather(n, world, torch.device("cuda", dev), dist)
+    g.bind(env)                                                         # the step writes the packed record itself (as bench.py runs it)
     gen = torch.Generator(); gen.manual_seed(1234)                      # CPU generator: the same stream on every rank
     rew, done = [], []
     for k in range(a.steps):
