@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=0, help="also render a DxD gripper-cam depth image per env each step (BASELINE config 5)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--rccl-one-channel", action="store_true",
+                    help="N > 1 only: NCCL_MIN/MAX_NCHANNELS=1, NCCL_NTHREADS=64 for the per-step all-gather (A/B switch; default: RCCL's own settings)")
     ap.add_argument("--no-stagger", action="store_true", help="keep all envs phase-locked (episode phase = step index for every env)")
     ap.add_argument("--solver-iterations", type=int, default=100, help="solver iteration cap (MuJoCo default 100); ablation only")
     ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
@@ -375,13 +377,13 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The one collective is a 64 KB all-gather per step.  k_step fills every SIMD with exactly one wave (366 of the 512
-        # registers of a lane), so a collective kernel that takes whole compute units pushes some of k_step's workgroups behind
-        # it; one channel of one wave can sit BESIDE k_step's wave on a SIMD instead.  (RCCL reads the NCCL_* names; setdefault:
-        # the caller's choice wins.  Unverified on hardware -- DESIGN.md section 7.)
-        os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "1")
-        os.environ.setdefault("NCCL_NTHREADS", "64")
+        # RCCL runs with its own defaults.  --rccl-one-channel (opt-in, never measured on two devices: DESIGN.md section 7) asks
+        # for one channel of one wave for the 64 KB all-gather: k_step fills every SIMD with exactly one wave, so a collective
+        # kernel that takes whole compute units pushes some of k_step's workgroups behind it; one wave can sit beside it.
+        if args.rccl_one_channel:
+            os.environ["NCCL_MIN_NCHANNELS"] = "1"
+            os.environ["NCCL_MAX_NCHANNELS"] = "1"
+            os.environ["NCCL_NTHREADS"] = "64"
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
@@ -416,6 +418,8 @@ def run_rank(args):
     rgb_ev = []
 
     def one_step():
+        if gather is not None:
+            gather.before_step()          # the step's stream waits for the exchange of step k-2, which reads the record buffer step k fills
         w.step()
         if rgb_bufs:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

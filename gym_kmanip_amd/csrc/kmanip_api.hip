@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.13 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.14 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -28,8 +28,8 @@ struct KHandle_ {
   std::vector<hipEvent_t> ev;   // 4 events per timed step
   std::vector<char> ev_render;  // the step rendered in the step (its fourth event was recorded)
   bool timing = false;
-  double* rd_rec[2] = {nullptr, nullptr};   // kmanip_bind_reward_done_record: the two record buffers, used alternately
-  int rd_next = 0;
+  double* rd_rec[2] = {nullptr, nullptr};   // kmanip_bind_reward_done_record: the two record buffers
+  int rd_sel = 0;                           // kmanip_select_reward_done_record: the one the next kmanip_step fills
   int timed_steps = 0;
   // render target bound to the step (BASELINE config 5: "depth render in the step"): kmanip_step then also renders
   int step_cam = -1, step_h = 0, step_w = 0;
@@ -240,6 +240,14 @@ int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stre
   return 0;
 }
 
+int kmanip_observe(KHandle h, double* obs_dev, double* reward_dev, void* stream) {
+  if (!h) { g_create_error = "kmanip_observe: null handle"; return -1; }
+  KM_ENTER(h);
+  kmanip_launch_observe(h->dmodel, h->desc, h->st, obs_dev, reward_dev, (hipStream_t)stream);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
 static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_dev, double* reward_dev, uint8_t* done_dev, void* stream) {
   if (!h) { g_create_error = "kmanip_step: null handle"; return -1; }
   if (!act_dev || !obs_dev || !reward_dev || !done_dev) { h->err = "kmanip_step: null buffer"; return -1; }
@@ -251,7 +259,7 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1)
   const bool split = h->ik_unfused;
   h->st.rd_rec = nullptr;
-  if (nchunk == 1 && h->rd_rec[0]) { h->st.rd_rec = h->rd_rec[h->rd_next]; h->rd_next ^= 1; }
+  if (nchunk == 1 && h->rd_rec[0]) h->st.rd_rec = h->rd_rec[h->rd_sel];     // (the CALLER alternates: kmanip_select_reward_done_record)
   if (split && nchunk != 1) { h->err = "kmanip_step_chunk needs the fused path (unset KMANIP_IK_UNFUSED)"; return -1; }
   if (split) {
     if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
@@ -432,7 +440,14 @@ int kmanip_bind_sim_time(KHandle h, double* sim_time_dev) {
 int kmanip_bind_reward_done_record(KHandle h, double* rec0_dev, double* rec1_dev) {
   if (!h) return -1;
   if ((rec0_dev == nullptr) != (rec1_dev == nullptr)) { h->err = "kmanip_bind_reward_done_record: two buffers or none"; return -1; }
-  h->rd_rec[0] = rec0_dev; h->rd_rec[1] = rec1_dev; h->rd_next = 0;
+  h->rd_rec[0] = rec0_dev; h->rd_rec[1] = rec1_dev; h->rd_sel = 0;
+  return 0;
+}
+
+int kmanip_select_reward_done_record(KHandle h, int index) {
+  if (!h) return -1;
+  if (index < 0 || index > 1 || !h->rd_rec[0]) { h->err = "kmanip_select_reward_done_record: index 0 / 1 of two bound buffers"; return -1; }
+  h->rd_sel = index;
   return 0;
 }
 

@@ -421,6 +421,8 @@ void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDev
                         double* reward, uint8_t* done, int nchunk, hipStream_t stream);
 void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const uint8_t* mask,
                          int use_done_bits, double* obs, hipStream_t stream);
+void kmanip_launch_observe(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs, double* reward,
+                           hipStream_t stream);
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
                                 hipStream_t stream);
 void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, uint8_t* rgb,

@@ -6,6 +6,8 @@
   void kmanip_launch_reset_##NL##_##G##_##S(const KDeviceModel*, const KDeviceState&, const uint8_t*, double*, hipStream_t);
 KM_DECL(10, 16, 0) KM_DECL(10, 16, 1) KM_DECL(20, 32, 0) KM_DECL(20, 32, 1)
 #undef KM_DECL
+void kmanip_launch_observe_10_16_1(const KDeviceModel*, const KDeviceState&, double*, double*, hipStream_t);
+void kmanip_launch_observe_20_32_1(const KDeviceModel*, const KDeviceState&, double*, double*, hipStream_t);
 
 void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act, double* obs, double* reward,
                         uint8_t* done, int nchunk, hipStream_t stream) {
@@ -19,4 +21,9 @@ void kmanip_launch_reset(const KDeviceModel* dm, const KModelDesc& hd, const KDe
   const bool newton = hd.solver == KM_SOLVER_NEWTON;
   if (hd.nlink <= 10) { if (newton) kmanip_launch_reset_10_16_1(dm, st, mask, obs, stream); else kmanip_launch_reset_10_16_0(dm, st, mask, obs, stream); }
   else { if (newton) kmanip_launch_reset_20_32_1(dm, st, mask, obs, stream); else kmanip_launch_reset_20_32_0(dm, st, mask, obs, stream); }
+}
+void kmanip_launch_observe(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, double* obs, double* reward,
+                           hipStream_t stream) {
+  if (hd.nlink <= 10) kmanip_launch_observe_10_16_1(dm, st, obs, reward, stream);
+  else kmanip_launch_observe_20_32_1(dm, st, obs, reward, stream);
 }

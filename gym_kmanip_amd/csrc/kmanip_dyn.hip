@@ -2374,6 +2374,28 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
   __syncthreads();
 }
 
+// get_reward, env_sim.py:148-179, from the kinematics and contacts of a trailing mj_step1 (fk_parallel + collide_parallel)
+template <int NL, int G>
+__device__ __forceinline__ real env_reward(Ws<NL>& w, const KModelDesc* m, int sub) {
+  constexpr int NV = Dim<NL>::NV;
+  real v2 = gsum<G>(sub < NV ? w.qvel[sub] * w.qvel[sub] : 0.0);
+  GSYNC();
+  real rew = -m->reward_vel_penalty * km_sqrt(v2);
+  for (int arm = 1; arm >= 0; arm--) {
+    if (!m->arm_present[arm] || !m->arm_has_grip[arm]) continue;
+    const int l = m->arm_site_link[arm];
+    real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]}, sp[3];
+    mat_vec3(sp, w.k.xmat[l], so);
+    real df[3] = {w.qpos[NL] - (sp[0] + w.k.xpos[l][0]), w.qpos[NL + 1] - (sp[1] + w.k.xpos[l][1]), w.qpos[NL + 2] - (sp[2] + w.k.xpos[l][2])};
+    rew += m->reward_grip_dist * (1.0 / (km_sqrt(dot3(df, df)) + m->epsilon));
+  }
+  if (m->touch_reward_enabled && (w.contact_mask & KM_CON_FINGERS_CUBE(NL))) {      // a FINGER on the cube (palm / link spheres do not count)
+    rew += m->reward_touch_cube;
+    if (!w.touch_ct) rew += m->reward_lift_cube;
+  }
+  return rew;
+}
+
 // ---------------------------------------------------------------------------------------------
 // EPB = envs per single-wave workgroup (<= 64 / G).  Fewer envs per wave = more waves per SIMD: the kernel is
 // bound by LDS/dependent-issue latency, so waves of different envs hide each other's waits.
@@ -2462,22 +2484,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
     collide_parallel<NL, G>(w, m, sub);
-    real v2 = gsum<G>(sub < NV ? w.qvel[sub] * w.qvel[sub] : 0.0);
-    GSYNC();
-    // get_reward, env_sim.py:148-179
-    rew = -m->reward_vel_penalty * km_sqrt(v2);
-    for (int arm = 1; arm >= 0; arm--) {
-      if (!m->arm_present[arm] || !m->arm_has_grip[arm]) continue;
-      const int l = m->arm_site_link[arm];
-      real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]}, sp[3];
-      mat_vec3(sp, w.k.xmat[l], so);
-      real df[3] = {w.qpos[NL] - (sp[0] + w.k.xpos[l][0]), w.qpos[NL + 1] - (sp[1] + w.k.xpos[l][1]), w.qpos[NL + 2] - (sp[2] + w.k.xpos[l][2])};
-      rew += m->reward_grip_dist * (1.0 / (km_sqrt(dot3(df, df)) + m->epsilon));
-    }
-    if (m->touch_reward_enabled && (w.contact_mask & KM_CON_FINGERS_CUBE(NL))) {      // a FINGER on the cube (palm / link spheres do not count)
-      rew += m->reward_touch_cube;
-      if (!w.touch_ct) rew += m->reward_lift_cube;
-    }
+    rew = env_reward<NL, G>(w, m, sub);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
     if (sub == 0) st.contact_mask[env] = w.contact_mask;
   } else {
@@ -2538,6 +2545,28 @@ __global__ __launch_bounds__(64) void k_reset(const KDeviceModel* __restrict__ d
   store_state<NL, G>(w, st, env, sub);
 }
 
+// get_observation + get_reward of the CURRENT state (no step): what a trailing mj_step1 and the two task methods give
+template <int NL, int G, int EPB>
+__global__ __launch_bounds__(64) void k_observe(const KDeviceModel* __restrict__ dm, KDeviceState st, double* __restrict__ obs,
+                                                double* __restrict__ reward) {
+  __shared__ Ws<NL> ws[EPB];
+  __shared__ LModel<NL> lm;
+  stage_model<NL>(lm, dm);
+  const KModelDesc* m = &dm->d;
+  const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
+  const int env = xcd_block(blockIdx.x, gridDim.x) * EPB + grp;
+  if (grp >= EPB || env >= st.num_envs) return;
+  Ws<NL>& w = ws[grp];
+  init_ws<NL>(w, sub);
+  load_state<NL, G>(w, st, env, sub, false);
+  GSYNC();
+  fk_parallel<NL, G>(w, lm, sub);
+  collide_parallel<NL, G>(w, m, sub);
+  const real rew = env_reward<NL, G>(w, m, sub);
+  if (obs) write_obs<NL, G>(w, lm, m, sub, obs + (size_t)env * m->obs_dim);
+  if (sub == 0) { st.contact_mask[env] = w.contact_mask; if (reward) reward[env] = rew; }
+}
+
 // envs per workgroup: as many waves as the chip has SIMD slots for, but no more lanes idle than needed.
 static int pick_epb(int num_envs, int max_epb) {
   const char* e = getenv("KMANIP_EPB");              // diagnostic override (tests exercise every launch shape)
@@ -2571,6 +2600,11 @@ static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const
   if (epb == 2) return launch_reset_e<NL, G, SOLVER, 2>(dm, st, mask, obs, stream);
   launch_reset_e<NL, G, SOLVER, 1>(dm, st, mask, obs, stream);
 }
+template <int NL, int G>
+static void launch_observe_t(const KDeviceModel* dm, const KDeviceState& st, double* obs, double* reward, hipStream_t stream) {
+  constexpr int EPB = 64 / G;
+  hipLaunchKernelGGL((k_observe<NL, G, EPB>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, obs, reward);
+}
 // ---- one (NL, G, SOLVER) variant per translation unit (the Makefile compiles this file four times, in parallel)
 #ifndef KM_VAR_NL
 #error "compile with -DKM_VAR_NL=<10|20> -DKM_VAR_G=<16|32> -DKM_VAR_SOLVER=<0|1>"
@@ -2585,3 +2619,9 @@ void KM_CAT4(kmanip_launch_reset_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDe
                                                                      const uint8_t* mask, double* obs, hipStream_t stream) {
   launch_reset_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, mask, obs, stream);
 }
+#if KM_VAR_SOLVER == 1      // (solver-independent: one copy per link-count class)
+void KM_CAT4(kmanip_launch_observe_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st, double* obs,
+                                                                       double* reward, hipStream_t stream) {
+  launch_observe_t<KM_VAR_NL, KM_VAR_G>(dm, st, obs, reward, stream);
+}
+#endif

@@ -30,7 +30,8 @@ class RewardDoneGather:
         self.rec = [torch.zeros((n_local, 2), dtype=torch.float64, device=device) for _ in range(2)]
         self.all = [torch.zeros((world * n_local, 2), dtype=torch.float64, device=device) for _ in range(2)]
         self.pending = [None, None]
-        self.k = 0
+        self.k = 0                # THE step counter: step k uses buffer k & 1 (the engine keeps none of its own)
+        self.env = None           # bound engine (bind): it writes rec[k & 1] inside its step launch
         # gloo has no device collectives: when a one-GPU box rehearses the multi-rank path over gloo, the records are
         # staged through host memory (synchronously); RCCL (backend "nccl") gathers the device buffers directly
         self.host_stage = bool(dist is not None and world > 1 and dist.get_backend() == "gloo"
@@ -41,18 +42,35 @@ class RewardDoneGather:
 
     def bind(self, env):
         """Let the engine write the packed records itself (KManipEnvHip.bind_reward_done_record -> kmanip_bind_reward_done_record):
-        post() then skips its two packing kernels.  Call before the first step; the engine alternates the buffers in step with
-        post()'s own counter."""
+        post() then skips its two packing kernels.  From then on every step must be bracketed `before_step(); env.step...;
+        post()` -- before_step() is what keeps the step from overwriting a record a collective is still reading."""
         env.bind_reward_done_record(self.rec[0], self.rec[1])
-        self.bound = True
+        self.env = env
 
-    def post(self, reward=None, done=None):
-        """Start the collective on this step's local results (packed here unless the engine is bound); returns the buffer index."""
-        b = self.k & 1
-        self.k += 1
+    def _retire(self, b):
+        # Work.wait() makes the CURRENT stream wait for the collective (RCCL) or blocks the host (gloo): either way everything
+        # enqueued on this stream afterwards runs after the collective has read rec[b] and written all[b]
         if self.pending[b] is not None:
             self.pending[b].wait()
-        if not getattr(self, "bound", False):
+            self.pending[b] = None
+
+    def before_step(self):
+        """Call BEFORE enqueuing step k.  ORDERING INVARIANT: the all-gather of step k-2 reads rec[k & 1] and writes
+        all[k & 1]; a bound engine's step k writes rec[k & 1] inside its launch, so the step's stream has to wait for that
+        collective before the launch is enqueued (a peer that lags two steps -- one IK crawl is seven -- would otherwise let
+        this rank ship step k's rewards as step k-2's).  Also points the engine at buffer k & 1: one counter, here."""
+        b = self.k & 1
+        self._retire(b)
+        if self.env is not None:
+            self.env.select_reward_done_record(b)
+        return b
+
+    def post(self, reward=None, done=None):
+        """Start the collective on step k's local results (packed here unless the engine is bound); returns the buffer index."""
+        b = self.k & 1
+        self.k += 1
+        self._retire(b)           # (no-op after before_step(); the un-bound path may skip before_step)
+        if self.env is None:
             self.rec[b][:, 0].copy_(reward)
             self.rec[b][:, 1].copy_(done)
         if self.host_stage:
@@ -67,9 +85,7 @@ class RewardDoneGather:
 
     def wait(self, b: Optional[int] = None):
         for i in ([b] if b is not None else [0, 1]):
-            if self.pending[i] is not None:
-                self.pending[i].wait()
-                self.pending[i] = None
+            self._retire(i)
 
     def result(self, b: int):
         """(reward[world*n], done[world*n] uint8) of buffer b, global env order."""

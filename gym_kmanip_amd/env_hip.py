@@ -141,8 +141,9 @@ class KManipEnvHip:
 
     def bind_reward_done_record(self, rec0=None, rec1=None):
         """kmanip_bind_reward_done_record: every step_flat / k_step then also writes the packed (reward, done) record of the
-        multi-GPU exchange (gym_kmanip_amd/dist.py) into rec0 / rec1 -- float64 [num_envs, 2] device tensors, used alternately
-        starting with rec0 -- so that the all-gather needs no packing kernel on the step's stream.  None, None unbinds."""
+        multi-GPU exchange (gym_kmanip_amd/dist.py) into rec0 or rec1 -- float64 [num_envs, 2] device tensors; which one is the
+        CALLER's choice (select_reward_done_record, rec0 after the bind) -- so that the all-gather needs no packing kernel on the
+        step's stream.  None, None unbinds."""
         torch = _torch()
         if (rec0 is None) != (rec1 is None):
             raise _libmod.KManipError("bind_reward_done_record: two buffers or none")
@@ -152,6 +153,23 @@ class KManipEnvHip:
         self._rd_rec = (rec0, rec1)                          # (keeps the tensors alive while bound)
         p = [C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0) for t in (rec0, rec1)]
         self._check(self.L.kmanip_bind_reward_done_record(self.h, p[0], p[1]), "kmanip_bind_reward_done_record")
+
+    def select_reward_done_record(self, index: int):
+        """kmanip_select_reward_done_record: the bound buffer (0 / 1) the following steps fill.  The caller must have made the
+        step's stream wait for whatever still reads that buffer (include/kmanip.h: ordering invariant)."""
+        self._check(self.L.kmanip_select_reward_done_record(self.h, int(index)), "kmanip_select_reward_done_record")
+
+    def observe(self, obs=None, reward=None):
+        """kmanip_observe: get_observation + get_reward (env_sim.py:110-179) of the CURRENT state, no step; fills and returns
+        (self.obs, self.reward) unless other float64 device tensors are given."""
+        torch = _torch()
+        obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        self._check_buf(obs, (self.num_envs, self.cm.obs_dim), torch.float64, "obs")
+        self._check_buf(reward, (self.num_envs,), torch.float64, "reward")
+        self._check(self.L.kmanip_observe(self.h, C.c_void_p(obs.data_ptr()), C.c_void_p(reward.data_ptr()), self._stream()),
+                    "kmanip_observe")
+        return obs, reward
 
     def step_chunk(self, acts, obs=None, reward=None, done=None):
         """K control steps in one launch (kmanip_step_chunk): acts float32 [K, num_envs, act_dim] on the device ->

@@ -26,7 +26,7 @@ from typing import Any, Dict
 import numpy as np
 
 from . import env_hip
-from .model import (CAMERAS, ENV_SPECS, MAX_EPISODE_STEPS, REWARD_SUCCESS_THRESHOLD, KM_DONE_DIVERGED, EnvSpec)
+from .model import (CAMERAS, ENV_SPECS, MAX_EPISODE_STEPS, REWARD_SUCCESS_THRESHOLD, KM_DONE_DIVERGED, EnvSpec, load_asset)
 
 OBS_DTYPE = np.float64   # __init__.py:50
 ACT_DTYPE = np.float32   # __init__.py:51
@@ -88,6 +88,54 @@ def _dict(d):
     return _spaces.Dict(d) if _HAVE_GYM else DictSpace(d)
 
 
+# keys of KManipEnv.info: the constructor's (env_base.py:201-212) and the ones reset()/step() add (env_base.py:223-229,244-251)
+INFO_KEYS = ("step", "episode", "is_success", "q_keys", "q_len", "a_len", "obs_list", "act_list", "cameras", "sim",
+             "sim_time", "cpu_time", "reward", "terminated")
+
+
+def spaces_for(env_id: str):
+    """{"observation": OrderedDict, "action": OrderedDict} of Boxes for a registered id: the Dict spaces KManipEnv.__init__
+    builds (env_base.py:115-190) -- same keys, insertion order (== flat column order of the action matrix), shapes, dtypes, bounds."""
+    spec: EnvSpec = ENV_SPECS[env_id]
+    q_len = len(spec.q_pos_home)
+    od = OrderedDict()
+    if "q_pos" in spec.obs_list:
+        od["q_pos"] = _box(-1, 1, (q_len,), OBS_DTYPE)
+    if "q_vel" in spec.obs_list:
+        od["q_vel"] = _box(-1, 1, (q_len,), OBS_DTYPE)
+    if "cube_pos" in spec.obs_list:
+        od["cube_pos"] = _box(-1, 1, (3,), OBS_DTYPE)
+    if "cube_orn" in spec.obs_list:
+        od["cube_orn"] = _box(-1, 1, (4,), OBS_DTYPE)
+    for o in spec.obs_list:                      # env_base.py:110-113,140-147: the Cam records of the "camera/<name>" keys
+        if "camera" in o:
+            cam = CAMERAS[o.split("/")[-1]]
+            od[cam.log_name] = _box(cam.low, cam.high, (cam.h, cam.w, 3), cam.dtype)
+    ad = OrderedDict()
+    for key in ["eel_pos", "eel_orn", "eer_pos", "eer_orn"]:
+        if key in spec.act_list:
+            ad[key] = _box(-1, 1, (3,), ACT_DTYPE)
+    for key in ["grip_l", "grip_r"]:
+        if key in spec.act_list:
+            ad[key] = _box(-1, 1, (1,), ACT_DTYPE)
+    if "q_pos_r" in spec.act_list:
+        ad["q_pos_r"] = _box(-1, 1, (len(spec.q_id_r_mask),), ACT_DTYPE)
+    if "q_pos_l" in spec.act_list:
+        ad["q_pos_l"] = _box(-1, 1, (len(spec.q_id_l_mask),), ACT_DTYPE)
+    return {"observation": od, "action": ad}
+
+
+def q_keys_for(env_id: str):
+    """The joint-name list the reference registers as `q_keys` (keys of Q_*_HOME_DICT, __init__.py:53-122) = the MJCF joint
+    names in qpos order -- except that the DualArm dict spells the left arm `joint_left_arm_1_*` where the XML says
+    `joint_left_arm_2_*` (only teleop's URDF mapping reads these keys)."""
+    spec: EnvSpec = ENV_SPECS[env_id]
+    names = [l["joint"]["name"] for l in load_asset(spec.asset)["links"]]
+    if spec.asset == "dual_arm":
+        names = [n.replace("joint_left_arm_2_", "joint_left_arm_1_") for n in names]
+    return names
+
+
 class KManipEnv(_EnvBase):
     metadata = {"render_modes": ["rgb_array"], "render_fps": 30}
 
@@ -115,39 +163,20 @@ class KManipEnv(_EnvBase):
         self.act_list = list(spec.act_list)
         # env_base.py:110-113: the Cam records of the "camera/<name>" observation keys
         self.cameras = [CAMERAS[o.split("/")[-1]] for o in self.obs_list if "camera" in o]
-        # observation space, env_base.py:115-147
-        od = OrderedDict()
-        if "q_pos" in self.obs_list:
-            od["q_pos"] = _box(-1, 1, (self.q_len,), OBS_DTYPE)
-        if "q_vel" in self.obs_list:
-            od["q_vel"] = _box(-1, 1, (self.q_len,), OBS_DTYPE)
-        if "cube_pos" in self.obs_list:
-            od["cube_pos"] = _box(-1, 1, (3,), OBS_DTYPE)
-        if "cube_orn" in self.obs_list:
-            od["cube_orn"] = _box(-1, 1, (4,), OBS_DTYPE)
-        for cam in self.cameras:
-            od[cam.log_name] = _box(cam.low, cam.high, (cam.h, cam.w, 3), cam.dtype)
-        self.observation_space = _dict(od)
-        # action space, env_base.py:149-190 (insertion order == flat column order)
-        ad = OrderedDict()
-        for key in ["eel_pos", "eel_orn", "eer_pos", "eer_orn"]:
-            if key in self.act_list:
-                ad[key] = _box(-1, 1, (3,), ACT_DTYPE)
-        for key in ["grip_l", "grip_r"]:
-            if key in self.act_list:
-                ad[key] = _box(-1, 1, (1,), ACT_DTYPE)
-        if "q_pos_r" in self.act_list:
-            ad["q_pos_r"] = _box(-1, 1, (len(self.q_id_r_mask),), ACT_DTYPE)
-        if "q_pos_l" in self.act_list:
-            ad["q_pos_l"] = _box(-1, 1, (len(self.q_id_l_mask),), ACT_DTYPE)
-        self.action_space = _dict(ad)
-        self.action_len = len(ad)
+        # observation / action spaces, env_base.py:115-190
+        sp = spaces_for(env_id)
+        self.observation_space = _dict(sp["observation"])
+        self.action_space = _dict(sp["action"])
+        self.action_len = len(sp["action"])
+        # joint names: teleop's URDF mapping reads them (env_base.py:66-68); part of `info`
+        self.q_keys = q_keys_for(env_id)
+        assert len(self.q_keys) == self.q_len, "q parameters do not match"          # env_base.py:68
         self.sim = True
         # backend seam, env_base.py:192-200
         self.env = env_hip.new(self, num_envs=num_envs, device=device, env_id_offset=env_id_offset,
                                auto_reset=False, **overrides)
         self.info: Dict[str, Any] = {
-            "step": self.step_idx, "episode": self.episode_idx, "is_success": False, "q_len": self.q_len,
+            "step": self.step_idx, "episode": self.episode_idx, "is_success": False, "q_keys": self.q_keys, "q_len": self.q_len,
             "a_len": self.action_len, "obs_list": self.obs_list, "act_list": self.act_list,
             "cameras": self.cameras, "sim": self.sim,
         }

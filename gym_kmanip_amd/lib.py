@@ -19,7 +19,7 @@ _lib = None
 # every symbol include/kmanip.h declares (tests check the library exports all of them)
 EXPORTS = [
     "kmanip_model_desc_size", "kmanip_create", "kmanip_reset", "kmanip_step", "kmanip_step_chunk", "kmanip_get_state",
-    "kmanip_set_state", "kmanip_get_episode", "kmanip_set_episode", "kmanip_get_counters", "kmanip_bind_sim_time", "kmanip_bind_reward_done_record", "kmanip_set_seed", "kmanip_get_diag", "kmanip_timing_summary", "kmanip_enable_timing", "kmanip_ik", "kmanip_ik_eval",
+    "kmanip_set_state", "kmanip_get_episode", "kmanip_set_episode", "kmanip_get_counters", "kmanip_bind_sim_time", "kmanip_bind_reward_done_record", "kmanip_select_reward_done_record", "kmanip_observe", "kmanip_set_seed", "kmanip_get_diag", "kmanip_timing_summary", "kmanip_enable_timing", "kmanip_ik", "kmanip_ik_eval",
     "kmanip_render_depth", "kmanip_render_rgb", "kmanip_bind_step_depth", "kmanip_scripted_action", "kmanip_sample_action", "kmanip_num_envs", "kmanip_last_error", "kmanip_version", "kmanip_destroy",
 ]
 
@@ -58,6 +58,8 @@ def load():
     lib.kmanip_get_counters.argtypes = [vp, vp, vp, vp]
     lib.kmanip_bind_sim_time.argtypes = [vp, vp]
     lib.kmanip_bind_reward_done_record.argtypes = [vp, vp, vp]
+    lib.kmanip_select_reward_done_record.argtypes = [vp, C.c_int]
+    lib.kmanip_observe.argtypes = [vp, vp, vp, vp]
     lib.kmanip_set_seed.argtypes = [vp, C.c_uint64, C.c_int]
     lib.kmanip_get_diag.argtypes = [vp, C.POINTER(C.c_uint32), i32p, i32p]
     lib.kmanip_timing_summary.argtypes = [vp, f64p, f64p, f64p, i32p]

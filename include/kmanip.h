@@ -233,12 +233,23 @@ int kmanip_get_counters(KHandle h, int32_t* step_idx_dev, int32_t* episode_dev, 
 int kmanip_bind_sim_time(KHandle h, double* sim_time_dev);
 
 /* The multi-GPU learner's per-step exchange is one packed record per env, (reward, done as a double), all-gathered across the
- * ranks (gym_kmanip_amd/dist.py).  Bound here, every kmanip_step writes that record itself -- rec0_dev / rec1_dev are
- * caller-owned double[num_envs, 2] buffers used alternately, call by call, starting with rec0 (a collective still reading one
- * buffer while the next step fills the other) -- so that the exchange costs the step's stream no packing kernel.  reward_dev /
- * done_dev are written as always.  NULL, NULL unbinds; kmanip_step_chunk does not write records.  Returns the index (0 / 1) of the
- * buffer the NEXT kmanip_step will fill, or -1. */
+ * ranks (gym_kmanip_amd/dist.py).  Bound here, every kmanip_step writes that record itself into ONE of two
+ * caller-owned double[num_envs, 2] buffers -- the one chosen by kmanip_select_reward_done_record (rec0 after the bind) -- so that
+ * the exchange costs the step's stream no packing kernel.  reward_dev / done_dev are written as always.  NULL, NULL unbinds;
+ * kmanip_step_chunk does not write records.
+ * ORDERING INVARIANT (the caller's): a collective that still READS buffer b must have completed -- or the step's stream must have
+ * been made to wait for it -- BEFORE the kmanip_step that fills b is enqueued; two buffers only mean that step k may overlap
+ * the exchange of step k-1, not that no wait is needed (dist.RewardDoneGather.before_step).  The library keeps no counter of
+ * its own: a step without an exchange (evaluation, a failed launch) cannot put the two sides out of phase. */
 int kmanip_bind_reward_done_record(KHandle h, double* rec0_dev, double* rec1_dev);
+/* index 0 / 1: the bound buffer the following kmanip_step calls fill. */
+int kmanip_select_reward_done_record(KHandle h, int index);
+
+/* KManipTask.get_observation + get_reward (env_sim.py:110-179) of every env's CURRENT state, without stepping -- what
+ * dm_control evaluates after a physics.forward(): obs_dev double[num_envs, obs_dim], reward_dev double[num_envs] (either may be
+ * NULL); the contact masks kmanip_get_diag returns are refreshed too.  Used by the parity tests against fixtures made from the
+ * reference's own Python (tests/golden/ref_obs_*.npz) and by callers that restore a checkpoint with kmanip_set_state. */
+int kmanip_observe(KHandle h, double* obs_dev, double* reward_dev, void* stream);
 
 /* KManipEnv.reset(seed=...) (env_base.py:219-220): re-key the cube-spawn stream.  restart_episodes != 0 also rewinds every
  * env's episode counter so that the next kmanip_reset draws episode 0 of the new seed (reset(seed=s) is then reproducible). */

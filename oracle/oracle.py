@@ -194,6 +194,39 @@ class Oracle:
         assert n >= 0
         return t[:n], fl[:n]
 
+    # ---- pieces used by tests/tools/refrun.py (the reference's own Python running over this physics)
+    def physics_step(self, qpos, qvel, ctrl, warm, qpos_step1, nsub):
+        """dm_control Physics.step(nsub), legacy order, for ONE env.  Returns (qpos, qvel, warm, bad, mask, touch_finger_cube,
+        touch_cube_table)."""
+        st = KoState()
+        nq, nv, nu = self.cm.nq, self.cm.nv, self.cm.nu
+        st.qpos[:nq] = list(qpos); st.qvel[:nv] = list(qvel); st.ctrl[:nu] = list(ctrl); st.qacc_warm[:nv] = list(warm)
+        mask = C.c_uint32(); tf = C.c_int32(); tt = C.c_int32()
+        bad = self.L.ko_physics_step(C.byref(self.desc), C.byref(st), _p(_f64(qpos_step1)), int(nsub), C.byref(mask),
+                                     C.byref(tf), C.byref(tt))
+        return (np.array(st.qpos[:nq]), np.array(st.qvel[:nv]), np.array(st.qacc_warm[:nv]), int(bad), mask.value,
+                tf.value, tt.value)
+
+    def after_reset(self, qpos, qvel, ctrl):
+        """mj_forward with actuation disabled: returns qacc_warmstart."""
+        st = KoState()
+        nq, nv, nu = self.cm.nq, self.cm.nv, self.cm.nu
+        st.qpos[:nq] = list(qpos); st.qvel[:nv] = list(qvel); st.ctrl[:nu] = list(ctrl)
+        self.L.ko_after_reset(C.byref(self.desc), C.byref(st))
+        return np.array(st.qacc_warm[:nv])
+
+    def contact_mask(self, qpos):
+        mask = C.c_uint32(); tf = C.c_int32(); tt = C.c_int32()
+        self.L.ko_contact_mask(C.byref(self.desc), _p(_f64(qpos)), C.byref(mask), C.byref(tf), C.byref(tt))
+        return mask.value, tf.value, tt.value
+
+    def observe(self, qpos, qvel):
+        """(get_observation's state keys, get_reward) at a state: env_sim.py:110-179."""
+        obs = np.zeros(self.cm.obs_dim)
+        rew = C.c_double()
+        self.L.ko_observe(C.byref(self.desc), _p(_f64(qpos)), _p(_f64(qvel)), _p(obs), C.byref(rew))
+        return obs, rew.value
+
     def render_depth(self, qpos, cam=0, h=64, w=64):
         out = np.zeros((h, w), dtype=np.float32)
         self.L.ko_render_depth(C.byref(self.desc), _p(_f64(qpos)), cam, h, w, _p(out, C.c_float))

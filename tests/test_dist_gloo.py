@@ -65,3 +65,100 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         obs, rew, done = ref.step(act_all)
         assert np.array_equal(got["rew"][k], rew), k
         assert np.array_equal(got["done"][k], done), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The bound-record ordering invariant (include/kmanip.h, dist.RewardDoneGather.before_step): a LAZY fake collective -- it
+# reads its input only when somebody waits for it, i.e. as late as a lagging RCCL peer may make the real one -- and a fake
+# bound engine that, like k_step, writes the selected record buffer inside its "launch".
+class _LazyWork:
+    def __init__(self, out, inp, world, log, tag):
+        self.out, self.inp, self.world, self.log, self.tag, self.done = out, inp, world, log, tag, False
+
+    def wait(self):
+        if not self.done:
+            self.log.append(("wait", self.tag))
+            self.out.copy_(self.inp.repeat(self.world, 1))        # reads the record buffer NOW
+            self.done = True
+
+
+class _LazyDist:
+    def __init__(self, world, log):
+        self.world, self.log, self.n = world, log, 0
+
+    def get_backend(self):
+        return "fake"
+
+    def all_gather_into_tensor(self, out, inp, async_op=False):
+        w = _LazyWork(out, inp, self.world, self.log, self.n)
+        self.n += 1
+        if not async_op:
+            w.wait()
+        return w
+
+
+class _BoundEngine:
+    """Stands for KManipEnvHip: bind_reward_done_record / select_reward_done_record / a step that writes the selected buffer."""
+
+    def __init__(self, n, log):
+        self.n, self.log, self.rec, self.sel, self.k = n, log, None, 0, 0
+
+    def bind_reward_done_record(self, r0, r1):
+        self.rec, self.sel = (r0, r1), 0
+
+    def select_reward_done_record(self, i):
+        self.sel = i
+
+    def step(self):
+        import torch
+        self.log.append(("write", self.sel, self.k))
+        self.rec[self.sel][:, 0] = torch.arange(self.n, dtype=torch.float64) + 1000.0 * self.k      # reward of step k
+        self.rec[self.sel][:, 1] = float(self.k % 2)
+        self.k += 1
+
+
+def test_bound_record_is_not_overwritten_before_its_gather_completed():
+    import torch
+    n, world, steps = 6, 2, 9
+    log = []
+    g = RewardDoneGather(n, world, torch.device("cpu"), _LazyDist(world, log))
+    eng = _BoundEngine(n, log)
+    g.bind(eng)
+    got = []
+    prev = None
+    for k in range(steps):                      # bench.py's loop: pipelined, nobody consumes a result before the next step
+        g.before_step()
+        eng.step()
+        b = g.post()
+        if prev is not None and k % 3 == 0:     # (a learner that only looks now and then)
+            got.append((k - 1, g.result(prev)[0].clone()))
+        prev = b
+    g.wait()
+    # every collective read its record before the step that reuses the buffer wrote it: wait(tag j) precedes write(., j + 2)
+    pos = {e: i for i, e in enumerate(log)}
+    for j in range(steps - 2):
+        assert pos[("wait", j)] < pos[("write", j & 1, j + 2)], (j, log)
+    for k, r in got:                            # and what was gathered for step k IS step k's reward
+        assert torch.equal(r, (torch.arange(n, dtype=torch.float64) + 1000.0 * k).repeat(world)), k
+    # the final buffers hold the last two steps
+    assert torch.equal(g.result((steps - 1) & 1)[0][:n], torch.arange(n, dtype=torch.float64) + 1000.0 * (steps - 1))
+    assert torch.equal(g.result((steps - 2) & 1)[0][:n], torch.arange(n, dtype=torch.float64) + 1000.0 * (steps - 2))
+
+
+def test_a_step_without_an_exchange_keeps_the_two_sides_in_phase():
+    """the engine used to flip its own buffer parity on every step, so one evaluation step without a post() made
+    every later post() gather the stale buffer.  The engine keeps no counter now: before_step() selects the buffer."""
+    import torch
+    n, world = 4, 2
+    log = []
+    g = RewardDoneGather(n, world, torch.device("cpu"), _LazyDist(world, log))
+    eng = _BoundEngine(n, log)
+    g.bind(eng)
+    for k in range(5):
+        if k == 2:
+            eng.step()                           # an extra step nobody exchanges (its record is overwritten by the next step)
+        g.before_step()
+        eng.step()
+        b = g.post()
+        r, _ = g.result(b)
+        assert torch.equal(r[:n], torch.arange(n, dtype=torch.float64) + 1000.0 * (eng.k - 1)), k

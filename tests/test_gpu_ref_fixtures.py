@@ -1,0 +1,135 @@
+"""The HIP path (through the C ABI) against fixtures made by running the REFERENCE'S OWN PYTHON in the build container
+(tests/golden/ref_*.npz: tests/tools/make_golden_ref.py over tests/tools/refrun.py; only the .npz data travels to the GPU box).
+
+What the fixtures pin to the reference itself -- not to the builder's reading of it -- is everything gym-kmanip's own files
+compute: before_step's grip / EE-delta / joint-delta decode incl. NumPy's float32/float64 promotions, ik()/ik_res/ik_jac over
+the real scipy.optimize.least_squares, get_observation, get_reward (incl. the touch / lift branch), initialize_episode and the
+k_step tuple.  MuJoCo's mj_step under them is the oracle's restatement.
+
+Tolerances as in test_gpu_parity.py: IK 1e-6 rad vs SciPy; one control step from the fixture's state: qpos 1e-6 (IK-limited),
+qvel 1e-5, obs / reward 1e-6; ctrl float32-quantised and bit-exact up to a counted 1-ulp straddle; masks / status exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ENVS3, GOLDEN
+from gym_kmanip_amd.model import compile_model
+from test_ref_fixtures import FAMILY, RUN_IDS, obs_columns
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(env_id, n, **kw):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from gym_kmanip_amd import env_hip
+    cm = compile_model(env_id, **kw)
+    return cm, env_hip.KManipEnvHip(cm, num_envs=n, seed=0), torch
+
+
+def _ref(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.mark.parametrize("env_id", RUN_IDS)
+def test_hip_step_vs_reference_run(env_id):
+    r = _ref("ref_run_%s.npz" % env_id)
+    T = len(r["action"])
+    cm, dev, torch = _dev(env_id, T, auto_reset=False)
+    dev.set_state(r["pre_qpos"], r["pre_qvel"], r["pre_ctrl"], r["pre_warm"], r["pre_step"])
+    dev.step_flat(torch.from_numpy(r["action"]).cuda())
+    q, v, c, w, s = dev.get_state()
+    mask, nfev, st = dev.get_diag()
+    obs, rew, done = dev.obs.cpu().numpy(), dev.reward.cpu().numpy(), dev.done.cpu().numpy()
+    flips = c != r["ctrl_set"]
+    if flips.any():
+        ulp = np.spacing(np.abs(r["ctrl_set"][flips]).astype(np.float32)).astype(np.float64)
+        assert (np.abs(c[flips] - r["ctrl_set"][flips]) <= ulp).all() and flips.sum() <= 2, flips.sum()
+    assert np.abs(q - r["post_qpos"]).max() < 1e-6 and np.abs(v - r["post_qvel"]).max() < 1e-5
+    assert np.abs(obs[:, obs_columns(cm)] - r["obs"]).max() < 1e-6 and np.abs(rew - r["reward"]).max() < 1e-6
+    assert np.array_equal(mask, r["contact_mask"])
+    assert np.array_equal(st, r["ik_status"]) and np.abs(nfev - r["ik_nfev"]).max() <= 1
+    assert np.array_equal(done & 1, (r["pre_step"] + 1 >= cm.desc.max_episode_steps).astype(np.uint8)) and not (done & 2).any()
+    assert np.array_equal(s, r["pre_step"] + 1)
+    for name, (h, wd) in (("grip_r", (40, 60)), ("grip_l", (40, 60))):       # the *Vision ids' small camera observations
+        if "img_" + name in r.files:
+            img = dev.render_rgb(name, h, wd).cpu().numpy().astype(int)
+            d = np.abs(img - r["img_" + name].astype(int))
+            assert (d > 1).mean() < 2e-3, (name, (d > 1).mean())             # one grey level; silhouette-grazing rays excepted
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_hip_ik_vs_reference(env):
+    g = _ref("ref_ik_%s.npz" % FAMILY[env])
+    cm, dev, torch = _dev(env, 1)
+    nf_mismatch = 0
+    for arm in range(2):
+        sel = np.where(g["arm"] == arm)[0]
+        if len(sel) == 0:
+            continue
+        n = cm.desc.arm_nq[arm]
+        m = 6 + 2 * n
+        q, qp_after, nfev, st = dev.ik(arm, g["qpos"][sel], g["goal_pos"][sel], g["goal_quat"][sel])
+        assert np.abs(q - g["q_out"][sel][:, :n]).max() < 1e-6 and np.abs(qp_after - g["qpos_after"][sel]).max() < 1e-6
+        nf_mismatch += int((nfev != g["nfev"][sel]).sum())
+        failed = g["status"][sel] == -2
+        assert np.array_equal(st[failed], g["status"][sel][failed]) and (nfev[failed] == 0).all()
+        res, jac = dev.ik_eval(arm, g["qpos"][sel], g["goal_pos"][sel], g["goal_quat"][sel])
+        assert np.abs(res - g["res0"][sel][:, :m]).max() < 1e-12
+        assert np.abs(jac.reshape(len(sel), -1) - g["jac0"][sel][:, :m * n]).max() < 1e-12
+    assert nf_mismatch <= 3, nf_mismatch
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_hip_observe_vs_reference(env):
+    """kmanip_observe (get_observation + get_reward of the current state) on the reference's seeded states: every clip."""
+    g = _ref("ref_obs_%s.npz" % FAMILY[env])
+    n = len(g["qpos"])
+    cm, dev, torch = _dev(env, n)
+    dev.set_state(g["qpos"], g["qvel"])
+    obs, rew = dev.observe()
+    assert np.abs(obs.cpu().numpy() - g["obs"]).max() < 1e-12
+    assert np.abs(rew.cpu().numpy() - g["reward"]).max() < 1e-12
+    assert np.array_equal(dev.get_diag()[0], g["contact_mask"])
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env", ENVS3)
+def test_hip_touch_lift_reward_vs_reference(env):
+    g = _ref("ref_touch_%s.npz" % FAMILY[env])
+    n = len(g["qpos"])
+    cm, dev, torch = _dev(env, n, touch_reward=True)
+    dev.set_state(g["qpos"], g["qvel"])
+    _, rew = dev.observe()
+    assert np.abs(rew.cpu().numpy() - g["reward"]).max() < 1e-12
+    assert np.array_equal(dev.get_diag()[0], g["contact_mask"])
+    assert {int(x) for x in np.floor(g["reward"])} == {0, 1, 2}
+    dev.k_close()
+    cm, dev, torch = _dev(env, n, touch_reward=False)                        # the reference as shipped: dead terms
+    dev.set_state(g["qpos"], g["qvel"])
+    assert (dev.observe()[1].cpu().numpy() < 1.0).all()
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env_id", ["KManipSoloArm", "KManipDualArmQPos", "KManipTorso"])
+def test_hip_reset_vs_reference_run(env_id):
+    """kmanip_reset against initialize_episode as the reference ran it: home pose in qpos and ctrl, zero velocity, the cube
+    at its qpos0 orientation inside the spawn box (its xyz comes from Philox here, from NumPy's global stream there:
+    DESIGN.md section 4 deviation 2), and -- with the fixture's spawn put in -- the reference's first observation and warm start."""
+    r = _ref("ref_run_%s.npz" % env_id)
+    E = len(r["reset_qpos"])
+    cm, dev, torch = _dev(env_id, E)
+    dev.k_reset()
+    q, v, c, w, s = dev.get_state()
+    nl = cm.nlink
+    assert np.array_equal(q[:, :nl], r["reset_qpos"][:, :nl]) and np.array_equal(c, r["reset_ctrl"]) and not v.any()
+    assert np.array_equal(q[:, nl + 3:], r["reset_qpos"][:, nl + 3:])
+    lo = np.array([cm.desc.cube_spawn_lo[k] for k in range(3)]); hi = np.array([cm.desc.cube_spawn_hi[k] for k in range(3)])
+    assert (q[:, nl:nl + 3] >= lo).all() and (q[:, nl:nl + 3] <= hi).all()
+    dev.set_state(r["reset_qpos"], r["reset_qvel"], r["reset_ctrl"])
+    obs, _ = dev.observe()
+    assert np.abs(obs.cpu().numpy()[:, obs_columns(cm)] - r["reset_obs"]).max() < 1e-12
+    dev.k_close()

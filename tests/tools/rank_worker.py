@@ -39,12 +39,21 @@ def main():
     g.bind(env)                                                         # the step writes the packed record itself (as bench.py runs it)
     gen = torch.Generator(); gen.manual_seed(1234)                      # CPU generator: the same stream on every rank
     rew, done = [], []
-    for k in range(a.steps):
-        act_all = torch.rand((a.total, env.cm.act_dim), generator=gen) * 2 - 1
-        env.step_flat(act_all[lo:hi].contiguous().cuda())
-        b = g.post(env.reward, env.done)
+
+    def take(b):
         r_all, d_all = g.result(b)
         rew.append(r_all.cpu().numpy().copy()); done.append(d_all.cpu().numpy().copy())
+
+    prev = None
+    for k in range(a.steps):
+        act_all = torch.rand((a.total, env.cm.act_dim), generator=gen) * 2 - 1
+        g.before_step()                                                 # (ordering invariant: gym_kmanip_amd/dist.py)
+        env.step_flat(act_all[lo:hi].contiguous().cuda())
+        b = g.post(env.reward, env.done)
+        if prev is not None:                                            # pipelined like bench.py: step k's exchange is in
+            take(prev)                                                  # flight while step k-1's result is consumed
+        prev = b
+    take(prev)
     st = env.get_state()
     np.savez(os.path.join(a.out, "rank%d.npz" % rank), rew=np.array(rew), done=np.array(done), obs=env.obs.cpu().numpy(),
              qpos=st[0], qvel=st[1], ctrl=st[2], lo=lo, hi=hi)
