@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--solver-iterations", type=int, default=100, help="solver iteration cap (MuJoCo default 100); ablation only")
     ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
                     help="newton = MuJoCo default, what the reference runs; pgs = the north star's named solver (100 sweeps)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (phase-locked, PGS, chunked, seam)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (long window, phase-locked, PGS, chunked, seam, the other BASELINE configs)")
     ap.add_argument("--chunk", type=int, default=16, help="also time kmanip_step_chunk with this many control steps per launch (0: skip)")
     return ap.parse_args(argv)
 
@@ -353,6 +353,61 @@ def measure_seam(torch, w, steps=256):
             "ratio_to_step_flat": dt_flat / dt_seam}
 
 
+def measure_config(torch, env_id, n, local_rank, steps, warmup, depth=0, solver="newton"):
+    """One short driver-clocked line for another BASELINE config on this GPU: the same desynchronised preparation, `steps` timed
+    control steps (wall clock around them, HIP events on the launch stream around the kernels), its own roofline figures."""
+    w = Workload(torch, env_id, n, local_rank, 0, 0, solver, 100, stagger=True)
+    env, cm = w.env, w.cm
+    if depth:
+        env.bind_step_depth("grip_r", depth, depth)
+    rgb_bufs = {c: env.render_rgb(c) for c in cm.cameras}
+    rgb_ev = []
+
+    def one():
+        w.step()
+        if rgb_bufs:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for c, buf in rgb_bufs.items():
+                env.render_rgb(c, out=buf)
+            e1.record()
+            rgb_ev.append((e0, e1))
+
+    w.lay_out(warmup + steps)
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    env.enable_timing(True)
+    del rgb_ev[:]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ik_ms, dyn_ms, rnd_ms, nt = env.timing_summary()
+    env.enable_timing(False)
+    if rgb_ev:
+        rnd_ms = sum(a.elapsed_time(b) for a, b in rgb_ev[:nt]) if nt else 0.0
+    bpe = algorithmic_bytes_per_env_step(cm, depth, rgb=bool(rgb_bufs))
+    kern_s = (dyn_ms + rnd_ms) / max(nt, 1) * 1e-3
+    achieved = bpe * n / kern_s / 1e9
+    w.close()
+    return {"workload": "%s, %d envs, 1 GPU%s, desynchronised" % (env_id, n, (", %dx%d float32 grip_r depth in the step" % (depth, depth)) if depth else
+                                                                 ((", uint8 RGB cameras %s after the step" % "+".join(cm.cameras)) if rgb_bufs else "")),
+            "value": n * steps / dt, "unit": "env steps/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "bytes_per_env_step": bpe, "algorithmic_bytes_per_launch": bpe * n,
+                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launches_timed": nt}}}
+
+
+OTHER_CONFIGS = [   # BASELINE.json configs 3, 4 (one GPU's shard), 5 and the reference's own *Vision observation at config 5's width
+    ("config3_dualarm_8192", dict(env_id="KManipDualArm", n=8192, steps=40, warmup=8)),
+    ("config4_torso_8192_shard", dict(env_id="KManipTorso", n=8192, steps=40, warmup=8)),
+    ("config5_soloarm_2048_depth64", dict(env_id="KManipSoloArm", n=2048, steps=96, warmup=8, depth=64)),
+    ("vision_soloarm_2048", dict(env_id="KManipSoloArmVision", n=2048, steps=48, warmup=8)),
+]
+
+
 def run_rank(args):
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -518,10 +573,19 @@ def run_rank(args):
         if world == 1 and not args.no_variants:
             torch.cuda.synchronize()
             if not args.depth and not rgb_bufs:
+                if args.steps < 512 and not args.no_stagger:
+                    # the driver's window (20 steps) holds none of the rare IK crawls (one launch in ~40 runs 2-7x long, DESIGN.md
+                    # 3.4): the same handle, still desynchronised, over 512 further steps of the stream
+                    dtl = w.timed(512, 8)
+                    out["long_window"] = {"value": n * 512 / dtl, "unit": "env steps/s", "steps": 512, "ms_per_step": dtl / 512 * 1e3,
+                                          "note": "same handle and stream as `value`, 512 further desynchronised steps: includes the rare IK-crawl launches a 20-step window misses"}
                 out["seam_variant"] = measure_seam(torch, w)
                 if args.chunk > 1:
                     out["chunked_variant"] = measure_chunked(torch, w, args.chunk)
             w.close()
+            if headline and args.solver == "newton" and not args.no_stagger:
+                for name, kw in OTHER_CONFIGS:      # driver-clocked lines for the other BASELINE configs (never part of `value`)
+                    out[name] = measure_config(torch, local_rank=local_rank, **kw)
             if not args.no_stagger:
                 out["phase_locked"] = measure_variant(torch, args, n, local_rank, rank, args.solver, False, 4 * EPISODE, EPISODE)
                 out["phase_locked"]["note"] = "all envs reset together (what plain auto-reset stepping gives: episodes never end early); whole episodes timed"

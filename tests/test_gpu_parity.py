@@ -821,8 +821,8 @@ def test_table_rectangle_gpu():
 
 def test_bound_reward_done_record():
     """kmanip_bind_reward_done_record: every step also writes the packed (reward, done) record of the multi-GPU exchange into the
-    two bound buffers alternately, starting with the first; reward / done themselves are written as always; unbinding stops it; a
-    chunked launch writes no record."""
+    bound buffer the CALLER selected (kmanip_select_reward_done_record; the first after the bind) -- the library keeps no parity of
+    its own --; reward / done themselves are written as always; unbinding stops it; a chunked launch writes no record."""
     torch = _torch()
     from gym_kmanip_amd import env_hip
     from gym_kmanip_amd.lib import KManipError
@@ -834,9 +834,16 @@ def test_bound_reward_done_record():
         e.bind_reward_done_record(rec[0], None)
     e.bind_reward_done_record(rec[0], rec[1])
     saw_done = False
-    for k in range(5):
+    with pytest.raises(KManipError):
+        e.select_reward_done_record(2)
+    order = [0, 0, 1, 0, 1, 1]                 # any order: e.g. a step nobody exchanges does not flip anything
+    for k in range(6):
+        if k > 0:
+            e.select_reward_done_record(order[k])
+        other = rec[1 - order[k]].clone()
         e.step_flat(e.sample_action())
-        r = rec[k & 1].cpu().numpy()
+        assert torch.equal(rec[1 - order[k]], other)
+        r = rec[order[k]].cpu().numpy()
         assert np.array_equal(r[:, 0], e.reward.cpu().numpy()) and np.array_equal(r[:, 1], e.done.cpu().numpy().astype(np.float64)), k
         saw_done |= bool(e.done.cpu().numpy().any())
     assert saw_done

@@ -49,7 +49,8 @@ def test_hip_step_vs_reference_run(env_id):
     assert np.abs(q - r["post_qpos"]).max() < 1e-6 and np.abs(v - r["post_qvel"]).max() < 1e-5
     assert np.abs(obs[:, obs_columns(cm)] - r["obs"]).max() < 1e-6 and np.abs(rew - r["reward"]).max() < 1e-6
     assert np.array_equal(mask, r["contact_mask"])
-    assert np.array_equal(st, r["ik_status"]) and np.abs(nfev - r["ik_nfev"]).max() <= 1
+    ran = r["ik_status"] != -3                      # (-3 = no ik() call for that arm: the device leaves its diagnostics alone)
+    assert np.array_equal(st[ran], r["ik_status"][ran]) and (np.abs(nfev - r["ik_nfev"])[ran] <= 1).all()
     assert np.array_equal(done & 1, (r["pre_step"] + 1 >= cm.desc.max_episode_steps).astype(np.uint8)) and not (done & 2).any()
     assert np.array_equal(s, r["pre_step"] + 1)
     for name, (h, wd) in (("grip_r", (40, 60)), ("grip_l", (40, 60))):       # the *Vision ids' small camera observations

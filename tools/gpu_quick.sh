@@ -38,5 +38,5 @@ PY
 fi
 if [ -f gym_kmanip_amd/libkmanip_hip_prof.so ]; then
   KMANIP_LIB=gym_kmanip_amd/libkmanip_hip_prof.so python3 tools/phase_profile.py > $OUT/phase.txt 2> $OUT/phase.err || echo "phase profile failed"
-  grep "last launch" $OUT/phase.txt
+  grep "last launch" $OUT/phase.txt || true
 fi

@@ -79,6 +79,118 @@ __global__ __launch_bounds__(64) void build_mfma(const double* Jg, const double*
   for (int i = 0; i < NV; i++) Hg[((size_t)env * NV + i) * NV + sub] = H[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second A/B: the one contraction the north star names for MFMA -- the IK's J^T J.  ik_jac's dense part is
+// 6 x n (n = 7; the two regulariser blocks are 9e-3 I and add a constant to the diagonal), one problem per 16-lane DPP row,
+// lane c < 8 of the row holds COLUMN c of J (6 doubles) and wants ROW c of A = J^T J (7 doubles) -- what the cooperative
+// trust-region solve consumes (kmanip_ik_coop.hpp).
+//   A: what the product does -- per entry six v_fmac_f64_dpp (row_newbcast:j folded into the FMA), four problems per instruction.
+//   B: v_mfma_f64_16x16x4_f64 -- two problems per 16 x 16 tile (columns 0-6 and 8-14; the off-diagonal blocks are waste), K = 6
+//      padded to 8 = two issues per tile, two tiles per wave; operands to the MFMA layout (lane = 16 k + i) and the result back to
+//      row-per-lane through LDS.
+constexpr int JN = 7, JK = 6;
+__global__ __launch_bounds__(64) void jtj_dpp(const double* Jg, double* Ag, int iters) {
+  const int lane = threadIdx.x, c = lane & 15, prob = blockIdx.x * 4 + lane / 16;
+  double Jc[JK], A[JN];
+#pragma unroll
+  for (int k = 0; k < JK; k++) Jc[k] = c < JN ? Jg[((size_t)prob * JK + k) * 8 + c] : 0.0;
+  for (int it = 0; it < iters; it++) {
+    static_for<0, JN>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      double s = 0;
+      dppfma_acc3<j>(s, Jc[0], Jc[0], Jc[1], Jc[1], Jc[2], Jc[2]);
+      dppfma_acc3<j>(s, Jc[3], Jc[3], Jc[4], Jc[4], Jc[5], Jc[5]);
+      A[j] = s;
+    });
+    Jc[0] = fma(A[it % JN], 1e-300, Jc[0]);
+  }
+#pragma unroll
+  for (int j = 0; j < JN; j++) if (c < JN) Ag[((size_t)prob * 8 + c) * 8 + j] = A[j];
+}
+template <int LAYOUT>
+__global__ __launch_bounds__(64) void jtj_mfma(const double* Jg, double* Ag, int iters) {
+  __shared__ double sJ[2][8][16];       // [tile][k (padded to 8)][column: problem 2t -> 0..7, problem 2t+1 -> 8..15]
+  __shared__ double sA[2][16][16];
+  const int lane = threadIdx.x, c = lane & 15, p_own = lane / 16, prob = blockIdx.x * 4 + p_own;
+  double Jc[JK], A[JN];
+#pragma unroll
+  for (int k = 0; k < JK; k++) Jc[k] = c < JN ? Jg[((size_t)prob * JK + k) * 8 + c] : 0.0;
+  if (lane < 32) { sJ[lane / 16][6][lane & 15] = 0; sJ[lane / 16][7][lane & 15] = 0; }
+  for (int it = 0; it < iters; it++) {
+    if (c < 8) {
+#pragma unroll
+      for (int k = 0; k < JK; k++) sJ[p_own / 2][k][(p_own & 1) * 8 + c] = Jc[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      v4d acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const double a = sJ[t][4 * q + lane / 16][c];          // A operand: (J^T)[i = c][k]; B operand: J[k][j = c] -- the same number
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) sA[t][LAYOUT == 0 ? 4 * (lane / 16) + r : 4 * r + lane / 16][c] = acc[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < JN; j++) A[j] = sA[p_own / 2][(p_own & 1) * 8 + (c & 7)][(p_own & 1) * 8 + j];
+    Jc[0] = fma(A[it % JN], 1e-300, Jc[0]);
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int j = 0; j < JN; j++) if (c < JN) Ag[((size_t)prob * 8 + c) * 8 + j] = A[j];
+}
+static int jtj_ab() {
+  const int nblk = 1024, nprob = nblk * 4;
+  std::vector<double> J((size_t)nprob * JK * 8, 0.0), A((size_t)nprob * 64), Aref((size_t)64 * 64, 0.0);
+  srand(2);
+  for (int p = 0; p < nprob; p++) for (int k = 0; k < JK; k++) for (int c = 0; c < JN; c++) J[((size_t)p * JK + k) * 8 + c] = rand() / (double)RAND_MAX - 0.5;
+  for (int p = 0; p < 64; p++) for (int i = 0; i < JN; i++) for (int j = 0; j < JN; j++) {
+    double s = 0;
+    for (int k = 0; k < JK; k++) s += J[((size_t)p * JK + k) * 8 + i] * J[((size_t)p * JK + k) * 8 + j];
+    Aref[((size_t)p * 8 + i) * 8 + j] = s;
+  }
+  double *Jd, *Ad;
+  CK(hipMalloc(&Jd, J.size() * 8)); CK(hipMalloc(&Ad, A.size() * 8));
+  CK(hipMemcpy(Jd, J.data(), J.size() * 8, hipMemcpyHostToDevice));
+  auto check = [&](const char* name) {
+    CK(hipMemcpy(A.data(), Ad, A.size() * 8, hipMemcpyDeviceToHost));
+    double err = 0;
+    for (int p = 0; p < 64; p++) for (int i = 0; i < JN; i++) for (int j = 0; j < JN; j++)
+      err = fmax(err, fabs(A[((size_t)p * 8 + i) * 8 + j] - Aref[((size_t)p * 8 + i) * 8 + j]));
+    fprintf(stderr, "%s: max |A - host| on 64 problems = %.3e\n", name, err);
+    return err;
+  };
+  CK(hipMemset(Ad, 0, A.size() * 8));
+  hipLaunchKernelGGL(jtj_dpp, dim3(nblk), dim3(64), 0, 0, Jd, Ad, 1); CK(hipDeviceSynchronize());
+  const double errA = check("jtj dpp");
+  hipLaunchKernelGGL(jtj_mfma<0>, dim3(nblk), dim3(64), 0, 0, Jd, Ad, 1); CK(hipDeviceSynchronize());
+  const double e0 = check("jtj mfma layout 0");
+  hipLaunchKernelGGL(jtj_mfma<1>, dim3(nblk), dim3(64), 0, 0, Jd, Ad, 1); CK(hipDeviceSynchronize());
+  const double e1 = check("jtj mfma layout 1");
+  const int layout = e0 <= e1 ? 0 : 1;
+  hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+  auto timeit = [&](int which) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; rep++) {
+      CK(hipEventRecord(ev0));
+      if (which == 0) hipLaunchKernelGGL(jtj_dpp, dim3(nblk), dim3(64), 0, 0, Jd, Ad, ITER);
+      else if (layout == 0) hipLaunchKernelGGL(jtj_mfma<0>, dim3(nblk), dim3(64), 0, 0, Jd, Ad, ITER);
+      else hipLaunchKernelGGL(jtj_mfma<1>, dim3(nblk), dim3(64), 0, 0, Jd, Ad, ITER);
+      CK(hipEventRecord(ev1)); CK(hipEventSynchronize(ev1));
+      float ms; CK(hipEventElapsedTime(&ms, ev0, ev1)); best = fminf(best, ms);
+    }
+    return best;
+  };
+  const float msA = timeit(0), msB = timeit(1);
+  printf("{\"what\": \"IK normal matrix A = J^T J, J 6 x 7 (ik_jac's dense rows), one problem per DPP row (4 per wave), 1024 waves (1 per SIMD), %d dependent builds per wave\", "
+         "\"dpp_valu\": {\"ns_per_build\": %.1f, \"max_abs_err\": %.2e}, \"mfma_f64_16x16x4\": {\"ns_per_build\": %.1f, \"max_abs_err\": %.2e, \"tiles_per_wave\": 2, \"issues_per_tile\": 2}, "
+         "\"mfma_over_dpp\": %.3f}\n", ITER, 1e6 * msA / ITER, errA, 1e6 * msB / ITER, fmin(e0, e1), msB / msA);
+  return (errA < 1e-12 && fmin(e0, e1) < 1e-12) ? 0 : 2;
+}
+
 int main() {
   const int nblk = 1024, nenv = nblk * EPW;
   std::vector<double> J((size_t)nenv * R * NV), d((size_t)nenv * R), M((size_t)nenv * NV * NV), Href((size_t)nenv * NV * NV), H((size_t)nenv * NV * NV);
@@ -131,5 +243,6 @@ int main() {
          "\"dpp_valu\": {\"ns_per_build\": %.1f, \"max_abs_err\": %.2e}, \"mfma_f64_16x16x4\": {\"ns_per_build\": %.1f, \"max_abs_err\": %.2e, \"d_layout\": \"%s\"}, "
          "\"mfma_over_dpp\": %.3f}\n",
          R, ITER, 1e6 * msA / ITER, errA, 1e6 * msB / ITER, errB, layout == 0 ? "row = 4*(lane/16)+r" : "row = 4*r+lane/16", msB / msA);
-  return (errA < 1e-9 && errB < 1e-9) ? 0 : 2;
+  const int rc2 = jtj_ab();
+  return (errA < 1e-9 && errB < 1e-9) ? rc2 : 2;
 }
