@@ -368,8 +368,7 @@ def measure_config(torch, env_id, n, local_rank, steps, warmup, depth=0, solver=
         if rgb_bufs:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            for c, buf in rgb_bufs.items():
-                env.render_rgb(c, out=buf)
+            env.render_cameras(out=rgb_bufs)         # all cameras of the observation in one launch
             e1.record()
             rgb_ev.append((e0, e1))
 
@@ -479,8 +478,7 @@ def run_rank(args):
         if rgb_bufs:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            for c, buf in rgb_bufs.items():
-                env.render_rgb(c, out=buf)
+            env.render_cameras(out=rgb_bufs)         # all cameras of the observation in one launch
             e1.record()
             rgb_ev.append((e0, e1))
         if gather is not None:

@@ -140,6 +140,19 @@ static int build_aux(const KModelDesc* d, KModelAux* x, std::string& err) {
     }
   }
   if (x->split != 0 && x->split != 10 && x->split != 11) { err = "internal: block split other than 10 / 11"; return -1; }
+  for (int i = 0; i < d->nlink; i++) {
+    double q[4] = {d->link_quat[i][0], d->link_quat[i][1], d->link_quat[i][2], d->link_quat[i][3]};
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (!(n > 0)) { err = "zero link quaternion"; return -1; }
+    for (int c = 0; c < 4; c++) q[c] /= n;
+    h_quat2mat(q, x->link_R[i]);
+  }
+  for (int c = 0; c < KM_MAX_CAMS; c++) x->cam_tanhalf[c] = d->cam_present[c] ? tan(0.5 * d->cam_fovy[c] * (M_PI / 180.0)) : 1.0;
+  for (int s = 0; s < d->nsphere; s++)
+    if (d->sphere_visible[s]) {
+      if (x->nvis == KM_RENDER_MAXVIS) { err = "the camera renders draw at most 4 visible spheres (the finger tips)"; return -1; }
+      x->vis_sphere[x->nvis++] = s;
+    }
   for (int a = 0; a < KM_MAX_ARMS; a++) {
     if (!d->arm_present[a]) continue;
     int chain[KM_MAX_LINKS], n = 0;
@@ -298,14 +311,25 @@ int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_
   return 0;
 }
 
-int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint8_t* rgb_dev, void* stream) {
+int kmanip_render_rgb_multi(KHandle h, int ncam, const int* cams, const int* heights, const int* widths, uint8_t* const* rgb_dev,
+                            void* stream) {
   if (!h) { g_create_error = "kmanip_render_rgb: null handle"; return -1; }
-  if (!rgb_dev || cam < 0 || cam >= KM_MAX_CAMS || height <= 0 || width <= 0) { h->err = "kmanip_render_rgb: bad arguments"; return -1; }
-  if (!h->desc.cam_present[cam]) { h->err = "kmanip_render_rgb: this model has no such camera"; return -1; }
+  if (ncam <= 0 || ncam > KM_MAX_CAMS || !cams || !heights || !widths || !rgb_dev) { h->err = "kmanip_render_rgb: bad arguments"; return -1; }
+  KRenderJobs jobs;
+  jobs.n = ncam;
+  for (int i = 0; i < ncam; i++) {
+    if (!rgb_dev[i] || cams[i] < 0 || cams[i] >= KM_MAX_CAMS || heights[i] <= 0 || widths[i] <= 0) { h->err = "kmanip_render_rgb: bad arguments"; return -1; }
+    if (!h->desc.cam_present[cams[i]]) { h->err = "kmanip_render_rgb: this model has no such camera"; return -1; }
+    jobs.cam[i] = cams[i]; jobs.height[i] = heights[i]; jobs.width[i] = widths[i]; jobs.rgb[i] = rgb_dev[i];
+  }
   KM_ENTER(h);
-  kmanip_launch_render_rgb(h->dmodel, h->st, cam, height, width, rgb_dev, (hipStream_t)stream);
+  kmanip_launch_render_rgb(h->dmodel, h->st, jobs, (hipStream_t)stream);
   HIPCHK(h, hipGetLastError());
   return 0;
+}
+
+int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint8_t* rgb_dev, void* stream) {
+  return kmanip_render_rgb_multi(h, 1, &cam, &height, &width, &rgb_dev, stream);
 }
 
 int kmanip_bind_step_depth(KHandle h, int cam, int height, int width, float* depth_dev) {

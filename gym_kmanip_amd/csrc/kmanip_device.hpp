@@ -28,7 +28,13 @@ struct KModelAux {
   int32_t chain_xidx[KM_MAX_ARMS][KM_MAX_CHAIN];  // index into the IK unknowns, -1 = fixed at current qpos
   double chain_R[KM_MAX_ARMS][KM_MAX_CHAIN][9];   // constant rotation of each chain link in its parent (from link_quat)
   double site_R[KM_MAX_ARMS][9];                  // constant rotation of the EE site in its link
+  // camera renders (kmanip_render.hip): per-model constants every workgroup would otherwise recompute from the desc
+  double link_R[KM_MAX_LINKS][9];                 // constant rotation of each link in its parent (from link_quat, normalised)
+  double cam_tanhalf[KM_MAX_CAMS];                // tan(fovy / 2)
+  int32_t nvis;                                   // visible spheres (the finger tips), at most KM_RENDER_MAXVIS
+  int32_t vis_sphere[4];
 };
+#define KM_RENDER_MAXVIS 4
 
 struct KDeviceModel {
   KModelDesc d;
@@ -425,7 +431,8 @@ void kmanip_launch_observe(const KDeviceModel* dm, const KModelDesc& hd, const K
                            hipStream_t stream);
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
                                 hipStream_t stream);
-void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, uint8_t* rgb,
-                              hipStream_t stream);
+// up to KM_MAX_CAMS camera images of every env in ONE launch (grid = envs x jobs): the *Vision observation
+struct KRenderJobs { int n; int cam[KM_MAX_CAMS], height[KM_MAX_CAMS], width[KM_MAX_CAMS]; uint8_t* rgb[KM_MAX_CAMS]; };
+void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, const KRenderJobs& jobs, hipStream_t stream);
 void kmanip_launch_scripted_action(const KDeviceModel* dm, const KDeviceState& st, float* act, hipStream_t stream);
 void kmanip_launch_sample_action(const KDeviceModel* dm, const KDeviceState& st, float* act, int ahead, hipStream_t stream);

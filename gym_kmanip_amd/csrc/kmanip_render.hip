@@ -16,8 +16,8 @@
 //
 // One workgroup (256 lanes) per env.  Forward kinematics run one link per lane with ceil(log2(depth)) rounds of pointer
 // jumping through LDS (the same scheme as k_step's fk_parallel), lane 0 builds the camera frame, then the lanes ray-cast.
-//   depth (k_render_depth): pixels p = lane, lane + 256, ...; float64 ray maths -- the depth parity bar against the float64
-//     oracle is 1e-6 m, which float32 intersection arithmetic (cancellation ~1e-5 m) would not meet.
+//   depth (k_render_depth): 128 lanes per env, pixels p = lane, lane + 128, ...; float64 ray maths -- the depth parity bar
+//     against the float64 oracle is 1e-6 m, which float32 intersection arithmetic (cancellation ~1e-5 m) would not meet.
 //   rgb (k_render_rgb, round 3): the *Vision observations are 480 x 640 x 3 + 40 x 60 x 3 bytes per env-step (__init__.py:
 //     158-161), 929 KB -- the one genuinely HBM-sized output of the path.  Round 2 cast every pixel in float64 (~150 FP64
 //     operations per pixel: 5 x the time the stores need) and wrote three separate bytes per pixel.  Now: (1) float32 ray
@@ -27,6 +27,7 @@
 //     three dwords (768 contiguous bytes per wave-instruction group); (4) the per-ray divides of the slab and plane tests are
 //     v_rcp_f32 on quantities that are linear in the pixel coordinates.
 #include "kmanip_device.hpp"
+#include <stdlib.h>
 
 struct RenderScene {
   real xpos[KM_MAX_LINKS][3], xmat[KM_MAX_LINKS][9];
@@ -43,9 +44,7 @@ __device__ __forceinline__ void render_fk(const KDeviceModel* dm, const KDeviceS
   const bool on = i < nl;
   real R[9], p[3];
   if (on) {
-    real Rl[9], q4[4] = {m->link_quat[i][0], m->link_quat[i][1], m->link_quat[i][2], m->link_quat[i][3]};
-    normalize4(q4);
-    quat2mat(Rl, q4);
+    const double* Rl = dm->x.link_R[i];                 // (normalised link_quat as a matrix: built once per model on the host)
     p[0] = m->link_pos[i][0]; p[1] = m->link_pos[i][1]; p[2] = m->link_pos[i][2];
     const real q = st.qpos[(size_t)i * NE + env];
     if (m->jnt_type[i] == KM_JNT_SLIDE) {
@@ -54,7 +53,7 @@ __device__ __forceinline__ void render_fk(const KDeviceModel* dm, const KDeviceS
       p[0] += Rl[2] * q; p[1] += Rl[5] * q; p[2] += Rl[8] * q;
     } else {
       real sn, cs;
-      sincos(q, &sn, &cs);
+      km_sincos(q, &sn, &cs);
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         R[3 * a] = cs * Rl[3 * a] + sn * Rl[3 * a + 1];
@@ -94,123 +93,42 @@ __device__ __forceinline__ void render_fk(const KDeviceModel* dm, const KDeviceS
   }
 }
 
+// Per-env scene after the FK: lane 0 builds the camera frame (mj_camlight, targetbody) and the cube pose, lanes 64.. one sphere
+// centre each (another wave: in parallel with lane 0).  Caller synchronises afterwards.
 __device__ __forceinline__ void render_camera(const KDeviceModel* dm, const KDeviceState& st, int env, int cam, int height, RenderScene* sc) {
   const KModelDesc* m = &dm->d;
-  const int nl = m->nlink, NE = st.num_envs;
-  // camera frame (mj_camlight, targetbody): z = (cam - target)/|.|, x = (0,0,1) x z, y = z x x; a link of -1 = world frame
-  const int cl = m->cam_link[cam], tl = m->cam_target_link[cam];
-  real co[3], to[3], t[3];
-  real cp[3] = {m->cam_pos[cam][0], m->cam_pos[cam][1], m->cam_pos[cam][2]};
-  real tp[3] = {m->cam_target_pos[cam][0], m->cam_target_pos[cam][1], m->cam_target_pos[cam][2]};
-  if (cl < 0) { co[0] = cp[0]; co[1] = cp[1]; co[2] = cp[2]; }
-  else { mat_vec3(t, sc->xmat[cl], cp); co[0] = sc->xpos[cl][0] + t[0]; co[1] = sc->xpos[cl][1] + t[1]; co[2] = sc->xpos[cl][2] + t[2]; }
-  if (tl < 0) { to[0] = tp[0]; to[1] = tp[1]; to[2] = tp[2]; }
-  else { mat_vec3(t, sc->xmat[tl], tp); to[0] = sc->xpos[tl][0] + t[0]; to[1] = sc->xpos[tl][1] + t[1]; to[2] = sc->xpos[tl][2] + t[2]; }
-  real z[3] = {co[0] - to[0], co[1] - to[1], co[2] - to[2]}, up[3] = {0, 0, 1}, x[3], y[3];
-  normalize3(z);
-  cross3(x, up, z); normalize3(x);
-  cross3(y, z, x); normalize3(y);
-  for (int c = 0; c < 3; c++) { sc->cam_o[c] = co[c]; sc->cam_x[c] = x[c]; sc->cam_y[c] = y[c]; sc->cam_z[c] = z[c]; }
-  sc->focal = (0.5 * height) / tan(0.5 * m->cam_fovy[cam] * (M_PI / 180.0));
-  real cq[4];
-  for (int c = 0; c < 3; c++) sc->cube_p[c] = st.qpos[(size_t)(nl + c) * NE + env];
-  for (int c = 0; c < 4; c++) cq[c] = st.qpos[(size_t)(nl + 3 + c) * NE + env];
-  normalize4(cq);
-  quat2mat(sc->cube_R, cq);
-  for (int s = 0; s < m->nsphere; s++) {
-    const int l = m->sphere_link[s];
-    real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]};
-    mat_vec3(t, sc->xmat[l], sl);
-    sc->sph[s][0] = sc->xpos[l][0] + t[0]; sc->sph[s][1] = sc->xpos[l][1] + t[1]; sc->sph[s][2] = sc->xpos[l][2] + t[2];
-  }
-}
-
-// nearest hit of the ray o + t d with the surrogate scene: returns t (zfar if none), the surface normal and the material id
-// (0 = none, 1 = table, 2 = cube, 3 = finger sphere)
-__device__ __forceinline__ real cast_ray(const KModelDesc* m, const RenderScene& sc, const real* d, real zfar, real* nrm, int& mat) {
-  real best = zfar;
-  mat = 0;
-  nrm[0] = 0; nrm[1] = 0; nrm[2] = 1;
-  // table top: the rectangle table_rect at z = table_z (kmanip.h)
-  if (d[2] != 0) {
-    const real t = (m->table_z - sc.cam_o[2]) / d[2];
-    const real hx = sc.cam_o[0] + t * d[0], hy = sc.cam_o[1] + t * d[1];
-    if (t > 0 && t < best && hx >= m->table_rect[0] && hx <= m->table_rect[1] && hy >= m->table_rect[2] && hy <= m->table_rect[3]) { best = t; mat = 1; }
-  }
-  // cube box (slab test in the cube frame)
-  {
-    real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]}, ol[3], dl[3];
-    matT_vec3(ol, sc.cube_R, rel);
-    matT_vec3(dl, sc.cube_R, d);
-    real t0 = -INFINITY, t1 = INFINITY;
-    int a0 = 0, a1 = 0;
-    real s0 = 0, s1 = 0;
-    bool ok = true;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const real h = m->cube_half[a];
-      if (dl[a] != 0) {
-        real ta = (-h - ol[a]) / dl[a], tb = (h - ol[a]) / dl[a];
-        real sa = -1, sb = 1;                      // outward normal sign of the face each root lies on
-        if (ta > tb) { real s = ta; ta = tb; tb = s; sa = 1; sb = -1; }
-        if (ta > t0) { t0 = ta; a0 = a; s0 = sa; }
-        if (tb < t1) { t1 = tb; a1 = a; s1 = sb; }
-      } else if (ol[a] < -h || ol[a] > h) ok = false;
-    }
-    if (ok && t0 <= t1 && t1 > 0) {
-      const bool front = t0 > 0;
-      const real t = front ? t0 : t1;
-      if (t < best) {
-        best = t; mat = 2;
-        const int ax = front ? a0 : a1;
-        const real sg = front ? s0 : s1;
-        nrm[0] = sg * sc.cube_R[ax]; nrm[1] = sg * sc.cube_R[3 + ax]; nrm[2] = sg * sc.cube_R[6 + ax];
-      }
-    }
-  }
-  // finger spheres (the link spheres are collision-only surrogates: they would wall in the wrist cameras)
-  for (int s = 0; s < m->nsphere; s++) {
-    if (!m->sphere_visible[s]) continue;
-    real oc[3] = {sc.cam_o[0] - sc.sph[s][0], sc.cam_o[1] - sc.sph[s][1], sc.cam_o[2] - sc.sph[s][2]};
-    const real a = dot3(d, d), b = dot3(d, oc), cc = dot3(oc, oc) - m->sphere_radius[s] * m->sphere_radius[s];
-    const real disc = b * b - a * cc;
-    if (disc >= 0) {
-      real t = (-b - sqrt(disc)) / a;
-      if (t > 0 && t < best) {
-        best = t; mat = 3;
-        const real ir = 1.0 / m->sphere_radius[s];
-        nrm[0] = (oc[0] + t * d[0]) * ir; nrm[1] = (oc[1] + t * d[1]) * ir; nrm[2] = (oc[2] + t * d[2]) * ir;
-      }
-    }
-  }
-  return best;
-}
-
-__global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
-                                                      float* __restrict__ depth) {
-  __shared__ RenderScene sc;
-  const KModelDesc* m = &dm->d;
-  const int env = blockIdx.x;
-  render_fk(dm, st, env, &sc);
-  if (threadIdx.x == 0) render_camera(dm, st, env, cam, height, &sc);
-  __syncthreads();
-  const real zfar = m->cam_zfar, znear = m->cam_znear;
-  const int npix = height * width;
-  const real inv_f = 1.0 / sc.focal;
-  for (int p = threadIdx.x; p < npix; p += blockDim.x) {
-    const int r = p / width, c = p - r * width;
-    const real dx = (c + 0.5 - 0.5 * width) * inv_f, dy = -(r + 0.5 - 0.5 * height) * inv_f;
-    real d[3] = {sc.cam_x[0] * dx + sc.cam_y[0] * dy - sc.cam_z[0], sc.cam_x[1] * dx + sc.cam_y[1] * dy - sc.cam_z[1],
-                 sc.cam_x[2] * dx + sc.cam_y[2] * dy - sc.cam_z[2]};
-    real nrm[3];
-    int mat;
-    const real best = cast_ray(m, sc, d, zfar, nrm, mat);
-    depth[(size_t)env * npix + p] = (float)fmin(fmax(best, znear), zfar);
+  const int nl = m->nlink, NE = st.num_envs, t = threadIdx.x;
+  if (t == 0) {
+    // camera frame: z = (cam - target)/|.|, x = (0,0,1) x z, y = z x x; a link of -1 = world frame
+    const int cl = m->cam_link[cam], tl = m->cam_target_link[cam];
+    real co[3], to[3], v[3];
+    real cp[3] = {m->cam_pos[cam][0], m->cam_pos[cam][1], m->cam_pos[cam][2]};
+    real tp[3] = {m->cam_target_pos[cam][0], m->cam_target_pos[cam][1], m->cam_target_pos[cam][2]};
+    if (cl < 0) { co[0] = cp[0]; co[1] = cp[1]; co[2] = cp[2]; }
+    else { mat_vec3(v, sc->xmat[cl], cp); co[0] = sc->xpos[cl][0] + v[0]; co[1] = sc->xpos[cl][1] + v[1]; co[2] = sc->xpos[cl][2] + v[2]; }
+    if (tl < 0) { to[0] = tp[0]; to[1] = tp[1]; to[2] = tp[2]; }
+    else { mat_vec3(v, sc->xmat[tl], tp); to[0] = sc->xpos[tl][0] + v[0]; to[1] = sc->xpos[tl][1] + v[1]; to[2] = sc->xpos[tl][2] + v[2]; }
+    real z[3] = {co[0] - to[0], co[1] - to[1], co[2] - to[2]}, up[3] = {0, 0, 1}, x[3], y[3];
+    normalize3_fast(z);
+    cross3(x, up, z); normalize3_fast(x);
+    cross3(y, z, x); normalize3_fast(y);
+    for (int c = 0; c < 3; c++) { sc->cam_o[c] = co[c]; sc->cam_x[c] = x[c]; sc->cam_y[c] = y[c]; sc->cam_z[c] = z[c]; }
+    sc->focal = (0.5 * height) / dm->x.cam_tanhalf[cam];
+    real cq[4];
+    for (int c = 0; c < 3; c++) sc->cube_p[c] = st.qpos[(size_t)(nl + c) * NE + env];
+    for (int c = 0; c < 4; c++) cq[c] = st.qpos[(size_t)(nl + 3 + c) * NE + env];
+    normalize4_fast(cq);
+    quat2mat(sc->cube_R, cq);
+  } else if (t >= 64 && t < 64 + m->nsphere) {
+    const int s = t - 64, l = m->sphere_link[s];
+    real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, v[3];
+    mat_vec3(v, sc->xmat[l], sl);
+    sc->sph[s][0] = sc->xpos[l][0] + v[0]; sc->sph[s][1] = sc->xpos[l][1] + v[1]; sc->sph[s][2] = sc->xpos[l][2] + v[2];
   }
 }
 
 // ---- RGB -----------------------------------------------------------------------------------------------------------
-#define KM_RGB_MAXSPH 4        // visible spheres (the two finger tips per arm)
+#define KM_RGB_MAXSPH KM_RENDER_MAXVIS        // visible spheres (the two finger tips per arm)
 struct RgbScene {              // float32 view of the scene for the pixel loop, built by lane 0 from the float64 RenderScene
   float o[3], X[3], Y[3], Z[3], inv_f, tz, zfar;
   float ol[3], DX[3], DY[3], DZ[3], half[3], R[9];       // cube: camera origin and the ray basis in the cube frame, half sizes, rotation
@@ -239,7 +157,8 @@ __device__ __forceinline__ bool rgb_project(const RenderScene& sc, const real* P
 // constants and rectangle), lanes 12-15 one table edge each, lane 16 the camera / cube-frame scalars; lane 0 then folds the corners
 // into the cube's rectangle and the rectangles into their union.
 struct RgbTmp { real row[8], col[8]; int ok[8]; };
-__device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene& sc, int height, int width, RgbScene* g, RgbTmp* tmp, int t) {
+__device__ __forceinline__ void rgb_scene(const KDeviceModel* dm, const RenderScene& sc, int height, int width, RgbScene* g, RgbTmp* tmp, int t) {
+  const KModelDesc* m = &dm->d;
   // bounding rectangles, one per object (an object that is not safely in front of the camera gets the whole image): the cube's
   // eight corners; a sphere's centre +- a conservative projected radius
   auto put = [&](int o, bool ok, real r0, real r1, real c0, real c1) {
@@ -255,10 +174,8 @@ __device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene
     tmp->ok[t] = rgb_project(sc, P, height, width, row, col);
     tmp->row[t] = row; tmp->col[t] = col;
   } else if (t < 8 + KM_RGB_MAXSPH) {
-    // the (t - 8)-th visible sphere (kmanip_create refuses models with more than KM_RGB_MAXSPH of them)
-    int s = -1, seen = 0;
-    for (int k = 0; k < m->nsphere; k++)
-      if (m->sphere_visible[k]) { if (seen == t - 8) s = k; seen++; }
+    // the (t - 8)-th visible sphere (the list is built on the host; kmanip_create refuses models with more than four)
+    const int s = t - 8 < dm->x.nvis ? dm->x.vis_sphere[t - 8] : -1;
     if (s >= 0) {
       const int ns = t - 8;
       const real rad = m->sphere_radius[s];
@@ -298,9 +215,7 @@ __device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene
     matT_vec3(v, sc.cube_R, sc.cam_z); for (int c = 0; c < 3; c++) g->DZ[c] = (float)v[c];
     for (int c = 0; c < 3; c++) g->half[c] = (float)m->cube_half[c];
     for (int c = 0; c < 9; c++) g->R[c] = (float)sc.cube_R[c];
-    int ns = 0;
-    for (int k = 0; k < m->nsphere; k++) ns += m->sphere_visible[k] ? 1 : 0;
-    g->nsph = ns < KM_RGB_MAXSPH ? ns : KM_RGB_MAXSPH;
+    g->nsph = dm->x.nvis;
     g->tab_L = 0.3f * (0.57735026919f + 0.57735026919f + 0.70710678119f);    // sum_l max(0, L_l . (0,0,1)), scene.xml:11-13
   }
   __syncthreads();
@@ -319,6 +234,118 @@ __device__ __forceinline__ void rgb_scene(const KModelDesc* m, const RenderScene
     }
   }
 }
+// ---- depth (BASELINE config 5) -------------------------------------------------------------------------------------
+// float64 ray maths (the parity bar against the float64 oracle is 1e-6 m; float32 intersection arithmetic cancels to ~1e-5 m).
+// Round 4: the pixel loop was bound by what it FETCHED per pixel, not by its arithmetic -- scene constants re-read from LDS and
+// model scalars from global memory inside the loop, a walk over all twelve collider spheres testing each one's `visible` flag.
+// Now the per-env scene a ray meets is hoisted into registers once (camera basis and the same basis turned into the cube frame,
+// so the slab test's direction is linear in the pixel coordinates; the visible spheres' centres from the host-built list), the
+// divides are reciprocal + Newton steps, and nothing but the image is touched inside the loop.  (A float32 pre-classification
+// with a float64 evaluation of the winner was built and measured first: 12 % of the pixels fell within its margins, i.e. nearly
+// every wave ran both paths -- 0.155 ms against round 3's 0.089; dropped.)
+struct DepthScene { real ol[3], DX[3], DY[3], DZ[3]; real oc[KM_RENDER_MAXVIS][3], cc[KM_RENDER_MAXVIS]; int nvis; };
+
+__global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
+                                                      float* __restrict__ depth) {
+  __shared__ RenderScene sc;
+  __shared__ DepthScene ds;
+  const KModelDesc* m = &dm->d;
+  const int env = blockIdx.x;
+  render_fk(dm, st, env, &sc);
+  render_camera(dm, st, env, cam, height, &sc);
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    // ray origin and basis in the cube frame, one vector per lane
+    const int k = threadIdx.x;
+    const real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]};
+    const real* src = k == 0 ? rel : (k == 1 ? sc.cam_x : (k == 2 ? sc.cam_y : sc.cam_z));
+    real* dst = k == 0 ? ds.ol : (k == 1 ? ds.DX : (k == 2 ? ds.DY : ds.DZ));
+    matT_vec3(dst, sc.cube_R, src);
+  } else if (threadIdx.x >= 64 && threadIdx.x < 64 + KM_RENDER_MAXVIS) {
+    const int ns = threadIdx.x - 64;
+    if (ns == 0) ds.nvis = dm->x.nvis;
+    if (ns < dm->x.nvis) {
+      const int sp = dm->x.vis_sphere[ns];
+      const real rad = m->sphere_radius[sp];
+      const real oc[3] = {sc.cam_o[0] - sc.sph[sp][0], sc.cam_o[1] - sc.sph[sp][1], sc.cam_o[2] - sc.sph[sp][2]};
+      ds.oc[ns][0] = oc[0]; ds.oc[ns][1] = oc[1]; ds.oc[ns][2] = oc[2];
+      ds.cc[ns] = dot3(oc, oc) - rad * rad;
+    }
+  }
+  __syncthreads();
+  // ---- everything the pixel loop reads, in registers
+  const real zfar = m->cam_zfar, znear = m->cam_znear;
+  const real k0 = m->table_z - sc.cam_o[2], ox = sc.cam_o[0], oy = sc.cam_o[1];
+  const real rx0 = m->table_rect[0], rx1 = m->table_rect[1], ry0 = m->table_rect[2], ry1 = m->table_rect[3];
+  real X[3], Y[3], Z[3], ol[3], DX[3], DY[3], DZ[3], hf[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    X[c] = sc.cam_x[c]; Y[c] = sc.cam_y[c]; Z[c] = sc.cam_z[c];
+    ol[c] = ds.ol[c]; DX[c] = ds.DX[c]; DY[c] = ds.DY[c]; DZ[c] = ds.DZ[c]; hf[c] = m->cube_half[c];
+  }
+  // |camera - cube centre|^2 - (bounding radius)^2, the radius padded by a relative 1e-9 so that roundoff never rejects a grazing ray
+  const real cube_cc = (ol[0] * ol[0] + ol[1] * ol[1] + ol[2] * ol[2]) - (hf[0] * hf[0] + hf[1] * hf[1] + hf[2] * hf[2]) * (1.0 + 1e-9);
+  const int nvis = ds.nvis;
+  real soc[KM_RENDER_MAXVIS][3], scc[KM_RENDER_MAXVIS];
+#pragma unroll
+  for (int s = 0; s < KM_RENDER_MAXVIS; s++) {
+    const int k = s < nvis ? s : 0;                      // (unused entries: finite copies, never tested)
+    soc[s][0] = ds.oc[k][0]; soc[s][1] = ds.oc[k][1]; soc[s][2] = ds.oc[k][2]; scc[s] = ds.cc[k];
+  }
+  const int npix = height * width;
+  const real inv_f = 1.0 / sc.focal, hw = 0.5 * width, hh = 0.5 * height;
+  float* __restrict__ out = depth + (size_t)env * npix;
+  int r = threadIdx.x / width, c = threadIdx.x - r * width;         // row / column advance incrementally (no division in the loop)
+  const int dr = blockDim.x / width, dc = blockDim.x - dr * width;
+  for (int p = threadIdx.x; p < npix; p += blockDim.x) {
+    const real dx = (c + 0.5 - hw) * inv_f, dy = -(r + 0.5 - hh) * inv_f;
+    c += dc; r += dr;
+    if (c >= width) { c -= width; r++; }
+    const real d0 = X[0] * dx + Y[0] * dy - Z[0], d1 = X[1] * dx + Y[1] * dy - Z[1], d2 = X[2] * dx + Y[2] * dy - Z[2];
+    real best = zfar;
+    // table top: the rectangle table_rect at z = table_z
+    if (d2 != 0) {
+      const real t = k0 * frcp(d2);
+      const real hx = ox + t * d0, hy = oy + t * d1;
+      if (t > 0 && t < best && hx >= rx0 && hx <= rx1 && hy >= ry0 && hy <= ry1) best = t;
+    }
+    // cube box: slab test in the cube frame -- only for rays that meet the box's bounding sphere (six operations decide it; a
+    // wave is one image row or two, so the test is coherent)
+    const real a2 = d0 * d0 + d1 * d1 + d2 * d2;
+    const real bq = DX[0] * dx + DY[0] * dy, bq1 = DX[1] * dx + DY[1] * dy, bq2 = DX[2] * dx + DY[2] * dy;   // (reused below)
+    const real bc = (bq - DZ[0]) * ol[0] + (bq1 - DZ[1]) * ol[1] + (bq2 - DZ[2]) * ol[2];
+    if (bc * bc - a2 * cube_cc >= 0) {
+      real t0 = -INFINITY, t1 = INFINITY;
+      bool ok = true;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const real dl = (a == 0 ? bq : (a == 1 ? bq1 : bq2)) - DZ[a];
+        if (dl != 0) {
+          const real inv = frcp(dl);
+          const real ta = (-hf[a] - ol[a]) * inv, tb = (hf[a] - ol[a]) * inv;
+          t0 = fmax(t0, fmin(ta, tb)); t1 = fmin(t1, fmax(ta, tb));
+        } else if (ol[a] < -hf[a] || ol[a] > hf[a]) ok = false;
+      }
+      if (ok && t0 <= t1 && t1 > 0) {
+        const real t = t0 > 0 ? t0 : t1;
+        if (t < best) best = t;
+      }
+    }
+    // the visible spheres (finger tips)
+#pragma unroll
+    for (int s = 0; s < KM_RENDER_MAXVIS; s++) {
+      if (s < nvis) {
+        const real b = d0 * soc[s][0] + d1 * soc[s][1] + d2 * soc[s][2], disc = b * b - a2 * scc[s];
+        if (disc >= 0) {
+          const real t = (-b - km_sqrt(disc)) * frcp(a2);
+          if (t > 0 && t < best) best = t;
+        }
+      }
+    }
+    out[p] = (float)fmin(fmax(best, znear), zfar);
+  }
+}
+
 // one pixel, float32: grey level * 255 of the three channels packed r | g << 8 | b << 16
 // does the ray direction (dx, dy) pass through the table top?
 __device__ __forceinline__ bool rgb_over_table(const RgbScene& g, float dx, float dy) {
@@ -402,17 +429,18 @@ __device__ __forceinline__ uint32_t rgb_pixel(const RgbScene& g, float dx, float
   return v | (v << 8) | (v << 16);
 }
 
-__global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
-                                                    uint8_t* __restrict__ rgb) {
+// grid = envs x jobs: blockIdx.y picks the camera / resolution / output buffer (all the cameras of a *Vision observation in one launch)
+__global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restrict__ dm, KDeviceState st, KRenderJobs jobs) {
   __shared__ RenderScene sc;
   __shared__ RgbScene g;
   __shared__ RgbTmp tmp;
-  const KModelDesc* m = &dm->d;
-  const int env = blockIdx.x;
+  const int env = blockIdx.x, job = blockIdx.y;
+  const int cam = jobs.cam[job], height = jobs.height[job], width = jobs.width[job];
+  uint8_t* __restrict__ rgb = jobs.rgb[job];
   render_fk(dm, st, env, &sc);
-  if (threadIdx.x == 0) render_camera(dm, st, env, cam, height, &sc);
+  render_camera(dm, st, env, cam, height, &sc);
   __syncthreads();
-  rgb_scene(m, sc, height, width, &g, &tmp, threadIdx.x);
+  rgb_scene(dm, sc, height, width, &g, &tmp, threadIdx.x);
   __syncthreads();
   const int npix = height * width;
   const float hw = 0.5f * width, hh = 0.5f * height, inv_f = g.inv_f;
@@ -483,9 +511,9 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
 
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
                                 hipStream_t stream) {
-  hipLaunchKernelGGL(k_render_depth, dim3(st.num_envs), dim3(256), 0, stream, dm, st, cam, height, width, depth);
+  // 128 lanes per env: two waves -- 2048 envs x 2 waves fill the chip's 4096 wave slots (120 registers: four waves per SIMD) in one round
+  hipLaunchKernelGGL(k_render_depth, dim3(st.num_envs), dim3(128), 0, stream, dm, st, cam, height, width, depth);
 }
-void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, uint8_t* rgb,
-                              hipStream_t stream) {
-  hipLaunchKernelGGL(k_render_rgb, dim3(st.num_envs), dim3(256), 0, stream, dm, st, cam, height, width, rgb);
+void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, const KRenderJobs& jobs, hipStream_t stream) {
+  hipLaunchKernelGGL(k_render_rgb, dim3(st.num_envs, jobs.n), dim3(256), 0, stream, dm, st, jobs);
 }

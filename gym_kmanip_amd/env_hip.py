@@ -245,6 +245,30 @@ class KManipEnvHip:
                     "kmanip_render_rgb")
         return out
 
+    def render_cameras(self, cams=None, out=None):
+        """Every camera of the observation (default: this id's `cameras`, head first) at its reference resolution in ONE launch
+        (kmanip_render_rgb_multi): {name: uint8 [num_envs, h, w, 3]}.  `out` = such a dict of buffers to fill."""
+        torch = _torch()
+        names = [getattr(c, "name", c) for c in (self.cm.cameras if cams is None else cams)]
+        if not names:
+            return {}
+        bufs = {}
+        for nm in names:
+            spec = CAMERAS[nm]
+            t = None if out is None else out[nm]
+            if t is None:
+                t = torch.empty((self.num_envs, spec.h, spec.w, 3), dtype=torch.uint8, device=self.device)
+            else:
+                self._check_buf(t, (self.num_envs, spec.h, spec.w, 3), torch.uint8, "rgb")
+            bufs[nm] = t
+        n = len(names)
+        ci = (C.c_int32 * n)(*[self._cam_index(nm) for nm in names])
+        hh = (C.c_int32 * n)(*[CAMERAS[nm].h for nm in names])
+        ww = (C.c_int32 * n)(*[CAMERAS[nm].w for nm in names])
+        pp = (C.c_void_p * n)(*[bufs[nm].data_ptr() for nm in names])
+        self._check(self.L.kmanip_render_rgb_multi(self.h, n, ci, hh, ww, pp, self._stream()), "kmanip_render_rgb_multi")
+        return bufs
+
     def bind_step_depth(self, cam="grip_r", height: int = 64, width: int = 64, out=None):
         """BASELINE config 5: every step_flat / k_step from now on also renders `cam` into the returned buffer
         (float32 [num_envs, height, width]), in the same C call.  bind_step_depth(None) unbinds."""

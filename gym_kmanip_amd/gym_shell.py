@@ -206,10 +206,13 @@ class KManipEnv(_EnvBase):
 
     # ------------------------------------------------------------------ observations
     def _observation(self, state_obs):
-        """state keys from the backend + one RGB render per camera observation (env_sim.py:140-145), in obs_list order."""
+        """state keys from the backend + the RGB render of every camera observation (env_sim.py:140-145; all of them in one
+        launch: kmanip_render_rgb_multi), in obs_list order."""
         obs = OrderedDict((k, v) for k, v in state_obs.items() if k in self.obs_list)
-        for cam in self.cameras:
-            obs[cam.log_name] = self.env.k_render(cam)
+        if self.cameras:
+            imgs = self.env.render_cameras(self.cameras)
+            for cam in self.cameras:
+                obs[cam.log_name] = imgs[cam.name]
         self._obs_dev = obs
         if self.device_outputs:
             return obs

@@ -302,6 +302,11 @@ int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_
  * KManipEnv.render() (env_base.py:215-217, the `top` camera): rgb_dev uint8[num_envs, height, width, 3], caller-owned
  * device memory.  Lambert shading of the surrogate scene under the reference's lights (scene.xml:8-13). */
 int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint8_t* rgb_dev, void* stream);
+/* ncam (<= KM_MAX_CAMS) of those images in ONE launch: the whole camera branch of a *Vision observation (head 480 x 640 + grip
+ * 40 x 60 per arm: env_base.py:140-146) costs the step's stream one launch instead of one per camera.  cams / heights / widths /
+ * rgb_dev are HOST arrays of ncam entries; rgb_dev[i] is device memory uint8[num_envs, heights[i], widths[i], 3]. */
+int kmanip_render_rgb_multi(KHandle h, int ncam, const int* cams, const int* heights, const int* widths, uint8_t* const* rgb_dev,
+                            void* stream);
 
 /* BASELINE config 5 ("64x64 gripper-cam depth render in the step"): bind a caller-owned device buffer
  * float[num_envs, height, width]; every kmanip_step then ends by rendering camera `cam` of the state it produced into it,

@@ -24,3 +24,6 @@ for h, w in ((64, 64), (8, 8)):
     buf = torch.empty((n, h, w), dtype=torch.float32, device="cuda")
     ms = t(lambda: e.render_depth("grip_r", h, w, out=buf))
     print("depth grip_r %3dx%3d  %.4f ms  %.2f TB/s" % (h, w, ms, n * h * w * 4 / ms / 1e9))
+bufs = e.render_cameras()
+ms = t(lambda: e.render_cameras(out=bufs))
+print("rgb   all cameras of the observation (%s) in one launch  %.4f ms  %.2f TB/s" % ("+".join(bufs), ms, sum(b.numel() for b in bufs.values()) / ms / 1e9))
