@@ -35,6 +35,10 @@ struct KHandle_ {
   int step_cam = -1, step_h = 0, step_w = 0;
   float* step_depth = nullptr;
   bool ik_unfused = false;      // KMANIP_IK_UNFUSED=1: before_step as its own launch (A/B timing only)
+  // wave slots in predicted-cost order (k_sort_envs) for launches of several residency rounds; KMANIP_COST_SORT=0 / 1 overrides
+  int32_t* slot_env = nullptr;
+  bool cost_sort = false;
+  KCostWeights cost_w{18, 1, 2000, 0, 0, 100};     // work units per: IK evaluation, Newton work unit, collider near the cube; bin width
   std::vector<void*> allocs;
 };
 
@@ -227,6 +231,20 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.rd_rec = nullptr;
   h->st.control_dt = desc->n_sub_steps * desc->timestep;
   { const char* e = getenv("KMANIP_IK_UNFUSED"); h->ik_unfused = e && e[0] == '1'; }
+  h->st.slot_env = nullptr;
+  h->st.wave_clk = nullptr;
+  if (const char* e = getenv("KMANIP_WAVE_CLOCKS")) if (e[0] == '1') CR(dalloc((void**)&h->st.wave_clk, sizeof(unsigned long long) * N));
+  CR(dalloc((void**)&h->slot_env, sizeof(int32_t) * N));
+  CR(dalloc((void**)&h->st.work, sizeof(int32_t) * N));
+  {
+    // more waves than SIMD slots (1024): four envs per wave on the single-arm models, two on the two-arm ones
+    h->cost_sort = num_envs > (nl <= 10 ? 4096 : 2048);
+    if (const char* e = getenv("KMANIP_COST_SORT")) h->cost_sort = e[0] == '1';
+    if (const char* e = getenv("KMANIP_COST_W")) {       // diagnostic: "ik,work,near-cube,armtab,cubetab,binwidth"
+      KCostWeights w = h->cost_w;
+      if (sscanf(e, "%d,%d,%d,%d,%d,%d", &w.ik, &w.work, &w.coupled, &w.armtab, &w.cubetab, &w.binw) == 6 && w.binw > 0) h->cost_w = w;
+    }
+  }
   // the initialisation above ran on the null stream; the caller's (non-blocking) streams must not start before it
   CR(hipDeviceSynchronize());
 #undef CR
@@ -250,6 +268,19 @@ int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stre
   KM_ENTER(h);
   kmanip_launch_reset(h->dmodel, h->desc, h->st, mask_dev, 0, obs_dev, (hipStream_t)stream);
   HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+// Diagnostics (not part of include/kmanip.h; KMANIP_WAVE_CLOCKS=1 at create): per wave slot, the ticks its wave spent in the last
+// k_step, the env it held, that env's work counter and IK evaluation counts -- HOST arrays of num_envs entries.  Synchronous.
+int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env, int32_t* work) {
+  if (!h || !h->st.wave_clk) return -1;
+  KM_ENTER(h);
+  HIPCHK(h, hipDeviceSynchronize());
+  const size_t N = (size_t)h->num_envs;
+  if (clk) HIPCHK(h, hipMemcpy(clk, h->st.wave_clk, sizeof(unsigned long long) * N, hipMemcpyDeviceToHost));
+  if (slot_env) HIPCHK(h, hipMemcpy(slot_env, h->slot_env, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+  if (work) HIPCHK(h, hipMemcpy(work, h->st.work, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -277,6 +308,11 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   if (split) {
     if (tm) HIPCHK(h, hipEventRecord(ev[0], s));
     kmanip_launch_ik_coop(h->dmodel, h->desc, h->st, act_dev, s);
+  }
+  h->st.slot_env = nullptr;
+  if (h->cost_sort) {                        // (one small launch: counting sort of the envs by their last step's diagnostics)
+    kmanip_launch_sort_envs(h->st, h->slot_env, h->cost_w, s);
+    h->st.slot_env = h->slot_env;
   }
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));        // (fused path: two events per step, each costs the stream a barrier packet)
   kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);

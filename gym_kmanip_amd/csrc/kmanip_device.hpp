@@ -408,6 +408,9 @@ struct KDeviceState {
   int32_t* ik_status; // [2][N]
   double* sim_time;   // [N] caller-owned (kmanip_bind_sim_time), may be NULL: data.time of every env = step_idx * control_dt
   double* rd_rec;     // [N][2] caller-owned (kmanip_bind_reward_done_record), may be NULL: this step's packed (reward, done) record
+  int32_t* work;      // [N] Newton work units of the env's last control step (two-arm kernels; 0 otherwise): k_sort_envs' predictor
+  unsigned long long* wave_clk;   // [N] or NULL (KMANIP_WAVE_CLOCKS=1, diagnostics): s_memtime ticks the wave that held slot s spent in k_step
+  const int32_t* slot_env;   // [N] or NULL: env handled by wave slot s (k_sort_envs: predicted-cost order, heaviest first); NULL = identity
   double control_dt;  // n_sub_steps * timestep
   int num_envs;
   int64_t env_id_offset;
@@ -434,5 +437,8 @@ void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, 
 // up to KM_MAX_CAMS camera images of every env in ONE launch (grid = envs x jobs): the *Vision observation
 struct KRenderJobs { int n; int cam[KM_MAX_CAMS], height[KM_MAX_CAMS], width[KM_MAX_CAMS]; uint8_t* rgb[KM_MAX_CAMS]; };
 void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, const KRenderJobs& jobs, hipStream_t stream);
+// slot_env[s] = the env wave slot s handles, envs ordered by the cost their LAST step predicts, heaviest first (LPT dispatch)
+struct KCostWeights { int ik, work, coupled, armtab, cubetab, binw; };
+void kmanip_launch_sort_envs(const KDeviceState& st, int32_t* slot_env, const KCostWeights& w, hipStream_t stream);
 void kmanip_launch_scripted_action(const KDeviceModel* dm, const KDeviceState& st, float* act, hipStream_t stream);
 void kmanip_launch_sample_action(const KDeviceModel* dm, const KDeviceState& st, float* act, int ahead, hipStream_t stream);

@@ -36,6 +36,12 @@
 #define KM_TREE_UNROLL(NL) NL <= 10 ? NL : 1
 #define KM_TARGET_WAVES 1024   // 256 CUs x 4 SIMDs: below this many workgroups, fewer envs per wave fills more SIMDs
 
+// Work units one Newton iteration of each kind adds to Ws::work (roughly kilo-clocks on the two-arm kernels; only their ORDER
+// matters: k_sort_envs ranks the envs by them).  Two-arm kernels only: the single-arm headline launch is one residency round.
+#define KM_WORK_ALL 40
+#define KM_WORK_ARM 14
+#define KM_WORK_PLAIN 3
+#define KM_WORK_CUBE 5
 template <int NL> struct Dim {
   static constexpr int NV = NL + 6;
   static constexpr int NQ = NL + 7;
@@ -116,6 +122,7 @@ struct Ws {
   real as[NV], tmp2[NV], tmp3[NV];
 #endif
   int ns, bad, touch_ct;
+  int work;                // Newton iterations of this control step, weighted by kind (KM_WORK_*): the cost predictor of k_sort_envs
   uint32_t contact_mask;   // KM_CON_* bits (which candidate pairs touch)
   uint32_t cact;           // active contact slots
   // single-dof constraint rows on ARM dofs (friction loss, then limits); the cube's friction-loss rows are
@@ -884,8 +891,11 @@ __device__ __forceinline__ bool over_table(const real (&tr)[4], const real* p) {
   return (p[0] >= tr[0]) & (p[0] <= tr[1]) & (p[1] >= tr[2]) & (p[1] <= tr[3]);
 }
 
-template <int NL, int G>
-__device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub) {
+// NEAR (the trailing mj_step1 of the two-arm kernels only): also report whether some collider is within KM_NEAR_MARGIN of the cube
+// without touching it -- the onset of the coupled Newton loop is what k_sort_envs' last-step counters cannot see coming
+#define KM_NEAR_MARGIN 0.015
+template <int NL, int G, bool NEAR = false>
+__device__ __forceinline__ int collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub) {
   constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS, NST = Dim<NL>::NST;
   static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
@@ -996,6 +1006,8 @@ __device__ __forceinline__ void collide_parallel(Ws<NL>& w, const KModelDesc* m,
     w.cact = act; w.contact_mask = mask;
     w.touch_ct = (mask & KM_CON_ANY_CUBE_TABLE) != 0;
   }
+  if constexpr (NEAR) return gor<G>((int)(sub >= 8 && sub < 8 + nsph && d1 < KM_NEAR_MARGIN));
+  return 0;
 }
 
 // MuJoCo impedance d(r) from the staged, pre-clamped solimp constants: no divide, no pow (power is 1 or 2: kmanip_create
@@ -1924,6 +1936,9 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
         rows &= (sub < lm.split || !lm.split) ? lowm : ~lowm;
       } else plain = !cq && __popc(rows) <= 2;
     }
+    if constexpr (NL > 10) {
+      if (sub == 0) w.work += plain ? KM_WORK_PLAIN : (prob == KM_SUB_ALL ? KM_WORK_ALL : (prob == KM_SUB_ARM ? KM_WORK_ARM : KM_WORK_CUBE));
+    }
     if (plain) {
       // everything the direction reads from LDS or from other lanes that does not depend on y is requested FIRST and together --
       // the row of M^-1, the 2 x 2 system's entries, the correction's two column entries, the two rows' weights -- so that the
@@ -2318,7 +2333,7 @@ __device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, in
     w.ctrl[i] = fused ? (real)(float)c : c;
     if (!fused) w.qpos_ik[i] = st.qpos_ik[(size_t)i * NE + env];
   }
-  if (sub == 0) w.bad = 0;
+  if (sub == 0) { w.bad = 0; w.work = 0; }
 }
 // state accessor of the fused before_step: the env's LDS workspace (diagnostics go straight to HBM)
 template <int NL> struct LdsIO {
@@ -2409,14 +2424,19 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
-  const int env = xcd_block(blockIdx.x, gridDim.x) * EPB + grp;
-  if (grp >= EPB || env >= st.num_envs) return;     // whole group exits together
+  // wave slot -> env: the identity behind the XCD-aware block mapping, or -- launches of several residency rounds -- the
+  // predicted-cost order of k_sort_envs with workgroup 0 first (longest-processing-time-first dispatch)
+  const int slot = (st.slot_env ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * EPB + grp;
+  if (grp >= EPB || slot >= st.num_envs) return;     // whole group exits together
+  const int env = st.slot_env ? st.slot_env[slot] : slot;
   Ws<NL>& w = ws[grp];
   CReg<NL> cr;
   real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   Prof pf;
   pf.start();
+  const unsigned long long t_wave0 = st.wave_clk ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long r_wave0 = st.wave_clk ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const bool fused = act != nullptr;
 #ifdef KM_DEBUG_NANFILL   // diagnostic build (-DKM_DEBUG_NANFILL=<value>): poison the workspace, so that a read of LDS this launch did not write shows
   { double* wp = reinterpret_cast<double*>(&w); for (int i = sub; i < (int)(sizeof(Ws<NL>) / 8); i += G) wp[i] = KM_DEBUG_NANFILL; GSYNC(); }
@@ -2436,7 +2456,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     if (kc > 0) {
       // what load_state does for the first step: ctrl <- float32(ctrl) (env_sim.py:40), qpos_ik <- qpos
       if (sub < NL) { w.ctrl[sub] = (real)(float)w.ctrl[sub]; w.qpos_ik[sub] = w.qpos[sub]; }
-      if (sub == 0) w.bad = 0;
+      if (sub == 0) { w.bad = 0; w.work = 0; }
       GSYNC();
     }
     // ---- KManipTask.before_step: 8 lanes per arm, one arm per 16-lane DPP row of the group (lanes 0-7 of row 0: right arm;
@@ -2483,7 +2503,8 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
-    collide_parallel<NL, G>(w, m, sub);
+    const int near_cube = collide_parallel<NL, G, (NL > 10)>(w, m, sub);
+    if constexpr (NL > 10) { if (sub == 0 && near_cube) w.work |= 1 << 30; }     // (bit 30: a collider on or close to the cube)
     rew = env_reward<NL, G>(w, m, sub);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
     if (sub == 0) st.contact_mask[env] = w.contact_mask;
@@ -2511,6 +2532,9 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub == 0) {
     st.step_idx[env] = step_idx; st.episode[env] = episode;
     if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
+    if constexpr (NL > 10) st.work[env] = w.work;      // (the last control step's: what the next launch's slot order is predicted from)
+    // (diagnostics: core-clock cycles in the low 40 bits; above them the wave's START on the constant 100 MHz clock, 24 bits)
+    if (st.wave_clk) st.wave_clk[slot] = ((__builtin_amdgcn_s_memtime() - t_wave0) & 0xFFFFFFFFFFull) | ((r_wave0 & 0xFFFFFFull) << 40);
   }
   store_state<NL, G>(w, st, env, sub);
   pf.ph(31);

@@ -79,3 +79,74 @@ void kmanip_launch_sample_action(const KDeviceModel* dm, const KDeviceState& st,
   const int n = st.num_envs * 4;          // act_dim <= 16: at most 4 blocks per env (idle lanes return)
   hipLaunchKernelGGL(k_sample_action, dim3((n + 255) / 256), dim3(256), 0, stream, dm, st, act, ahead);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-slot assignment by predicted cost (round 4).  When a launch has more waves than the chip has SIMD slots (the two-arm
+// models at 8192 envs: 4096 waves on 1024 slots), the hardware hands a freed slot the NEXT workgroup in index order, so the
+// launch ends at  total / slots + (how late the longest waves started): measured 5.8 M clocks against a mean-bound 4.0 M
+// (DualArm @ 8192).  Longest-processing-time-first fixes exactly that: workgroup 0 gets the envs expected to take longest.
+// The predictor is what the env's LAST step left in the diagnostics -- contacts persist over steps (a sphere on the cube = the
+// coupled 26-dof Newton loop, a sphere on the table = the arm problem off its Woodbury shortcut), the IK's evaluation count
+// partly (an "IK failed" start stays failed) -- quantised to 32 bins; envs of a bin also share waves, so a wave's two envs wait
+// less for each other.  An env's bits do not depend on its slot or its wave-mates (tests compare shards and launch shapes).
+// One workgroup, counting sort, deterministic: thread t owns envs t, t + 256, ...
+#define KM_SORT_BINS 32
+#define KM_SORT_UNROLL 8
+__global__ __launch_bounds__(256) void k_sort_envs(KDeviceState st, int32_t* __restrict__ slot_env, KCostWeights w) {
+  __shared__ int cnt[KM_SORT_BINS][256];
+  __shared__ int base[KM_SORT_BINS];
+  const int t = threadIdx.x, N = st.num_envs;
+  // bins of KM_SORT_UNROLL envs at a time: their loads are independent and go out together (one workgroup walks the whole batch:
+  // a dependent load per iteration would cost a memory round trip per 256 envs)
+  auto bins = [&](int e0, int (&b)[KM_SORT_UNROLL]) {
+    uint32_t mask[KM_SORT_UNROLL]; int nf0[KM_SORT_UNROLL], nf1[KM_SORT_UNROLL], wk[KM_SORT_UNROLL];
+#pragma unroll
+    for (int k = 0; k < KM_SORT_UNROLL; k++) {
+      const int e = e0 + 256 * k, ec = e < N ? e : 0;
+      mask[k] = st.contact_mask[ec]; nf0[k] = st.ik_nfev[ec]; nf1[k] = st.ik_nfev[(size_t)N + ec]; wk[k] = st.work[ec];
+    }
+#pragma unroll
+    for (int k = 0; k < KM_SORT_UNROLL; k++) {
+      const int nf = max(nf0[k], nf1[k]);                              // (the two arms' solves run side by side, one per DPP row)
+      // work bit 30: a collider within KM_NEAR_MARGIN of the cube (or on it) -- the coupled Newton loop is on or about to start
+      const int cost = w.ik * nf + w.work * (wk[k] & 0x3FFFFFFF) + ((wk[k] >> 30) ? w.coupled : 0)
+                       + ((mask[k] & KM_CON_ANY_SPHERE_TABLE) ? w.armtab : 0) + ((mask[k] & KM_CON_ANY_CUBE_TABLE) ? w.cubetab : 0);
+      b[k] = e0 + 256 * k < N ? KM_SORT_BINS - 1 - min(cost / w.binw, KM_SORT_BINS - 1) : -1;      // bin 0 = heaviest
+    }
+  };
+  for (int b = 0; b < KM_SORT_BINS; b++) cnt[b][t] = 0;
+  for (int e0 = t; e0 < N; e0 += 256 * KM_SORT_UNROLL) {
+    int b[KM_SORT_UNROLL];
+    bins(e0, b);
+#pragma unroll
+    for (int k = 0; k < KM_SORT_UNROLL; k++) if (b[k] >= 0) cnt[b[k]][t]++;
+  }
+  __syncthreads();
+  // exclusive prefix over the 256 threads of every bin: wave v takes bins v, v + 4, ...; a lane scans four neighbouring threads'
+  // counts itself and the 64 lane sums by shuffles
+  {
+    const int lane = t & 63, wv = t >> 6;
+    for (int b = wv; b < KM_SORT_BINS; b += 4) {
+      const int c0 = cnt[b][4 * lane], c1 = cnt[b][4 * lane + 1], c2 = cnt[b][4 * lane + 2], c3 = cnt[b][4 * lane + 3];
+      const int s = c0 + c1 + c2 + c3;
+      int inc = s;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+      const int ex = inc - s;
+      cnt[b][4 * lane] = ex; cnt[b][4 * lane + 1] = ex + c0; cnt[b][4 * lane + 2] = ex + c0 + c1; cnt[b][4 * lane + 3] = ex + c0 + c1 + c2;
+      if (lane == 63) base[b] = inc;
+    }
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < KM_SORT_BINS; b++) { const int c = base[b]; base[b] = acc; acc += c; } }
+  __syncthreads();
+  for (int e0 = t; e0 < N; e0 += 256 * KM_SORT_UNROLL) {
+    int b[KM_SORT_UNROLL];
+    bins(e0, b);
+#pragma unroll
+    for (int k = 0; k < KM_SORT_UNROLL; k++) if (b[k] >= 0) slot_env[base[b[k]] + cnt[b[k]][t]++] = e0 + 256 * k;
+  }
+}
+void kmanip_launch_sort_envs(const KDeviceState& st, int32_t* slot_env, const KCostWeights& w, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sort_envs, dim3(1), dim3(256), 0, stream, st, slot_env, w);
+}

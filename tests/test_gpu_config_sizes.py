@@ -205,3 +205,34 @@ def test_parity_soak_one_step_samples(env):
     assert n_ctrl <= 4, n_ctrl
     assert seen & 0xF, hex(seen)                   # cube-table contacts were in the sample
     dev.k_close()
+
+
+def test_cost_sorted_wave_slots_change_nothing_but_the_order(monkeypatch):
+    """Launches of several residency rounds run their waves in predicted-cost order (k_sort_envs: longest first, from the last
+    step's diagnostics).  The order is a permutation of the envs, and an env's bits do not depend on it: a handle with the sort on
+    (automatic above 2048 two-arm envs) against one with KMANIP_COST_SORT=0, bit for bit, across an auto-reset."""
+    import ctypes as C
+    import torch
+    from gym_kmanip_amd import env_hip
+    n = 4096
+    monkeypatch.setenv("KMANIP_WAVE_CLOCKS", "1")
+    a = env_hip.make("KManipDualArm", num_envs=n, seed=5)              # sorted (n > 2048)
+    monkeypatch.setenv("KMANIP_COST_SORT", "0")
+    b = env_hip.make("KManipDualArm", num_envs=n, seed=5)
+    monkeypatch.delenv("KMANIP_COST_SORT")
+    a.k_reset(); b.k_reset()
+    ph = (58 + np.arange(n) % 6).astype(np.int32)
+    a.set_state(step=ph); b.set_state(step=ph)
+    slot = np.zeros(n, dtype=np.int32)
+    orders = set()
+    for k in range(10):
+        act = a.sample_action().clone()
+        a.step_flat(act); b.step_flat(act)
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), k
+        assert a.L.kmanip_dbg_wave_clocks(a.h, None, slot.ctypes.data_as(C.POINTER(C.c_int32)), None) == 0
+        assert np.array_equal(np.sort(slot), np.arange(n)), k                    # a permutation
+        orders.add(slot.tobytes())
+    sa, sb = a.get_state(), b.get_state()
+    assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    assert len(orders) > 5                                                       # and it does re-order from step to step
+    a.k_close(); b.k_close()
