@@ -38,6 +38,13 @@
 
 // Work units one Newton iteration of each kind adds to Ws::work (roughly kilo-clocks on the two-arm kernels; only their ORDER
 // matters: k_sort_envs ranks the envs by them).  Two-arm kernels only: the single-arm headline launch is one residency round.
+// (measured on the single-arm kernel, tests/tools/wave_times.py with -DKM_WORK_COUNTERS_ALL: wave cycles = 375 k + 308 x the
+// slowest env's work units + 13.8 k x the largest IK evaluation count, R^2 0.66; the counters cost it 1.5 %, so it ships without)
+#ifdef KM_WORK_COUNTERS_ALL
+#define KM_WORK_COUNTERS(NL) true
+#else
+#define KM_WORK_COUNTERS(NL) ((NL) > 10)
+#endif
 #define KM_WORK_ALL 40
 #define KM_WORK_ARM 14
 #define KM_WORK_PLAIN 3
@@ -1936,7 +1943,7 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
         rows &= (sub < lm.split || !lm.split) ? lowm : ~lowm;
       } else plain = !cq && __popc(rows) <= 2;
     }
-    if constexpr (NL > 10) {
+    if constexpr (KM_WORK_COUNTERS(NL)) {
       if (sub == 0) w.work += plain ? KM_WORK_PLAIN : (prob == KM_SUB_ALL ? KM_WORK_ALL : (prob == KM_SUB_ARM ? KM_WORK_ARM : KM_WORK_CUBE));
     }
     if (plain) {
@@ -2503,8 +2510,8 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
-    const int near_cube = collide_parallel<NL, G, (NL > 10)>(w, m, sub);
-    if constexpr (NL > 10) { if (sub == 0 && near_cube) w.work |= 1 << 30; }     // (bit 30: a collider on or close to the cube)
+    const int near_cube = collide_parallel<NL, G, KM_WORK_COUNTERS(NL)>(w, m, sub);
+    if constexpr (KM_WORK_COUNTERS(NL)) { if (sub == 0 && near_cube) w.work |= 1 << 30; }     // (bit 30: a collider on or close to the cube)
     rew = env_reward<NL, G>(w, m, sub);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
     if (sub == 0) st.contact_mask[env] = w.contact_mask;
@@ -2532,7 +2539,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub == 0) {
     st.step_idx[env] = step_idx; st.episode[env] = episode;
     if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
-    if constexpr (NL > 10) st.work[env] = w.work;      // (the last control step's: what the next launch's slot order is predicted from)
+    if constexpr (KM_WORK_COUNTERS(NL)) st.work[env] = w.work;      // (the last control step's: what the next launch's slot order is predicted from)
     // (diagnostics: core-clock cycles in the low 40 bits; above them the wave's START on the constant 100 MHz clock, 24 bits)
     if (st.wave_clk) st.wave_clk[slot] = ((__builtin_amdgcn_s_memtime() - t_wave0) & 0xFFFFFFFFFFull) | ((r_wave0 & 0xFFFFFFull) << 40);
   }
