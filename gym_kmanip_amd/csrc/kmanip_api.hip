@@ -237,8 +237,9 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   CR(dalloc((void**)&h->slot_env, sizeof(int32_t) * N));
   CR(dalloc((void**)&h->st.work, sizeof(int32_t) * N));
   {
-    // more waves than SIMD slots (1024): four envs per wave on the single-arm models, two on the two-arm ones
-    h->cost_sort = num_envs > (nl <= 10 ? 4096 : 2048);
+    // more waves than SIMD slots (1024) at two envs per wave: the two-arm models (their kernels carry the work counters the
+    // order is predicted from; the single-arm kernel ships without them -- KMANIP_COST_SORT=1 still sorts it by its IK counts)
+    h->cost_sort = nl > 10 && num_envs > 2048;
     if (const char* e = getenv("KMANIP_COST_SORT")) h->cost_sort = e[0] == '1';
     if (const char* e = getenv("KMANIP_COST_W")) {       // diagnostic: "ik,work,near-cube,armtab,cubetab,binwidth"
       KCostWeights w = h->cost_w;

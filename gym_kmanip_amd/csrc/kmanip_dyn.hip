@@ -1286,8 +1286,12 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
     __builtin_amdgcn_sched_barrier(0);
     if ((act >> c) & 1u) {
       real wk[4], ak[4], F[4] = {0, 0, 0, 0};
+      {
+#pragma clang fp contract(off)
 #pragma unroll
-      for (int k = 0; k < 4; k++) { wk[k] = gsum<G>(cr.jb[c][k] * warm); ak[k] = gsum<G>(cr.jb[c][k] * a_s); }
+        for (int k = 0; k < 4; k++) { wk[k] = cr.jb[c][k] * warm; ak[k] = cr.jb[c][k] * a_s; }
+        gsum_n<G, 4>(wk); gsum_n<G, 4>(ak);
+      }
       ConRec& rc = w.rec[c];
       const real R = rc.R;
 #pragma unroll
@@ -1353,8 +1357,14 @@ __device__ __forceinline__ real solve_accel(Ws<NL>& w, const LModel<NL>& lm, con
         const ConRec& rr = w.rec[c];
         const real Rc = rr.R;
         real u[4], Dk[4] = {0, 0, 0, 0}, f[6];
+        {
+          // the four basis projections u = J a as INTERLEAVED group sums (round 4; bitwise the same sums as four gsum calls:
+          // the products are rounded before the first addition either way)
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int k = 0; k < 4; k++) u[k] = gsum<G>(cr.jb[c][k] * a);
+          for (int k = 0; k < 4; k++) u[k] = cr.jb[c][k] * a;
+          gsum_n<G, 4>(u);
+        }
 #pragma unroll
         for (int e = 0; e < 6; e++) {
           const int k = e / 2 + 1;

@@ -40,7 +40,11 @@ __device__ __forceinline__ double km_rcp(double x) {
   r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
   return r;
 }
-// sqrt(x) for x >= 0 (0 -> 0), no denormal / inf handling: x * rsqrt(x) with one residual correction
+// sqrt(x) for x >= 0 (0 -> 0), no denormal / inf handling: x * rsqrt(x) with one residual correction.
+// DOMAIN: finite x.  +inf gives NaN (rsq(inf) = 0, 0 * inf), not inf.  Callers that can see a diverging env's numbers (the reward's
+// |qvel|, the Newton / IK convergence norms) do not rely on it: k_step raises the divergence flag from isfinite(qacc) / isfinite(qpos)
+// -- independent of these values --, zeroes reward and observation of such an env, and a NaN norm fails every `< tol` test, i.e. the
+// loop runs to its iteration cap and the non-finite qacc is then flagged (tests: test_diverged_flag_and_recovery).
 __device__ __forceinline__ double km_sqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
   y = y * __builtin_fma(-0.5 * x * y, y, 1.5);

@@ -41,22 +41,24 @@ def _cmp_state(g, o, k="", resync=None):
     """qpos / qvel within tolerance, step counters and ctrl bit-exact.  ctrl is float32-quantised (env_sim.py:40,71), so a
     free-running comparison has one legitimate failure mode: two float64 IK results that agree to 1e-9 can straddle a
     float32 rounding boundary.  With `resync` (a one-element list used as a counter) such a flip -- every mismatching entry
-    within one float32 ulp -- re-synchronises the oracle to the device state instead of failing; callers bound the count."""
+    within one float32 ulp -- re-synchronises the oracle to the device state instead of failing; callers bound the count.
+    Returns the boolean mask of the envs whose ctrl flipped (all False normally): ONLY those envs get the looser bar for this
+    step (their step was driven by targets 1.2e-7 apart: ten times the bars); every other env keeps the normal one."""
     sg, so = g.get_state(), o.get_state()
-    flip = not np.array_equal(sg[2], so[2])
-    if flip:
-        bad = sg[2] != so[2]
+    bad = sg[2] != so[2]
+    flipped = bad.any(axis=1)
+    if flipped.any():
         ulp = np.spacing(np.abs(so[2][bad]).astype(np.float32)).astype(np.float64)
         assert resync is not None and (np.abs(sg[2][bad] - so[2][bad]) <= ulp).all(), ("ctrl", k, sg[2][bad], so[2][bad])
-    # (the step that follows a flipped ctrl entry was driven by targets 1.2e-7 apart: ten times the bars for that one step)
-    tq, tv = (10 * TOL_Q, 10 * TOL_V) if flip else (TOL_Q, TOL_V)
-    assert np.abs(sg[0] - so[0]).max() < tq, ("qpos", k, np.abs(sg[0] - so[0]).max())
-    assert np.abs(sg[1] - so[1]).max() < tv, ("qvel", k, np.abs(sg[1] - so[1]).max())
+    tq = np.where(flipped, 10 * TOL_Q, TOL_Q)[:, None]
+    tv = np.where(flipped, 10 * TOL_V, TOL_V)[:, None]
+    assert (np.abs(sg[0] - so[0]) < tq).all(), ("qpos", k, np.abs(sg[0] - so[0]).max())
+    assert (np.abs(sg[1] - so[1]) < tv).all(), ("qvel", k, np.abs(sg[1] - so[1]).max())
     assert np.array_equal(sg[4], so[4]), ("step_idx", k)
-    if flip:
+    if flipped.any():
         resync[0] += 1
         o.set_state(*sg)
-    return flip
+    return flipped
 
 
 @pytest.mark.parametrize("env", ENVS3)
@@ -139,15 +141,18 @@ def test_step_parity_vs_oracle(env, n, steps, solver):
         dev.step_flat(torch.from_numpy(act).cuda())
         oo, ro, do = orc.step(act)
         flip = _cmp_state(dev, orc, k, resync)                     # (a flipped float32 ctrl entry: the observation's velocity part moves with qvel)
-        assert np.abs(dev.obs.cpu().numpy() - oo).max() < (10 * TOL_V if flip else TOL_Q), k
-        assert np.abs(dev.reward.cpu().numpy() - ro).max() < (10 * TOL_R if flip else TOL_R), k
+        assert (np.abs(dev.obs.cpu().numpy() - oo) < np.where(flip, 10 * TOL_V, TOL_Q)[:, None]).all(), k      # (only the flipped envs get the loose bar)
+        assert (np.abs(dev.reward.cpu().numpy() - ro) < np.where(flip, 10 * TOL_R, TOL_R)).all(), k
         assert np.array_equal(dev.done.cpu().numpy(), do), k
         mg, nfg, stg = dev.get_diag(); mo, nfo, sto = orc.get_diag()
         assert np.array_equal(mg, mo), (k, mg, mo)
         assert np.array_equal(stg == -2, sto == -2) and np.abs(nfg - nfo).max() <= 1, k
         saw_contact |= bool(mg.any()); saw_reset |= bool(do.any())
     assert saw_contact and saw_reset
-    assert resync[0] <= (2 if solver == "pgs" else 1), resync      # float32 ctrl flips (a handful in 799 k samples: profiles/r03_parity_soak.txt)
+    # float32 ctrl flips: a handful in 799 k samples (profiles/r03_parity_soak.txt).  These short runs are deterministic: the Newton
+    # runs of SoloArm and Torso have none, DualArm's has exactly one (one env, one entry, one ulp); the non-converging PGS variant
+    # drifts further from the oracle late in an episode and may straddle a boundary twice.  A flipped env alone gets the loose bar.
+    assert resync[0] <= (2 if solver == "pgs" else (1 if env == "KManipDualArm" else 0)), resync
     dev.k_close()
 
 
