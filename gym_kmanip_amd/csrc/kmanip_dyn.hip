@@ -1733,6 +1733,12 @@ __device__ __forceinline__ real slot_eval(const SlotC& sc, const real (&X)[4], r
   }
   return 0.5 * (sc.D * ((m1p * m1p + m1m * m1m) + (m2p * m2p + m2m * m2m)) + sc.D3 * (m3p * m3p + m3m * m3m));
 }
+// which of the slot's six edges are active at the shifted projections X (the comparisons slot_eval's weights W come from)
+__device__ __forceinline__ int slot_edge_mask(const SlotC& sc, const real (&X)[4]) {
+  const real t1 = sc.mu * X[1], t2 = sc.mu * X[2], t3 = sc.mu3 * X[3];
+  return (int)(X[0] + t1 < 0) | (int)(X[0] - t1 < 0) << 1 | (int)(X[0] + t2 < 0) << 2 | (int)(X[0] - t2 < 0) << 3
+         | (int)(X[0] + t3 < 0) << 4 | (int)(X[0] - t3 < 0) << 5;
+}
 // this slot's contribution to phi'(alpha) and phi''(alpha) along y (X already holds u + alpha y)
 __device__ __forceinline__ void slot_ls(const SlotC& sc, const real (&X)[4], const real (&y)[4], real& e1, real& e2) {
   const real t1 = sc.mu * X[1], t2 = sc.mu * X[2], t3 = sc.mu3 * X[3], s1 = sc.mu * y[1], s2 = sc.mu * y[2], s3 = sc.mu3 * y[3];
@@ -1842,10 +1848,12 @@ __device__ __forceinline__ void newton_eval_sl(const Ws<NL>& w, int sub, const C
 
 // Hessian row `sub` (block [D0, D1) of the subset) from the slots' weights: H += J_c^T W_c J_c, the weights of slot c arriving
 // from lane c inside the FMAs that build t = W_c J_c[:, sub]
-template <int NL, int G, int S>
+// CUBECOLS: only the cube's columns NL..NV-1 of every row (the partial refactorisation of newton_loop_sl; the entries are built by
+// the same operations in the same order as in the full build, so they come out bitwise the same)
+template <int NL, int G, int S, bool CUBECOLS = false>
 __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, const CReg<NL>& cr, real mdiag, int qf, int ql,
                                                   const real (&W)[7], real (&h)[Dim<NL>::NV], bool in, uint32_t act, bool joint) {
-  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC, J0 = CUBECOLS ? NL : 0;
   using SS = SubSet<NL, S>;
   {
     real dg = sub < NL ? 0.0 : mdiag;
@@ -1854,7 +1862,7 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
     // dofs outside the problem: zero rows -- or, in the joint loop (whose pivots run over them too), identity rows
     const real idg = joint ? 1.0 : 0.0;
 #pragma unroll
-    for (int j = 0; j < NV; j++) h[j] = in ? (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0) : ((j == sub) ? idg : 0.0);
+    for (int j = J0; j < NV; j++) h[j] = in ? (j < NL ? cr.mrow[j] : 0.0) + ((j == sub) ? dg : 0.0) : ((j == sub) ? idg : 0.0);
   }
   real Wb[7];
 #pragma unroll
@@ -1878,7 +1886,7 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
         // Jacobian can be nonzero in); DPP sources = the Jacobian columns (or their row copies), written long before: the
         // first run of a two-row group still waits for the swap that made the copies
         const BSrc<G> j0s = bsrc<G>(j0), j1s = bsrc<G>(j1), j2s = bsrc<G>(j2), j3s = bsrc<G>(j3);
-        static_for<SS::c0(c), SS::c1(c)>([&](auto jc) {
+        static_for<(SS::c0(c) > J0 ? SS::c0(c) : J0), SS::c1(c)>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr bool WT = G == 32 && j == SS::c0(c);
           if constexpr (SS::kind(c) != 2) dppfma_acc4<j & 15, WT>(h[j], bsel<G, j>(j0s), t0, bsel<G, j>(j1s), t1, bsel<G, j>(j2s), t2, bsel<G, j>(j3s), t3);
@@ -1911,8 +1919,30 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
   int prob = (JOINT && two) ? (int)KM_SUB_ARM : S;
   uint32_t act = w.cact;
   bool in = sub >= SS::D0 && sub < SS::D1, slin = slot_lane_in<NL, S>(sub);
+  // Partial refactorisation (round 4; one-row groups, whole-problem / joint loop).  Most iterations of a coupled env only move
+  // edges of the cube's table contacts (the stiff ones): rows and columns of the ARM dofs -- the first NL pivots -- are then
+  // exactly what the previous iteration factorised.  When no group of the wave has changed anything on its arm side (single-
+  // dof rows of arm dofs, edge sets of the sphere slots) since the factor that sits in LDS (w.LT) was made, the iteration keeps
+  // L's first NL columns, REPLAYS their updates on the cube block (the same FMAs on the same numbers in the same order as the
+  // full factorisation, minus the pivots' reciprocal-square-root chains) and factorises only the cube's 6 x 6 Schur complement:
+  // bitwise the result of the full path, so an env's bits still do not depend on its wave-mates -- whose state decides which
+  // path the wave takes.  `sig0` = the arm-side signature of the cached factor, `invd_keep` its 1 / L_ii.
+  int sig0 = 0;
+  bool cache_ok = false;
+  real invd_keep = 0;
   auto enter = [&](int pr) {
     constexpr uint32_t ARM_SLOTS = ((1u << NC) - 1u) & ~((1u << (4 + NSS)) - 1u);
+    cache_ok = false;
+    if constexpr (JOINT) {
+      if (pr == KM_SUB_CUBE) {
+        // a wave-mate's cube problem has identity rows on the arm dofs: the arm columns of ITS factor are known without a
+        // factorisation (strictly-lower entries 0, 1 / L_ii = 1 -- and whatever 1 / L_ii a full pass would compute there only ever
+        // multiplies the zero arm components of its right-hand side), so its first iteration need not force the wave onto the full path
+#pragma unroll
+        for (int k = 0; k < NL; k++) w.LT[sub][k] = 0;
+        invd_keep = sub < NL ? 1.0 : 0.0; sig0 = 0; cache_ok = true;
+      }
+    }
     prob = pr;
     act = pr == KM_SUB_ARM ? (w.cact & ARM_SLOTS) : (w.cact & 0xFu);
     in = pr == KM_SUB_ARM ? sub < NL : (sub >= NL && sub < NV);
@@ -1989,7 +2019,19 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
       pf.ph(11 + 6 * S);
     } else {
       real h[NV];
-      newton_hessian_sl<NL, G, S>(w, sub, cr, mdiag, qf, ql, W, h, in, act, JOINT);
+      bool partial = false;
+      int sig = 0;
+      if constexpr (S == KM_SUB_ALL && G == 16) {
+        // arm-side signature of this iteration's Hessian: quadratic-zone flags of the arm dofs' own rows, edge sets of the sphere slots
+        // (an inactive slot's projections are arbitrary finite numbers: not part of the signature; a condim-3 pair has no torsion edges)
+        sig = (in && sub < NL ? (qf | ql << 1) : 0)
+              | ((slin && sub >= 4 && ((act >> sub) & 1u)) ? (slot_edge_mask(sc, u) & (sc.D3 != 0 ? 0x3F : 0xF)) << 2 : 0);
+        const bool same = cache_ok && gor<G>((int)(sig != sig0)) == 0;
+        partial = __all(same);                      // (the groups of the wave that are in this branch)
+      }
+      if constexpr (S == KM_SUB_ALL && G == 16) { if (prob == KM_SUB_ALL) pf.cnt(partial ? 41 : 42, 1); else pf.cnt(43, partial ? 1 : 0x10000); }
+      if (partial) newton_hessian_sl<NL, G, S, true>(w, sub, cr, mdiag, qf, ql, W, h, in, act, JOINT);
+      else newton_hessian_sl<NL, G, S>(w, sub, cr, mdiag, qf, ql, W, h, in, act, JOINT);
       pf.ph(9 + 6 * S);
       // ---- p = -H^-1 grad
       int hbad = 0;
@@ -2040,6 +2082,31 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
           real ut[NV];
           if constexpr (ND <= 6) {
             chol_rows1<NV, SS::D0, SS::D1, BASE, true>(h, ut, invd, sl, live, hbad);
+          } else if constexpr (S == KM_SUB_ALL && G == 16) {
+            if (partial) {
+              // L's arm columns from LDS (row `sub` of the factor: exact zeros on and above the diagonal), their updates replayed on
+              // the cube columns, then the cube block's six pivots
+#pragma unroll
+              for (int k = 0; k < NL; k++) h[k] = w.LT[sub][k];
+              static_for<0, NL>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                fnmac_cols<16, NL, NV, NV, true>(h, bsrc<16>(h[k]), h[k]);
+              });
+              dpp_settle(h[NL]);
+              real invc = 0;
+              chol_rows1<NV, NL, NV, 0, false>(h, ut, invc, sl, live, hbad);
+              invd = sub < NL ? invd_keep : invc;
+#pragma unroll
+              for (int k = NL; k < NV; k++) w.LT[sub][k] = h[k];
+              GSYNC();
+#pragma unroll
+              for (int k = 0; k < NV; k++) ut[k] = w.LT[k][sub];
+              GSYNC();
+            } else {
+              chol_rows1<NV, SS::D0, SS::D1, BASE, false>(h, ut, invd, sl, live, hbad);
+              chol_transpose<NV, SS::D0, SS::D1, BASE>(w.LT, h, ut, sl);
+              invd_keep = invd; sig0 = sig; cache_ok = true;
+            }
           } else {
             chol_rows1<NV, SS::D0, SS::D1, BASE, false>(h, ut, invd, sl, live, hbad);
             chol_transpose<NV, SS::D0, SS::D1, BASE>(w.LT, h, ut, sl);

@@ -13,7 +13,8 @@ names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mas
          "IK: residual + Jacobian", "IK: normal matrix", "IK: trust-region solve", "IK: select_step", "IK: ratio / radius / tests",
          "newton: start eval at qacc_smooth (when it beats the warm start)", "invert_mass: row loads (two-arm block path)"]
 names += ["-"] * (40 - len(names))
-names += ["newton: waiting for wave-mates in a loop this env does not run (divergence)", "-", "-", "-"]
+names += ["newton: waiting for wave-mates in a loop this env does not run (divergence)", "COUNT coupled-env iterations on the partial refactorisation",
+          "COUNT coupled-env iterations on the full factorisation", "COUNT wave-mates' non-plain iterations in the joint loop: partial + 65536 * full"]
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 env_id = sys.argv[2] if len(sys.argv) > 2 else "KManipSoloArm"          # 20-link ids: totals only (no per-workgroup view)
 n = 4096
@@ -45,7 +46,10 @@ per = v / nblocks / steps            # cycles (100 MHz memtime ticks?) per block
 tot = per.sum()
 print("solver", solver, "total ticks per block per step %.0f" % tot)
 for nm, x in zip(names, per):
-    print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / tot))
+    if nm.startswith("COUNT"):
+        print("  %-26s %10.4f" % (nm, x))
+    else:
+        print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / tot))
 
 # ---- per-workgroup, per-lane-group view of the LAST launch: the kernel ends when its slowest wave does, and a wave is as
 # slow as its slowest env in every phase.  Slot 13 ("integrate") of a group also holds its wait for the sibling envs.
