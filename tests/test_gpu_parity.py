@@ -586,9 +586,11 @@ def test_step_chunk_equals_single_steps(env, n, K):
     a = env_hip.make(env, num_envs=n, seed=17); b = env_hip.make(env, num_envs=n, seed=17)
     a.k_reset(); b.k_reset()
     gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    saw_done = False
     for rounds in range(11):                                             # 11 x 7 = 77 steps > 64
         acts = (torch.rand((K, n, a.cm.act_dim), generator=gen, device="cuda") * 2 - 1).contiguous()
         obs_c, rew_c, done_c = a.step_chunk(acts)
+        saw_done |= bool(done_c.any())
         for k in range(K):
             b.step_flat(acts[k])
             assert torch.equal(obs_c[k], b.obs) and torch.equal(rew_c[k], b.reward) and torch.equal(done_c[k], b.done), (rounds, k)
@@ -597,7 +599,7 @@ def test_step_chunk_equals_single_steps(env, n, K):
         assert np.array_equal(x, y)
     for x, y in zip(a.get_diag(), b.get_diag()):
         assert np.array_equal(x, y)
-    assert (a.done.cpu().numpy() | 1).all() or True
+    assert saw_done == (11 * K >= 64)             # (the SoloArm run crosses the TimeLimit auto-reset inside a chunk; the Torso run stops at step 55)
     a.k_close(); b.k_close()
 
 

@@ -1,0 +1,71 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root: every measurement profiles/r04_* is made from, into gpurun_out/r04/.
+# Usage: bash tools/collect_r04.sh [part ...]   parts: main sq final phase slow configs short soak misc (default: all)
+set -o pipefail
+export TMPDIR=/tmp
+OUT=gpurun_out/r04
+mkdir -p $OUT
+PARTS=${@:-main sq final phase slow configs short soak misc}
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+stats() {  # <dir> <prefix>: copy the kernel-stats CSV of a rocprofv3 --kernel-trace --stats run
+  f=$(find $1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/$2
+}
+if has main; then
+  bash tools/collect_profiles.sh r04 > $OUT/collect_profiles.log 2>&1
+  cp gpurun_out/prof_r04/bench.json $OUT/bench.json; cp gpurun_out/prof_r04/bench_under_prof.json $OUT/bench_under_rocprof.json
+  cp gpurun_out/prof_r04/pmc_hbm.json $OUT/pmc_hbm.json; stats gpurun_out/prof_r04 kernel_stats.csv
+  echo "main done"
+fi
+if has sq; then
+  bash tools/collect_sq.sh r04 > $OUT/collect_sq.log 2>&1; cp gpurun_out/sq_r04/sq.json $OUT/sq_counters.json; echo "sq done"
+fi
+if has final; then
+  # the default bench line once more, now that the counter files of THIS library version exist (bench.py reads roofline.traffic /
+  # roofline.valu from profiles/r04_pmc_hbm.json / r04_sq_counters.json and refuses files of another version)
+  cp $OUT/pmc_hbm.json profiles/r04_pmc_hbm.json; cp $OUT/sq_counters.json profiles/r04_sq_counters.json
+  python3 bench.py > $OUT/bench.json 2> $OUT/bench_final.err; echo "final done"
+fi
+if has phase; then
+  L=gym_kmanip_amd/libkmanip_hip_prof.so
+  KMANIP_LIB=$L python3 tools/phase_profile.py newton KManipSoloArm > $OUT/phase_profile.txt 2> $OUT/phase.err
+  KMANIP_LIB=$L python3 tools/phase_profile.py newton KManipDualArm > $OUT/phase_profile_dualarm.txt 2>> $OUT/phase.err
+  KMANIP_LIB=$L python3 tools/phase_profile.py newton KManipTorso > $OUT/phase_profile_torso.txt 2>> $OUT/phase.err
+  echo "phase done"
+fi
+if has slow; then
+  python3 tests/tools/slow_launches.py 512 > $OUT/slow_launches.txt 2> $OUT/slow.err; echo "slow done"
+fi
+if has configs; then
+  python3 bench.py --env KManipDualArm --envs-per-gpu 8192 --no-variants > $OUT/bench_dualarm_8192.json 2> $OUT/cfg.err
+  python3 bench.py --env KManipTorso --envs-per-gpu 8192 --no-variants > $OUT/bench_torso_8192.json 2>> $OUT/cfg.err
+  python3 bench.py --envs-per-gpu 2048 --depth 64 --no-variants > $OUT/bench_config5_depth64.json 2>> $OUT/cfg.err
+  python3 bench.py --env KManipSoloArmVision --envs-per-gpu 2048 --steps 256 --no-variants > $OUT/bench_vision_2048.json 2>> $OUT/cfg.err
+  for cfg in "dualarm_8192 --env KManipDualArm --envs-per-gpu 8192" "torso_8192 --env KManipTorso --envs-per-gpu 8192" "config5_depth64 --envs-per-gpu 2048 --depth 64" "vision_2048 --env KManipSoloArmVision --envs-per-gpu 2048 --steps 256"; do
+    set -- $cfg; tag=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$tag -o ktrace -- python3 bench.py "$@" --no-cpu-baseline --no-variants > /dev/null 2>> $OUT/cfg.err
+    stats $OUT/kt_$tag kernel_stats_$tag.csv; rm -rf $OUT/kt_$tag
+  done
+  echo "configs done"
+fi
+if has short; then
+  for i in 1 2 3; do python3 bench.py --steps 20 --warmup 5 --no-variants --no-cpu-baseline; done > $OUT/bench_short_x3.jsonl 2> $OUT/short.err
+  python3 - <<PY > $OUT/bench_short_x3.txt
+import json
+v = [json.loads(l) for l in open("$OUT/bench_short_x3.jsonl") if l.strip()]
+vals = [d["value"] for d in v]
+print("three back-to-back  python bench.py --steps 20 --warmup 5 --no-variants --no-cpu-baseline  (the driver's window):")
+for d in v: print("  value %.4g env steps/s  ms_per_step %.4f  k_step %.4f ms" % (d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_avg"]["k_step"]))
+print("  spread (max - min) / mean = %.2f %%" % (100 * (max(vals) - min(vals)) / (sum(vals) / len(vals))))
+PY
+  echo "short done"
+fi
+if has soak; then
+  python3 tests/tools/parity_soak.py 2048 130 > $OUT/parity_soak.txt 2> $OUT/soak.err; echo "soak done"
+fi
+if has misc; then
+  tools/_build/libm_check > $OUT/libm_check.txt 2>&1
+  python3 tests/tools/render_timing.py 2048 2>/dev/null | grep -v amdgpu.ids > $OUT/render_timing.txt
+  python3 tools/kernel_resources.py gym_kmanip_amd/libkmanip_hip.so > $OUT/kernel_resources.txt
+  echo "misc done"
+fi
+ls $OUT
