@@ -5,12 +5,13 @@
  * (tests/, __graft_entry__.smoke()) and as the timed `cpu_baseline` ("port") leg of bench.py.
  * The shipped path (gym_kmanip_amd/csrc) never links, imports or calls this file.
  *
- * PARITY STATUS: "parity unpinned" against the reference's MuJoCo numbers -- the reference
- * publishes no golden vectors (tests/test_env.py:8-24 only runs gymnasium's check_env) and
- * cannot run here (gymnasium/mujoco/dm_control absent, robot meshes git-ignored: SURVEY.md
- * section 8c).  What IS pinned: the IK half against the real scipy.optimize.least_squares
- * (the exact solver ik_mujoco.py:129-135 calls) and scipy Rotation, through
- * oracle/ik_scipy.py and tests/golden/ (generated by tests/tools/make_golden.py).
+ * PARITY STATUS: the restatements of gym-kmanip's OWN code below (before_step, ik / ik_res / ik_jac, get_observation, get_reward,
+ * initialize_episode, the k_step tuple) are pinned to the reference's own Python, run in the build container over stand-ins for
+ * its absent third-party packages (tests/tools/refrun.py -> tests/golden/ref_*.npz; tests/test_ref_fixtures.py: ko_step
+ * reproduces 419 reference steps with ctrl bit-exact), and the IK's solver to the real scipy.optimize.least_squares.
+ * The restatement of MuJoCo's mj_step (CRBA, RNE, constraint rows, solvers, Euler) and of dm_control's step order stays
+ * "parity unpinned": the reference publishes no golden vectors (tests/test_env.py:8-24 only runs gymnasium's check_env) and its
+ * engine cannot run here (gymnasium / mujoco / dm_control absent, robot meshes git-ignored: SURVEY.md section 8c).
  *
  * Restated reference code (file:line under /root/reference/gym_kmanip/):
  *   env_sim.py:23-36    KManipTask.initialize_episode      -> ko_reset
