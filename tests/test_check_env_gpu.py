@@ -271,3 +271,20 @@ def test_render_shows_the_table_rectangle():
     dep = dev.render_depth("top", 48, 64).cpu().numpy()[0]
     assert (dep >= d.cam_zfar - 1e-6).mean() > 0.3 and (dep < 2.0).mean() > 0.04
     dev.k_close()
+
+
+def test_all_cameras_in_one_launch_equal_the_single_renders():
+    """kmanip_render_rgb_multi (every camera of a *Vision observation in one launch: grid = envs x cameras) writes, bit for bit,
+    what one kmanip_render_rgb call per camera writes -- at the reference resolutions, for a two-arm id's three cameras too."""
+    import torch
+    from gym_kmanip_amd import env_hip
+    for env_id, n in (("KManipSoloArmVision", 24), ("KManipTorsoVision", 8)):
+        e = env_hip.make(env_id, num_envs=n, seed=3)
+        e.k_reset()
+        for k in range(6):
+            e.step_flat(e.sample_action())
+        multi = e.render_cameras()
+        assert list(multi) == e.cm.cameras and len(multi) >= 2
+        for cam, img in multi.items():
+            assert torch.equal(img, e.render_rgb(cam)), (env_id, cam)
+        e.k_close()
