@@ -64,3 +64,16 @@ k = min(len(first), len(later), 800)
 if k > 100:
     f = np.polyfit(first[:k], later[:k] * 10.0, 1)   # ns per cycle
     print("core clock estimate from the first-round ends: %.2f GHz (%d waves)" % (1.0 / f[0], k))
+# ---- how much of the launch is scheduling?  Greedy list scheduling of the LAST launch's measured wave durations on 1024 slots
+import heapq
+def makespan(durs, m=1024):
+    h = [0.0] * m
+    heapq.heapify(h)
+    for d in durs:
+        heapq.heappush(h, heapq.heappop(h) + d)
+    return max(h)
+d_last = starts[-1][1]
+if len(d_last) > 1024:
+    rng = np.random.default_rng(0)
+    print("list scheduling of the last launch's waves on 1024 slots (M cycles): dispatch order as run %.2f | true longest-first %.2f | random %.2f | total / 1024 = %.2f | longest wave %.2f" % (
+        makespan(d_last) / 1e6, makespan(np.sort(d_last)[::-1]) / 1e6, makespan(rng.permutation(d_last)) / 1e6, d_last.sum() / 1024 / 1e6, d_last.max() / 1e6))
