@@ -677,6 +677,21 @@ def test_raw_step_rejects_malformed_tensors():
         e.step_chunk(torch.zeros((3, 8, 7), dtype=torch.float64, device="cuda"))
     with pytest.raises(KManipError):
         e.step_chunk(torch.zeros((3, 8, 7), dtype=torch.float32, device="cuda"), obs=torch.zeros((3, 8, 27), dtype=torch.float32, device="cuda"))
+    # round-4 entry points: observe / the one-launch camera render / the record selection check their arguments too
+    with pytest.raises(KManipError):
+        e.observe(obs=torch.zeros((8, 27), dtype=torch.float32, device="cuda"))
+    with pytest.raises(KManipError):
+        e.observe(reward=torch.zeros(7, dtype=torch.float64, device="cuda"))
+    with pytest.raises(KManipError):
+        e.select_reward_done_record(0)                         # nothing bound
+    with pytest.raises(KManipError):
+        e.render_cameras(["grip_l"])                           # the single-arm model has no such camera
+    with pytest.raises(KManipError):
+        e.render_cameras(["head"], out={"head": torch.zeros((8, 480, 640, 3), dtype=torch.float32, device="cuda")})
+    import ctypes as C
+    five = (C.c_int32 * 5)(2, 2, 2, 2, 2); ptrs = (C.c_void_p * 5)()
+    assert e.L.kmanip_render_rgb_multi(e.h, 5, five, five, five, ptrs, None) != 0      # more jobs than cameras
+    assert b"bad arguments" in e.L.kmanip_last_error(e.h)
     e.k_close()
     for n in (0, -3):                                            # an empty / negative batch is refused at create
         with pytest.raises(KManipError):
