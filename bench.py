@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--solver-iterations", type=int, default=100, help="solver iteration cap (MuJoCo default 100); ablation only")
     ap.add_argument("--solver", default="newton", choices=["pgs", "newton"],
                     help="newton = MuJoCo default, what the reference runs; pgs = the north star's named solver (100 sweeps)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (long window, phase-locked, PGS, chunked, seam, the other BASELINE configs)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (long window, phase-locked, PGS, chunked, seam, two handles, the other BASELINE configs)")
     ap.add_argument("--chunk", type=int, default=16, help="also time kmanip_step_chunk with this many control steps per launch (0: skip)")
     return ap.parse_args(argv)
 
@@ -329,6 +329,33 @@ def measure_chunked(torch, w, K):
             "note": "no launch boundary per step: waves do not wait for the batch's slowest env at every step"}
 
 
+def measure_two_handles(torch, args, n, local_rank, steps=256):
+    """Secondary: TWO independent batches of n envs (two handles, two streams -- e.g. a double-buffered actor: one batch steps
+    while the policy works on the other's observations), each stepped one control step per call like `value`'s.  A single batch's
+    launch is one residency round and ends with its slowest wave -- half the SIMD time of the launch is idle (DESIGN.md 3.4b) --;
+    a second batch's waves fill the slots the first one's early finishers free.  Whole-GPU env steps/s over both batches."""
+    ws = [Workload(torch, args.env, n, local_rank, 0, i * n, args.solver, args.solver_iterations, stagger=True) for i in range(2)]
+    streams = [torch.cuda.Stream() for _ in ws]
+    for w in ws:
+        w.lay_out(16 + steps)
+    torch.cuda.synchronize()
+
+    def rounds(k):
+        for _ in range(k):
+            for w, s in zip(ws, streams):
+                with torch.cuda.stream(s):
+                    w.step()
+    rounds(16)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    rounds(steps)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    for w in ws:
+        w.close()
+    return {"what": "two independent handles of %d envs each, one stream each, every handle one kmanip_step per call" % n,
+            "value": 2 * n * steps / dt, "unit": "env steps/s", "steps": steps, "ms_per_round_of_both_steps": dt / steps * 1e3,
+            "note": "not the headline (its workload is ONE batch of %d envs): what the GPU sustains when a second batch is in flight" % n}
+
+
 def measure_seam(torch, w, steps=256):
     """The drop-in path: KManipEnvHip.k_step with a DICT of device tensors keyed like the reference action space
     (env_base.py:241-259 -> env_sim.py:196-200), returning the 5-tuple -- vs step_flat on the same envs."""
@@ -582,6 +609,7 @@ def run_rank(args):
                     out["chunked_variant"] = measure_chunked(torch, w, args.chunk)
             w.close()
             if headline and args.solver == "newton" and not args.no_stagger:
+                out["two_handles_variant"] = measure_two_handles(torch, args, n, local_rank)
                 for name, kw in OTHER_CONFIGS:      # driver-clocked lines for the other BASELINE configs (never part of `value`)
                     out[name] = measure_config(torch, local_rank=local_rank, **kw)
             if not args.no_stagger:

@@ -1,0 +1,30 @@
+import sys, os, time
+sys.path.insert(0, '.')
+import numpy as np, torch
+from gym_kmanip_amd import env_hip
+def mk(n, off):
+    e = env_hip.make("KManipSoloArm", num_envs=n, seed=0, env_id_offset=off)
+    e.k_reset(); e.set_state(step=((off + np.arange(n)) % 64).astype(np.int32))
+    return e
+def run(handles, steps, warm=70):
+    streams = [torch.cuda.Stream() for _ in handles]
+    banks = []
+    for e in handles:
+        b = torch.empty((warm + steps, e.num_envs, e.cm.act_dim), dtype=torch.float32, device="cuda")
+        for k in range(warm + steps): e.sample_action(b[k], ahead=k)
+        banks.append(b)
+    torch.cuda.synchronize()
+    for k in range(warm):
+        for e, s, b in zip(handles, streams, banks):
+            with torch.cuda.stream(s): e.step_flat(b[k])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(warm, warm + steps):
+        for e, s, b in zip(handles, streams, banks):
+            with torch.cuda.stream(s): e.step_flat(b[k])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    return sum(e.num_envs for e in handles) * steps / dt, dt / steps * 1e3
+for cfg in ([4096], [4096, 4096], [2048, 2048], [4096, 4096, 4096, 4096], [1024] * 4):
+    hs = [mk(n, sum(cfg[:i])) for i, n in enumerate(cfg)]
+    v, ms = run(hs, 256)
+    print("handles %s on their own streams: %.3f M env steps/s, %.4f ms per round of steps" % (cfg, v / 1e6, ms))
+    for e in hs: e.k_close()
