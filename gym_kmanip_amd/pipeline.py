@@ -1,0 +1,107 @@
+"""Several independent env batches kept in flight on one GPU (the deployment shape that uses the chip).
+
+One batch's control step is ONE launch that ends with its slowest wave: at 4096 single-arm envs the mean wave runs 0.72 M cycles
+and the launch 1.5 M, so over a launch the SIMDs sit idle half the time.  The reference steps one env per call
+(`KManipEnv.step`, env_base.py:241-259) and has no vector env at all; a batched caller that alternates K >= 2 batches around its
+policy -- batch A steps while the policy works on batch B's observations -- gets the idle half back WITHOUT giving up the per-step
+boundary: every batch is a handle of its own (`kmanip_create` with `env_id_offset` = its first global env id, so the K batches are
+exactly the envs of one K x n batch: RNG streams are keyed by the global id) on a stream of its own; the second batch's waves take
+the SIMD slots the first batch's early finishers free, and a batch's next step starts when ITS slowest wave ends.
+Measured (profiles/r04_multi_handle_timing.txt): 2 x 4096 single-arm envs 10.9 M env steps/s against 6.5 M for one batch; DualArm
+2 x 4096: 4.9 M against 3.9 M for one 8192-env handle.
+"""
+from __future__ import annotations
+
+import time
+from typing import List, Optional
+
+from . import env_hip
+from .model import compile_model
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class InterleavedBatches:
+    """K handles of `envs_per_batch` envs each, one stream per handle.
+
+        batches = InterleavedBatches("KManipSoloArm", 4096, k=2)
+        for i in range(batches.k):
+            with batches.on(i):
+                batches.env[i].k_reset()
+        for t in range(T):
+            for i in range(batches.k):
+                with batches.on(i):                         # torch stream context of batch i
+                    act = policy(batches.env[i].obs)        # the caller's kernels, on the same stream
+                    batches.env[i].step_flat(act)           # returns at once; nothing synchronises
+
+    Batch i holds the global envs [i * n, (i + 1) * n) of seed `seed`: its trajectories are bit for bit those of the same envs in
+    one K * n-env handle (tests/test_gpu_config_sizes.py)."""
+
+    def __init__(self, env_id: str, envs_per_batch: int, k: int = 2, device: int = 0, seed: int = 0, env_id_offset: int = 0,
+                 calibrate: bool = True, **compile_kw):
+        torch = _torch()
+        assert k >= 1
+        self.k, self.n = k, envs_per_batch
+        self.cm = compile_model(env_id, **compile_kw)
+        self.env: List[env_hip.KManipEnvHip] = [
+            env_hip.KManipEnvHip(self.cm, num_envs=envs_per_batch, device=device, seed=seed, env_id_offset=env_id_offset + i * envs_per_batch)
+            for i in range(k)]
+        with torch.cuda.device(device):
+            self.stream = [torch.cuda.Stream() for _ in range(k)]
+        self.device = device
+        if calibrate and k > 1:
+            self._separate_queues()
+
+    def on(self, i: int):
+        """torch stream context of batch i: everything enqueued inside runs on that batch's stream."""
+        return _torch().cuda.stream(self.stream[i])
+
+    def synchronize(self, i: Optional[int] = None):
+        for s in (self.stream if i is None else [self.stream[i]]):
+            s.synchronize()
+
+    def close(self):
+        for e in self.env:
+            e.k_close()
+
+    # Two streams of torch's pool can share a hardware queue; their kernels then run one after the other and two batches take
+    # twice one batch's time.  For every stream after the first: try a few pool streams on a short burst of real control steps
+    # (zero actions; the state is check-pointed before and restored after, so the probe leaves no trace) and keep the candidate
+    # that overlaps best.
+    def _separate_queues(self, tries: int = 3, reps: int = 4):
+        torch = _torch()
+        fresh = [int(e.get_episode().max()) < 0 for e in self.env]       # never reset: the probe needs a state to step from
+        for e, f in zip(self.env, fresh):
+            if f:
+                e.k_reset()
+        ck = [e.checkpoint() for e in self.env]
+        zero = torch.zeros((self.n, self.cm.act_dim), dtype=torch.float32, device=self.env[0].device)
+        torch.cuda.synchronize(self.device)
+
+        def burst(streams):
+            for _ in range(reps):
+                for e, s in zip(self.env, streams):
+                    with torch.cuda.stream(s):
+                        e.step_flat(zero)
+            torch.cuda.synchronize(self.device)
+
+        for i in range(1, self.k):
+            best = None
+            for _ in range(tries):
+                with torch.cuda.device(self.device):
+                    cand = torch.cuda.Stream()
+                trial = self.stream[:i] + [cand]
+                burst(trial)                                     # warm
+                t0 = time.perf_counter()
+                burst(trial)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, cand)
+            self.stream[i] = best[1]
+        for e, c, f in zip(self.env, ck, fresh):
+            e.restore(c)
+            if f:
+                e.set_episode([-1] * self.n)                     # as created: the caller's first k_reset is episode 0

@@ -236,3 +236,42 @@ def test_cost_sorted_wave_slots_change_nothing_but_the_order(monkeypatch):
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
     assert len(orders) > 5                                                       # and it does re-order from step to step
     a.k_close(); b.k_close()
+
+
+def test_interleaved_batches_are_the_envs_of_one_big_batch():
+    """pipeline.InterleavedBatches: K handles on K streams, stepped round-robin without synchronising.  Batch i is, bit for bit,
+    envs [i * n, (i + 1) * n) of one K * n-env handle (global-id RNG keys), and the stream-pairing probe of the constructor
+    (real control steps between a checkpoint and its restore) leaves no trace."""
+    import torch
+    import gym_kmanip_amd as k
+    from gym_kmanip_amd import env_hip
+    n, K = 512, 2
+    two = k.make_interleaved("KManipSoloArm", n, k=K, seed=9)
+    one = env_hip.make("KManipSoloArm", num_envs=K * n, seed=9)
+    plain = k.make_interleaved("KManipSoloArm", n, k=K, seed=9, calibrate=False)
+    one.k_reset()
+    for b in (two, plain):
+        for i in range(K):
+            with b.on(i):
+                b.env[i].k_reset()
+    for step in range(70):                                     # across the TimeLimit auto-reset
+        act = one.sample_action().clone()                      # (drawn on the default stream: the batches' streams wait for it)
+        one.step_flat(act)
+        for b in (two, plain):
+            for i in range(K):
+                b.stream[i].wait_stream(torch.cuda.current_stream())
+                with b.on(i):
+                    b.env[i].step_flat(act[i * n:(i + 1) * n].contiguous())
+        torch.cuda.current_stream().wait_stream(two.stream[0])  # (act's memory is reused by the next clone only after its readers)
+        for b in (two, plain):
+            for i in range(K):
+                torch.cuda.current_stream().wait_stream(b.stream[i])
+    two.synchronize(); plain.synchronize(); torch.cuda.synchronize()
+    for b in (two, plain):
+        for i in range(K):
+            sl = slice(i * n, (i + 1) * n)
+            assert torch.equal(b.env[i].obs, one.obs[sl]) and torch.equal(b.env[i].reward, one.reward[sl]) and torch.equal(b.env[i].done, one.done[sl])
+            for x, y in zip(b.env[i].get_state(), one.get_state()):
+                assert np.array_equal(x, y[sl])
+    assert two.stream[0] != two.stream[1]
+    two.close(); plain.close(); one.k_close()
