@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: every measurement profiles/r04_* is made from, into gpurun_out/r04/.
-# Usage: bash tools/collect_r04.sh [part ...]   parts: main sq final phase slow configs short soak misc (default: all)
+# Usage: bash tools/collect_r04.sh [part ...]   parts: main sq final phase slow configs short soak misc waves multi (default: all)
 set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/r04
 mkdir -p $OUT
-PARTS=${@:-main sq final phase slow configs short soak misc}
+PARTS=${@:-main sq final phase slow configs short soak misc waves multi}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 stats() {  # <dir> <prefix>: copy the kernel-stats CSV of a rocprofv3 --kernel-trace --stats run
   f=$(find $1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/$2
@@ -67,5 +67,20 @@ if has misc; then
   python3 tests/tools/render_timing.py 2048 2>/dev/null | grep -v amdgpu.ids > $OUT/render_timing.txt
   python3 tools/kernel_resources.py gym_kmanip_amd/libkmanip_hip.so > $OUT/kernel_resources.txt
   echo "misc done"
+fi
+if has waves; then
+  # per-wave cycles against the cost predictors; the single-arm fit needs a -DKM_WORK_COUNTERS_ALL build
+  python3 tests/tools/wave_times.py KManipSoloArm 4096 2>/dev/null | grep -v amdgpu > $OUT/wave_times_solo.txt
+  python3 tests/tools/wave_times.py KManipDualArm 8192 2>/dev/null | grep -v amdgpu > $OUT/wave_times_dualarm.txt
+  KMANIP_COST_SORT=0 python3 tests/tools/wave_times.py KManipDualArm 8192 2>/dev/null | grep -v amdgpu > $OUT/wave_times_dualarm_unsorted.txt
+  python3 tests/tools/wave_times.py KManipTorso 8192 2>/dev/null | grep -v amdgpu > $OUT/wave_times_torso.txt
+  bash tools/sort_ab.sh > $OUT/sort_ab.txt 2>/dev/null
+  echo "waves done"
+fi
+if has multi; then
+  for e in KManipSoloArm KManipDualArm KManipTorso KManipSoloArmVision; do python3 tests/tools/multi_handle_timing.py $e 2>/dev/null | grep handles; done > $OUT/multi_handle_timing.txt
+  tools/_build/mfma_ab > $OUT/mfma_ab.json 2>/dev/null
+  tools/_build/rsq_check > $OUT/rsq_check_raw.txt 2>/dev/null
+  echo "multi done"
 fi
 ls $OUT
