@@ -193,6 +193,16 @@ int kmanip_model_desc_size(void);
  * layout).  The library owns model, state and scratch. */
 int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t seed,
                   int64_t env_id_offset, KHandle* out);
+/* Launch shape (no effect on results: an env's bits depend neither on its wave-mates nor on the order its wave is dispatched in --
+ * tests compare shards, launch shapes and orders bit for bit).  A step is ONE launch of single-wave workgroups holding 4 (10-link
+ * models) or 2 (20-link models) envs each.  When a two-arm handle has more waves than the GPU has SIMD slots (more than 2048 envs),
+ * kmanip_step first orders the envs by the cost their last step predicts and dispatches the longest waves first (k_sort_envs, one
+ * small extra launch).  Diagnostic environment variables, read at create: KMANIP_COST_SORT=0/1 (force that order
+ * off / on), KMANIP_COST_W (its weights), KMANIP_EPB (envs per wave), KMANIP_IK_UNFUSED=1 (before_step as its own launch),
+ * KMANIP_NO_BLOCK_SPLIT=1 (two-arm inertia as one block), KMANIP_WAVE_CLOCKS=1 (per-wave cycle counts for tests/tools/wave_times.py).
+ * Throughput note: one batch's launch ends with its slowest wave and leaves about half the SIMD time idle; handles are
+ * independent and every entry point takes the caller's stream, so two or more batches kept in flight on different streams fill
+ * it (gym_kmanip_amd/pipeline.py). */
 
 /* Replaces KManipEnvSim.k_reset (env_sim.py:190-194) -> KManipTask.initialize_episode
  * (env_sim.py:23-36): reset envs whose mask byte is nonzero (NULL = all) to the home pose,
