@@ -15,7 +15,10 @@ from oracle.oracle import Oracle
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 130
+only = sys.argv[3] if len(sys.argv) > 3 else None           # optional: one env id
 for env in ["KManipSoloArm", "KManipDualArm", "KManipTorso"]:
+    if only and env != only:
+        continue
     cm = compile_model(env, auto_reset=True)
     dev = env_hip.KManipEnvHip(cm, num_envs=n, seed=11, env_id_offset=3); orc = Oracle(cm, n, seed=11, env_id_offset=3)
     dev.k_reset(); orc.reset()
@@ -30,10 +33,16 @@ for env in ["KManipSoloArm", "KManipDualArm", "KManipTorso"]:
         a = dev.sample_action()                   # bench.py's counter-based action stream
         act = a.cpu().numpy()
         assert np.array_equal(act, orc.sample_action())
+        pre = orc.get_state()
         dev.step_flat(a)
         oo, ro, do = orc.step(act, nthreads=16)
         sg, so = dev.get_state(), orc.get_state()
         ok = ~(sg[2] != so[2]).any(axis=1)       # a float32 rounding flip of ctrl (1 ulp) legitimately moves that env's step by ~1e-5
+        dvk = np.where(ok, np.abs(sg[1] - so[1]).max(axis=1), 0.0)
+        if dvk.max() > worst["v"] and os.environ.get("KM_SOAK_DUMP"):
+            e = int(dvk.argmax())                 # the worst one-step sample so far: its inputs and both outputs, for offline analysis
+            np.savez(os.path.join(os.environ["KM_SOAK_DUMP"], "worst_%s.npz" % env), step=k, env=e, act=act[e], **{"pre%d" % i: pre[i][e] for i in range(5)},
+                     **{"dev%d" % i: sg[i][e] for i in range(5)}, **{"orc%d" % i: so[i][e] for i in range(5)})
         worst["q"] = max(worst["q"], float(np.abs(sg[0] - so[0])[ok].max())); worst["v"] = max(worst["v"], float(np.abs(sg[1] - so[1])[ok].max()))
         worst["r"] = max(worst["r"], float(np.abs(dev.reward.cpu().numpy() - ro)[ok].max()))
         mg, nfg, stg = dev.get_diag(); mo, nfo, sto = orc.get_diag()
