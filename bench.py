@@ -608,33 +608,44 @@ def run_rank(args):
         }
         if dt < 0.25:
             out["warning"] = "timed window %.3f s < 0.25 s: too short for a stable rate (use --steps >= %d)" % (dt, int(0.3 / (dt / args.steps)) + 1)
+        def secondary(key, fn, into=None):
+            """A secondary measurement must never cost the run its one JSON line: a failure is recorded under its key."""
+            try:
+                (out if into is None else into)[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                (out if into is None else into)[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+
         if world == 1 and not args.no_variants:
             torch.cuda.synchronize()
             if not args.depth and not rgb_bufs:
                 if args.steps < 512 and not args.no_stagger:
                     # the driver's window (20 steps) holds none of the rare IK crawls (one launch in ~40 runs 2-7x long, DESIGN.md
                     # 3.4): the same handle, still desynchronised, over 512 further steps of the stream
-                    dtl = w.timed(512, 8)
-                    out["long_window"] = {"value": n * 512 / dtl, "unit": "env steps/s", "steps": 512, "ms_per_step": dtl / 512 * 1e3,
-                                          "note": "same handle and stream as `value`, 512 further desynchronised steps: includes the rare IK-crawl launches a 20-step window misses"}
-                out["seam_variant"] = measure_seam(torch, w)
+                    def long_window():
+                        dtl = w.timed(512, 8)
+                        return {"value": n * 512 / dtl, "unit": "env steps/s", "steps": 512, "ms_per_step": dtl / 512 * 1e3,
+                                "note": "same handle and stream as `value`, 512 further desynchronised steps: includes the rare IK-crawl launches a 20-step window misses"}
+                    secondary("long_window", long_window)
+                secondary("seam_variant", lambda: measure_seam(torch, w))
                 if args.chunk > 1:
-                    out["chunked_variant"] = measure_chunked(torch, w, args.chunk)
+                    secondary("chunked_variant", lambda: measure_chunked(torch, w, args.chunk))
             w.close()
             if headline and args.solver == "newton" and not args.no_stagger:
-                out["two_handles_variant"] = measure_two_handles(torch, args, n, local_rank)
+                secondary("two_handles_variant", lambda: measure_two_handles(torch, args, n, local_rank))
                 for name, kw in OTHER_CONFIGS:      # driver-clocked lines for the other BASELINE configs (never part of `value`)
-                    out[name] = measure_config(torch, local_rank=local_rank, **kw)
-                    if kw["n"] == 8192:             # the same 8192 envs as two independent 4096-env batches in flight
-                        out[name]["as_two_handles"] = measure_two_handles(torch, args, 4096, local_rank, steps=64, env_id=kw["env_id"])
+                    secondary(name, lambda kw=kw: measure_config(torch, local_rank=local_rank, **kw))
+                    if kw["n"] == 8192 and "error" not in out[name]:   # the same 8192 envs as two independent 4096-env batches in flight (DESIGN.md 3.4b)
+                        secondary("as_two_handles", lambda kw=kw: measure_two_handles(torch, args, 4096, local_rank, steps=64, env_id=kw["env_id"]), into=out[name])
             if not args.no_stagger:
-                out["phase_locked"] = measure_variant(torch, args, n, local_rank, rank, args.solver, False, 4 * EPISODE, EPISODE)
-                out["phase_locked"]["note"] = "all envs reset together (what plain auto-reset stepping gives: episodes never end early); whole episodes timed"
+                def phase_locked():
+                    r = measure_variant(torch, args, n, local_rank, rank, args.solver, False, 4 * EPISODE, EPISODE)
+                    r["note"] = "all envs reset together (what plain auto-reset stepping gives: episodes never end early); whole episodes timed"
+                    return r
+                secondary("phase_locked", phase_locked)
             if args.solver == "newton":
-                out["pgs_variant"] = measure_variant(torch, args, n, local_rank, rank, "pgs", not args.no_stagger, 32, 8)
+                secondary("pgs_variant", lambda: measure_variant(torch, args, n, local_rank, rank, "pgs", not args.no_stagger, 32, 8))
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed on rank 0 of the 1-GPU run only
-            out["cpu_baseline"] = cpu_baseline(cm, n)
-            out["cpu_baseline"]["solver"] = args.solver
+            secondary("cpu_baseline", lambda: dict(cpu_baseline(cm, n), solver=args.solver))
         print(json.dumps(out), flush=True)
     try:
         w.close()
