@@ -608,12 +608,31 @@ def run_rank(args):
         }
         if dt < 0.25:
             out["warning"] = "timed window %.3f s < 0.25 s: too short for a stable rate (use --steps >= %d)" % (dt, int(0.3 / (dt / args.steps)) + 1)
-        def secondary(key, fn, into=None):
-            """A secondary measurement must never cost the run its one JSON line: a failure is recorded under its key."""
+        out["secondary_errors"] = 0
+        gpu_dead = []      # a HIP / runtime error is sticky: every later GPU measurement would fail the same way
+
+        def secondary(key, fn, into=None, gpu=True):
+            """A secondary measurement must never cost the run its one JSON line: a failure is recorded under its key and counted
+            in `secondary_errors`; after a HIP / runtime error (as opposed to a Python-level one) no further GPU secondary runs."""
+            tgt = out if into is None else into
+            if gpu and gpu_dead:
+                tgt[key] = {"error": "skipped: an earlier secondary measurement (%s) left the GPU in an error state" % gpu_dead[0]}
+                out["secondary_errors"] += 1
+                return
             try:
-                (out if into is None else into)[key] = fn()
+                tgt[key] = fn()
             except Exception as e:  # noqa: BLE001
-                (out if into is None else into)[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                tgt[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["secondary_errors"] += 1
+                txt = "%s %s" % (type(e).__name__, e)
+                if gpu and (isinstance(e, (RuntimeError, MemoryError)) or "HIP" in txt or "hip" in txt):
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:  # noqa: BLE001
+                        gpu_dead.append(key)
+                    else:
+                        if "out of memory" in txt.lower() or "hipError" in txt:
+                            gpu_dead.append(key)
 
         if world == 1 and not args.no_variants:
             torch.cuda.synchronize()
@@ -645,8 +664,10 @@ def run_rank(args):
             if args.solver == "newton":
                 secondary("pgs_variant", lambda: measure_variant(torch, args, n, local_rank, rank, "pgs", not args.no_stagger, 32, 8))
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed on rank 0 of the 1-GPU run only
-            secondary("cpu_baseline", lambda: dict(cpu_baseline(cm, n), solver=args.solver))
+            secondary("cpu_baseline", lambda: dict(cpu_baseline(cm, n), solver=args.solver), gpu=False)
         print(json.dumps(out), flush=True)
+        if out["secondary_errors"] and os.environ.get("KMANIP_BENCH_STRICT") == "1":
+            sys.exit(5)      # opt-in: the JSON line is out; tell a caller that wants it (CI, collect scripts) that part of it failed
     try:
         w.close()
     except Exception:  # noqa: BLE001

@@ -243,7 +243,10 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
     if (const char* e = getenv("KMANIP_COST_SORT")) h->cost_sort = e[0] == '1';
     if (const char* e = getenv("KMANIP_COST_W")) {       // diagnostic: "ik,work,near-cube,armtab,cubetab,binwidth"
       KCostWeights w = h->cost_w;
-      if (sscanf(e, "%d,%d,%d,%d,%d,%d", &w.ik, &w.work, &w.coupled, &w.armtab, &w.cubetab, &w.binw) == 6 && w.binw > 0) h->cost_w = w;
+      // (negative weights would make a cost negative; the kernel clamps the bin, and they are refused here)
+      if (sscanf(e, "%d,%d,%d,%d,%d,%d", &w.ik, &w.work, &w.coupled, &w.armtab, &w.cubetab, &w.binw) == 6 && w.binw > 0 &&
+          w.ik >= 0 && w.work >= 0 && w.coupled >= 0 && w.armtab >= 0 && w.cubetab >= 0) h->cost_w = w;
+      else { g_create_error = "kmanip_create: KMANIP_COST_W must be six comma-separated integers >= 0 with a bin width > 0"; kmanip_destroy(h); return -2; }
     }
   }
   // the initialisation above ran on the null stream; the caller's (non-blocking) streams must not start before it
@@ -272,7 +275,7 @@ int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stre
   return 0;
 }
 
-// Diagnostics (not part of include/kmanip.h; KMANIP_WAVE_CLOCKS=1 at create): per wave slot, the ticks its wave spent in the last
+// Diagnostics (include/kmanip_debug.h, not part of the boundary; KMANIP_WAVE_CLOCKS=1 at create): per wave slot, the ticks its wave spent in the last
 // k_step, the env it held, that env's work counter and IK evaluation counts -- HOST arrays of num_envs entries.  Synchronous.
 int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env, int32_t* work) {
   if (!h || !h->st.wave_clk) return -1;

@@ -6,7 +6,7 @@
 #include <stdint.h>
 #include <type_traits>
 
-#include "../../include/kmanip.h"
+#include "../../include/kmanip_debug.h"   // includes kmanip.h
 #include "kmanip_math.hpp"
 
 #define KM_MAX_CHAIN 8

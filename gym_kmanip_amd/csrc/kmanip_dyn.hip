@@ -2668,6 +2668,16 @@ __global__ __launch_bounds__(64) void k_observe(const KDeviceModel* __restrict__
   init_ws<NL>(w, sub);
   load_state<NL, G>(w, st, env, sub, false);
   GSYNC();
+  // a state restored from a diverged checkpoint: what k_step reports for such an env -- zero observation and reward, no contacts
+  // (the kinematics of a non-finite state would put garbage into the mask the diagnostics and the next cost sort read)
+  int lb = 0;
+  for (int i = sub; i < Dim<NL>::NQ; i += G) lb |= !isfinite(w.qpos[i]);
+  for (int i = sub; i < Dim<NL>::NV; i += G) lb |= !isfinite(w.qvel[i]);
+  if (gor<G>(lb)) {
+    if (obs) for (int i = sub; i < m->obs_dim; i += G) obs[(size_t)env * m->obs_dim + i] = 0;
+    if (sub == 0) { st.contact_mask[env] = 0; if (reward) reward[env] = 0; }
+    return;
+  }
   fk_parallel<NL, G>(w, lm, sub);
   collide_parallel<NL, G>(w, m, sub);
   const real rew = env_reward<NL, G>(w, m, sub);

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_sort_envs(KDeviceState st, int32_t* __r
       // work bit 30: a collider within KM_NEAR_MARGIN of the cube (or on it) -- the coupled Newton loop is on or about to start
       const int cost = w.ik * nf + w.work * (wk[k] & 0x3FFFFFFF) + ((wk[k] >> 30) ? w.coupled : 0)
                        + ((mask[k] & KM_CON_ANY_SPHERE_TABLE) ? w.armtab : 0) + ((mask[k] & KM_CON_ANY_CUBE_TABLE) ? w.cubetab : 0);
-      b[k] = e0 + 256 * k < N ? KM_SORT_BINS - 1 - min(cost / w.binw, KM_SORT_BINS - 1) : -1;      // bin 0 = heaviest
+      b[k] = e0 + 256 * k < N ? KM_SORT_BINS - 1 - max(0, min(cost / w.binw, KM_SORT_BINS - 1)) : -1;      // bin 0 = heaviest; clamped both ways: cnt[][] / base[] are indexed by it
     }
   };
   for (int b = 0; b < KM_SORT_BINS; b++) cnt[b][t] = 0;

@@ -21,7 +21,10 @@ def shard_range(total_envs: int, world: int, rank: int) -> Tuple[int, int]:
 class RewardDoneGather:
     """Asynchronous, double-buffered all-gather of (reward, done) across ranks (equal shard sizes)."""
 
-    def __init__(self, n_local: int, world: int, device, dist=None):
+    def __init__(self, n_local: int, world: int, device, dist=None, force_collective: bool = False):
+        """force_collective: issue the real all_gather_into_tensor(async_op=True) even when world == 1 (which otherwise
+        short-circuits to a device copy) -- a one-GPU box can then execute the RCCL device-collective path the N > 1 job
+        will run (tests/test_multi_rank_gpu.py::test_rccl_device_collective_world1)."""
         import torch
         self.torch = torch
         self.dist = dist
@@ -32,6 +35,8 @@ class RewardDoneGather:
         self.pending = [None, None]
         self.k = 0                # THE step counter: step k uses buffer k & 1 (the engine keeps none of its own)
         self.env = None           # bound engine (bind): it writes rec[k & 1] inside its step launch
+        self._armed = -1          # the step before_step() last prepared: post() of a bound engine insists on it
+        self.force_collective = bool(force_collective and dist is not None)
         # gloo has no device collectives: when a one-GPU box rehearses the multi-rank path over gloo, the records are
         # staged through host memory (synchronously); RCCL (backend "nccl") gathers the device buffers directly
         self.host_stage = bool(dist is not None and world > 1 and dist.get_backend() == "gloo"
@@ -63,11 +68,17 @@ class RewardDoneGather:
         self._retire(b)
         if self.env is not None:
             self.env.select_reward_done_record(b)
+        self._armed = self.k
         return b
 
     def post(self, reward=None, done=None):
         """Start the collective on step k's local results (packed here unless the engine is bound); returns the buffer index."""
         b = self.k & 1
+        if self.env is not None and self._armed != self.k:
+            # a bound engine fills the buffer before_step() selected: without it this step wrote the OTHER buffer (or the one a
+            # collective was still reading) and the gather below would ship a stale record every other step
+            raise RuntimeError("RewardDoneGather.post(): before_step() was not called for step %d of a bound engine "
+                               "(contract: before_step(); env.step...; post())" % self.k)
         self.k += 1
         self._retire(b)           # (no-op after before_step(); the un-bound path may skip before_step)
         if self.env is None:
@@ -77,7 +88,7 @@ class RewardDoneGather:
             self.h_rec.copy_(self.rec[b])
             self.dist.all_gather_into_tensor(self.h_all, self.h_rec)
             self.all[b].copy_(self.h_all)
-        elif self.dist is not None and self.world > 1:
+        elif self.dist is not None and (self.world > 1 or self.force_collective):
             self.pending[b] = self.dist.all_gather_into_tensor(self.all[b], self.rec[b], async_op=True)
         else:
             self.all[b].copy_(self.rec[b])

@@ -141,7 +141,8 @@ class KManipEnv(_EnvBase):
 
     def __init__(self, env_id: str = "KManipSoloArm", num_envs: int = 1, device: int = 0, seed: int = 0,
                  squeeze: bool = False, env_id_offset: int = 0, device_outputs: bool = False,
-                 log_h5py: bool = False, log_prefix: str = "test", log_env_ids=None, log_backend=None, **overrides):
+                 log_h5py: bool = False, log_prefix: str = "test", log_env_ids=None, log_backend=None,
+                 log_reference_layout: bool = False, log_h5py_module=None, **overrides):
         spec: EnvSpec = ENV_SPECS[env_id]
         self.env_id = env_id
         self.seed = seed
@@ -187,9 +188,13 @@ class KManipEnv(_EnvBase):
             self.log_dir = os.path.join(DATA_DIR, "{}.{}.{}".format(log_prefix, str(uuid.uuid4())[:6], datetime.now().strftime(DATE_FORMAT)))
             os.makedirs(self.log_dir, exist_ok=True)
             from .episode_log import EpisodeLogger
-            meta = {k: v for k, v in self.info.items() if k not in ("cameras",)}
+            # log_reference_layout: the reference logger's tree exactly (`action` = grip_r broadcast over a_len key columns,
+            # `metadata` = the info dict at reset; episode_log.py, tests/golden/ref_h5_tree_*.json); default: the flat action row
+            grip = self.env.cm.act_slices.get("grip_r")
             self.logger = EpisodeLogger(self.log_dir, num_envs, self.q_len, self.env.cm.act_dim, device=self.env.obs.device,
-                                        env_ids=[0] if log_env_ids is None else log_env_ids, info=meta, backend=log_backend)
+                                        env_ids=[0] if log_env_ids is None else log_env_ids, info=self.info, backend=log_backend,
+                                        grip_r_col=None if grip is None else grip.start,
+                                        reference_action_quirk=log_reference_layout, h5py_module=log_h5py_module)
             for cam in self.cameras:                                                 # env_base.py:233-234
                 self.logger.cam(cam)
 

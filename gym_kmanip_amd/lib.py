@@ -24,6 +24,10 @@ EXPORTS = [
 ]
 
 
+# include/kmanip_debug.h: diagnostics, not part of the boundary (product build; the -DKM_PROFILE build adds kmanip_dbg_prof*)
+DEBUG_EXPORTS = ["kmanip_dbg_wave_clocks"]
+
+
 class KManipError(RuntimeError):
     pass
 
@@ -78,6 +82,7 @@ def load():
     lib.kmanip_version.restype = C.c_char_p
     lib.kmanip_destroy.argtypes = [vp]
     lib.kmanip_destroy.restype = None
+    lib.kmanip_dbg_wave_clocks.argtypes = [vp, C.POINTER(C.c_ulonglong), i32p, i32p]
     if lib.kmanip_model_desc_size() != C.sizeof(KModelDesc):
         raise KManipError("KModelDesc layout mismatch: lib %d vs python %d"
                           % (lib.kmanip_model_desc_size(), C.sizeof(KModelDesc)))

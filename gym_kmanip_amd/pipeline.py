@@ -54,6 +54,9 @@ class InterleavedBatches:
         self.device = device
         if calibrate and k > 1:
             self._separate_queues()
+        # the handles were created, their output tensors zero-filled and sim_time bound on the default stream; the batch
+        # streams are non-blocking, so nothing the caller enqueues on them may start before that is complete -- on every path
+        torch.cuda.synchronize(device)
 
     def on(self, i: int):
         """torch stream context of batch i: everything enqueued inside runs on that batch's stream."""
@@ -69,8 +72,12 @@ class InterleavedBatches:
 
     # Two streams of torch's pool can share a hardware queue; their kernels then run one after the other and two batches take
     # twice one batch's time.  For every stream after the first: try a few pool streams on a short burst of real control steps
-    # (zero actions; the state is check-pointed before and restored after, so the probe leaves no trace) and keep the candidate
-    # that overlaps best.
+    # (zero actions) and keep the candidate that overlaps best.  The probe's trace is removed: the state (qpos, qvel, ctrl, warm
+    # start, step and episode counters) is check-pointed before and restored after, and the outputs the probe's steps wrote are
+    # recomputed from the restored state (observe(): obs, reward and the contact masks get_diag / the first cost sort read) or
+    # zeroed (done, sim_time as a never-stepped handle has them).  NOT restored: the IK diagnostics (ik_nfev / ik_status of the
+    # probe's last step stay until the caller's first step overwrites them; the first cost sort of a two-arm handle reads them
+    # as a predictor -- an order, never a result).
     def _separate_queues(self, tries: int = 3, reps: int = 4):
         torch = _torch()
         fresh = [int(e.get_episode().max()) < 0 for e in self.env]       # never reset: the probe needs a state to step from
@@ -105,3 +112,10 @@ class InterleavedBatches:
             e.restore(c)
             if f:
                 e.set_episode([-1] * self.n)                     # as created: the caller's first k_reset is episode 0
+            e.observe()
+            e.done.zero_()
+            if f:
+                e.obs.zero_(); e.reward.zero_()                  # a handle that was never reset has no observation yet
+            # sim_time = steps since the env's last reset x control_timestep (kmanip_bind_sim_time), from the restored counters
+            e.sim_time.copy_(torch.from_numpy(c[4].astype("float64") * (self.cm.desc.n_sub_steps * self.cm.desc.timestep)))
+        torch.cuda.synchronize(self.device)

@@ -24,6 +24,14 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points declared in this header (and the diagnostics of
+ * kmanip_debug.h) are the ONLY symbols it exports (tests/test_abi.py compares the dynamic symbol table with the two headers). */
+#if defined(__GNUC__)
+#define KMANIP_API __attribute__((visibility("default")))
+#else
+#define KMANIP_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -185,13 +193,13 @@ typedef struct KModelDesc {
 typedef struct KHandle_* KHandle;
 
 /* sizeof(KModelDesc) as compiled into the library (host bindings check their mirror). */
-int kmanip_model_desc_size(void);
+KMANIP_API int kmanip_model_desc_size(void);
 
 /* Replaces env_sim.new(gym_env) (reference env_sim.py:206-211): build `num_envs` simulated envs
  * on HIP device `device`.  `env_id_offset` is the global index of local env 0 (multi-GPU
  * sharding: RNG streams are keyed by the GLOBAL env id so results do not depend on the shard
  * layout).  The library owns model, state and scratch. */
-int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t seed,
+KMANIP_API int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t seed,
                   int64_t env_id_offset, KHandle* out);
 /* Launch shape (no effect on results: an env's bits depend neither on its wave-mates nor on the order its wave is dispatched in --
  * tests compare shards, launch shapes and orders bit for bit).  A step is ONE launch of single-wave workgroups holding 4 (10-link
@@ -208,7 +216,7 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
  * (env_sim.py:23-36): reset envs whose mask byte is nonzero (NULL = all) to the home pose,
  * zero velocity and a fresh cube spawn; writes their observation rows.  mask/obs are device
  * pointers: mask uint8[num_envs], obs double[num_envs, obs_dim] (may be NULL). */
-int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stream);
+KMANIP_API int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stream);
 
 /* Replaces KManipEnvSim.k_step (env_sim.py:196-200): one control step for every env =
  * KManipTask.before_step (env_sim.py:38-108, incl. ik_mujoco.ik) + physics.step(10)
@@ -216,31 +224,31 @@ int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stre
  * act_dev float[num_envs, act_dim]; obs_dev double[num_envs, obs_dim];
  * reward_dev double[num_envs]; done_dev uint8[num_envs] (KM_DONE_* bits).  All device memory,
  * owned by the caller. */
-int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward_dev,
+KMANIP_API int kmanip_step(KHandle h, const float* act_dev, double* obs_dev, double* reward_dev,
                 uint8_t* done_dev, void* stream);
 
 /* State access for parity tests / checkpointing (state is
  * (qpos, qvel, ctrl, qacc_warmstart, time)); HOST pointers, env-major
  * [num_envs, nq|nv|nu|nv], step_idx int32[num_envs]; any pointer may be NULL. Synchronous. */
-int kmanip_get_state(KHandle h, double* qpos, double* qvel, double* ctrl, double* qacc_warm,
+KMANIP_API int kmanip_get_state(KHandle h, double* qpos, double* qvel, double* ctrl, double* qacc_warm,
                      int32_t* step_idx);
-int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const double* ctrl,
+KMANIP_API int kmanip_set_state(KHandle h, const double* qpos, const double* qvel, const double* ctrl,
                      const double* qacc_warm, const int32_t* step_idx);
 
 /* The episode counter completes the checkpoint: the cube-spawn stream is keyed (seed, global env id, episode), so a
  * restored run draws the same spawns as the original only if `episode` is restored too.  HOST int32[num_envs]. Synchronous. */
-int kmanip_get_episode(KHandle h, int32_t* episode);
-int kmanip_set_episode(KHandle h, const int32_t* episode);
+KMANIP_API int kmanip_get_episode(KHandle h, int32_t* episode);
+KMANIP_API int kmanip_set_episode(KHandle h, const int32_t* episode);
 
 /* Asynchronous device-to-device copy of the per-env counters into caller-owned DEVICE buffers (int32[num_envs] each, either
  * may be NULL) on `stream`: lets the k_step seam return sim_time (= step_idx * control_timestep, env_sim.py:194,200) as a
  * device tensor without synchronising. */
-int kmanip_get_counters(KHandle h, int32_t* step_idx_dev, int32_t* episode_dev, void* stream);
+KMANIP_API int kmanip_get_counters(KHandle h, int32_t* step_idx_dev, int32_t* episode_dev, void* stream);
 
 /* Bind a caller-owned DEVICE buffer double[num_envs] that every kmanip_step / kmanip_reset also fills with the env's
  * simulation time (dm_control's data.time, the last element of k_step's return tuple, env_sim.py:194,200) =
  * steps since the env's last reset x control_timestep.  NULL unbinds.  The buffer must outlive the binding. */
-int kmanip_bind_sim_time(KHandle h, double* sim_time_dev);
+KMANIP_API int kmanip_bind_sim_time(KHandle h, double* sim_time_dev);
 
 /* The multi-GPU learner's per-step exchange is one packed record per env, (reward, done as a double), all-gathered across the
  * ranks (gym_kmanip_amd/dist.py).  Bound here, every kmanip_step writes that record itself into ONE of two
@@ -251,24 +259,25 @@ int kmanip_bind_sim_time(KHandle h, double* sim_time_dev);
  * been made to wait for it -- BEFORE the kmanip_step that fills b is enqueued; two buffers only mean that step k may overlap
  * the exchange of step k-1, not that no wait is needed (dist.RewardDoneGather.before_step).  The library keeps no counter of
  * its own: a step without an exchange (evaluation, a failed launch) cannot put the two sides out of phase. */
-int kmanip_bind_reward_done_record(KHandle h, double* rec0_dev, double* rec1_dev);
+KMANIP_API int kmanip_bind_reward_done_record(KHandle h, double* rec0_dev, double* rec1_dev);
 /* index 0 / 1: the bound buffer the following kmanip_step calls fill. */
-int kmanip_select_reward_done_record(KHandle h, int index);
+KMANIP_API int kmanip_select_reward_done_record(KHandle h, int index);
 
 /* KManipTask.get_observation + get_reward (env_sim.py:110-179) of every env's CURRENT state, without stepping -- what
  * dm_control evaluates after a physics.forward(): obs_dev double[num_envs, obs_dim], reward_dev double[num_envs] (either may be
- * NULL); the contact masks kmanip_get_diag returns are refreshed too.  Used by the parity tests against fixtures made from the
+ * NULL); the contact masks kmanip_get_diag returns are refreshed too.  An env whose qpos / qvel hold a non-finite value (a restored
+ * diverged checkpoint) gets what kmanip_step reports for a diverged env: zero observation, zero reward, an empty contact mask.  Used by the parity tests against fixtures made from the
  * reference's own Python (tests/golden/ref_obs_*.npz) and by callers that restore a checkpoint with kmanip_set_state. */
-int kmanip_observe(KHandle h, double* obs_dev, double* reward_dev, void* stream);
+KMANIP_API int kmanip_observe(KHandle h, double* obs_dev, double* reward_dev, void* stream);
 
 /* KManipEnv.reset(seed=...) (env_base.py:219-220): re-key the cube-spawn stream.  restart_episodes != 0 also rewinds every
  * env's episode counter so that the next kmanip_reset draws episode 0 of the new seed (reset(seed=s) is then reproducible). */
-int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes);
+KMANIP_API int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes);
 
 /* Per-env diagnostics of the last kmanip_step (HOST pointers, may be NULL):
  * contact_mask uint32 (KM_CON_* bits, from the trailing mj_step1), ik_nfev int32[num_envs, 2],
  * ik_status int32[num_envs, 2]. Synchronous. */
-int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status);
+KMANIP_API int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status);
 
 /* Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).  While enabled, every kmanip_step
  * records an event before and after k_step, one more after the bound in-step render, and -- only on the KMANIP_IK_UNFUSED=1 A/B
@@ -277,51 +286,51 @@ int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t
  * summed durations in milliseconds of the three legs (stand-alone IK: 0 on the product path; k_step; k_render of
  * kmanip_bind_step_depth: 0 when nothing is bound) over the recorded steps, then clears the ring.  Any output pointer may be NULL. */
 #define KM_TIMING_SLOTS 1024
-int kmanip_enable_timing(KHandle h, int enable);
-int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, double* render_ms_sum, int32_t* nsteps);
+KMANIP_API int kmanip_enable_timing(KHandle h, int enable);
+KMANIP_API int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, double* render_ms_sum, int32_t* nsteps);
 
 /* nsteps control steps in ONE launch, for callers that already hold the next nsteps actions of every env (action-chunking
  * policies such as ACT, scripted / replayed action streams): exactly the result of nsteps consecutive kmanip_step calls,
  * with act_dev float[nsteps, num_envs, act_dim], obs_dev double[nsteps, num_envs, obs_dim], reward_dev double[nsteps,
  * num_envs], done_dev uint8[nsteps, num_envs].  Without a launch boundary per step the waves do not wait for the
  * batch's slowest env at every step, so throughput follows the mean wave rather than the slowest one. */
-int kmanip_step_chunk(KHandle h, int nsteps, const float* act_dev, double* obs_dev, double* reward_dev,
+KMANIP_API int kmanip_step_chunk(KHandle h, int nsteps, const float* act_dev, double* obs_dev, double* reward_dev,
                       uint8_t* done_dev, void* stream);
 
 /* Standalone batched IK (ik_mujoco.ik, reference ik_mujoco.py:100-155) for parity tests:
  * qpos HOST double[n, nq] (in: current; out: qpos after the IK's last evaluation),
  * goal_pos double[n,3], goal_quat double[n,4] (wxyz), arm 0/1; q_out double[n, arm_nq]
  * (the clipped result.x that the reference writes into ctrl). Synchronous. */
-int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos,
+KMANIP_API int kmanip_ik(KHandle h, int arm, int n, double* qpos, const double* goal_pos,
               const double* goal_quat, double* q_out, int32_t* nfev, int32_t* status);
 
 /* ik_res / ik_jac (reference ik_mujoco.py:20-53 / :56-97) as the device IK evaluates them, at x = qpos[q_mask] with
  * q_pos_prev = x, for parity tests: qpos HOST double[n, nq], goal_pos [n,3], goal_quat [n,4] (wxyz);
  * res double[n, 6 + 2*arm_nq], jac double[n, (6 + 2*arm_nq) x arm_nq] row-major.  Synchronous. */
-int kmanip_ik_eval(KHandle h, int arm, int n, const double* qpos, const double* goal_pos,
+KMANIP_API int kmanip_ik_eval(KHandle h, int arm, int n, const double* qpos, const double* goal_pos,
                    const double* goal_quat, double* res, double* jac);
 
 /* Replaces KManipEnvSim.k_render (env_sim.py:187-188) / the camera branch of get_observation
  * (env_sim.py:140-145) for the gripper cameras, as BASELINE.json config 5 defines it: a height x width
  * float32 DEPTH image (metres along the optical axis) of every env's current state.
  * depth_dev: float[num_envs, height, width] device memory owned by the caller. */
-int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream);
+KMANIP_API int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_dev, void* stream);
 
 /* The same cameras as uint8 RGB, what dm_control's physics.render(height, width, camera_id) returns for the camera
  * observations of the *Vision env ids (env_sim.py:140-145; shapes env_base.py:140-146, cameras __init__.py:157-161) and for
  * KManipEnv.render() (env_base.py:215-217, the `top` camera): rgb_dev uint8[num_envs, height, width, 3], caller-owned
  * device memory.  Lambert shading of the surrogate scene under the reference's lights (scene.xml:8-13). */
-int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint8_t* rgb_dev, void* stream);
+KMANIP_API int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint8_t* rgb_dev, void* stream);
 /* ncam (<= KM_MAX_CAMS) of those images in ONE launch: the whole camera branch of a *Vision observation (head 480 x 640 + grip
  * 40 x 60 per arm: env_base.py:140-146) costs the step's stream one launch instead of one per camera.  cams / heights / widths /
  * rgb_dev are HOST arrays of ncam entries; rgb_dev[i] is device memory uint8[num_envs, heights[i], widths[i], 3]. */
-int kmanip_render_rgb_multi(KHandle h, int ncam, const int* cams, const int* heights, const int* widths, uint8_t* const* rgb_dev,
+KMANIP_API int kmanip_render_rgb_multi(KHandle h, int ncam, const int* cams, const int* heights, const int* widths, uint8_t* const* rgb_dev,
                             void* stream);
 
 /* BASELINE config 5 ("64x64 gripper-cam depth render in the step"): bind a caller-owned device buffer
  * float[num_envs, height, width]; every kmanip_step then ends by rendering camera `cam` of the state it produced into it,
  * on the step's stream (one C call per control step).  depth_dev == NULL unbinds. */
-int kmanip_bind_step_depth(KHandle h, int cam, int height, int width, float* depth_dev);
+KMANIP_API int kmanip_bind_step_depth(KHandle h, int cam, int height, int width, float* depth_dev);
 
 /* The scripted data-generation policy of reference examples/2_synthetic_data.py:28-41, for every env, on device:
  * act_dev float[num_envs, act_dim] arrives holding action_space.sample() (the caller draws it) and leaves with its
@@ -329,7 +338,7 @@ int kmanip_bind_step_depth(KHandle h, int cam, int height, int width, float* dep
  * (cube_pos - site("eer_site_pos").xpos, normalised), evaluated at the env's current state.  The reference
  * stores that vector as float64 in the action dict; the flat action buffer is float32 (ACT_DTYPE).
  * Returns an error for env ids without an eer_pos action (the *QPos ids). */
-int kmanip_scripted_action(KHandle h, float* act_dev, void* stream);
+KMANIP_API int kmanip_scripted_action(KHandle h, float* act_dev, void* stream);
 
 /* action_space.sample() for every env, on device -- what the reference's rollout loops feed env.step with
  * (examples/2_log_with_h5py.py:22-26, 3_save_to_video.py:20-27; spaces env_base.py:151-188: every key a Box(-1, 1, float32)):
@@ -338,14 +347,14 @@ int kmanip_scripted_action(KHandle h, float* act_dev, void* stream);
  * on the shard layout or on what was drawn before, and the CPU oracle draws identical bits (SURVEY 8d's synthetic inputs).
  * `ahead` >= 0 draws the action the env will need `ahead` control steps from now, assuming TimeLimit-only episodes (the
  * reference never terminates early), so the next K actions can be laid out before stepping. */
-int kmanip_sample_action(KHandle h, float* act_dev, int ahead, void* stream);
+KMANIP_API int kmanip_sample_action(KHandle h, float* act_dev, int ahead, void* stream);
 
-int kmanip_num_envs(KHandle h);
-const char* kmanip_last_error(KHandle h);   /* h may be NULL: error of the last failed create */
-const char* kmanip_version(void);
+KMANIP_API int kmanip_num_envs(KHandle h);
+KMANIP_API const char* kmanip_last_error(KHandle h);   /* h may be NULL: error of the last failed create */
+KMANIP_API const char* kmanip_version(void);
 
 /* Replaces KManipEnvSim.k_close (env_sim.py:202-203). */
-void kmanip_destroy(KHandle h);
+KMANIP_API void kmanip_destroy(KHandle h);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,33 @@ def test_header_symbols_exported(L):
         assert hasattr(L, name), name
 
 
+def _declared(header, macros=()):
+    """Function names a header declares, after the C preprocessor (so #ifdef'd diagnostics count only when their macro is set)."""
+    import subprocess
+    out = subprocess.check_output(["gcc", "-E", "-P", "-x", "c"] + ["-D" + m for m in macros]
+                                  + [os.path.join(ROOT, "include", header)], text=True)
+    return set(re.findall(r"\b(kmanip_[a-z_0-9]+)\s*\(", out))
+
+
+def test_exported_symbols_are_exactly_the_declared_ones(L):
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table holds the functions of include/kmanip.h and
+    include/kmanip_debug.h and NOTHING else (no C++ launch helpers, no kernel stubs, no libstdc++ instantiations)."""
+    import shutil
+    import subprocess
+    if shutil.which("nm") is None or shutil.which("gcc") is None:
+        pytest.skip("no binutils / gcc")
+    rows = [l.split() for l in subprocess.check_output(["nm", "-D", "--defined-only", klib.LIB_PATH], text=True).splitlines()]
+    exported = {r[-1] for r in rows}
+    assert all(r[-2] == "T" for r in rows), [r for r in rows if r[-2] != "T"]
+    assert _declared("kmanip.h") == set(klib.EXPORTS)
+    assert _declared("kmanip_debug.h") == set(klib.EXPORTS) | set(klib.DEBUG_EXPORTS)
+    assert exported == set(klib.EXPORTS) | set(klib.DEBUG_EXPORTS), exported ^ (set(klib.EXPORTS) | set(klib.DEBUG_EXPORTS))
+    prof = os.path.join(os.path.dirname(klib.LIB_PATH), "libkmanip_hip_prof.so")
+    if os.path.exists(prof):      # the diagnostic build: the same rule with KM_PROFILE's extra declarations
+        exp = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", prof], text=True).splitlines()}
+        assert exp == _declared("kmanip_debug.h", ["KM_PROFILE"]), exp ^ _declared("kmanip_debug.h", ["KM_PROFILE"])
+
+
 def test_desc_layout_matches(L):
     assert L.kmanip_model_desc_size() == C.sizeof(KModelDesc)
     assert b"gfx950" in L.kmanip_version()
@@ -76,5 +103,6 @@ def test_header_is_plain_c():
     hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "kmanip.h")
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
-    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", hdr])
+    for h in (hdr, hdr.replace("kmanip.h", "kmanip_debug.h")):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", h])
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", h])

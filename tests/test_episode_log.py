@@ -14,43 +14,13 @@ def _load_meta(z):
     return json.loads(bytes(z["metadata"]).decode())
 
 
-class _FakeAttrs(dict):
-    def __setitem__(self, k, v):
-        if isinstance(v, (dict, set)) or (isinstance(v, list) and v and not isinstance(v[0], (int, float, str))):
-            raise TypeError("h5py cannot store %r" % type(v))         # what h5py does for objects without an HDF5 type
-        super().__setitem__(k, v)
+import os
+import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+import h5_recorder as H5  # noqa: E402  (the recording h5py stand-in the reference's own logger was run against)
 
-class _FakeNode:
-    def __init__(self):
-        self.attrs, self.children = _FakeAttrs(), {}
-
-    def create_group(self, path):
-        node = self
-        for part in path.strip("/").split("/"):
-            node = node.children.setdefault(part, _FakeNode())
-        return node
-
-    def create_dataset(self, path, data=None, chunks=None):
-        parts = path.strip("/").split("/")
-        node = self.create_group("/".join(parts[:-1])) if len(parts) > 1 else self
-        node.children[parts[-1]] = ("dataset", np.array(data), chunks)
-
-
-class _FakeH5:
-    """h5py's File / Group / attrs surface that log_h5py.py uses, in memory -- executes the logger's h5py branch where the real
-    module cannot be installed (the real one is exercised by test_h5py_file_when_available wherever it exists)."""
-    files = {}
-
-    class File(_FakeNode):
-        def __init__(self, path, mode, rdcc_nbytes=None):
-            super().__init__()
-            assert mode == "w" and rdcc_nbytes == 2 * 1024 ** 2
-            self.path, self.closed = path, False
-
-        def close(self):
-            self.closed = True
-            _FakeH5.files[self.path] = self
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _episode(lg, n, q_len, a_len, cams=()):
@@ -63,32 +33,88 @@ def _episode(lg, n, q_len, a_len, cams=()):
     return last
 
 
-def test_h5py_branch_builds_the_reference_tree(tmp_path):
-    """log_h5py.new / cam / step restated: root attr `sim`, `metadata` attrs (unstorable values skipped), `observations/images`
-    group, float32 qpos / qvel / action datasets, and per camera `metadata/camera/<name>` attrs + a uint8
-    `observations/images/<name>` dataset chunked one frame at a time."""
-    from gym_kmanip_amd.model import CAMERAS
-    cm = compile_model("KManipSoloArmVision")
-    n, q_len, a_len = 3, 10, cm.act_dim
-    lg = EpisodeLogger(str(tmp_path), n, q_len, a_len, env_ids=[2], info={"sim": True, "q_len": q_len, "cameras": {"not": "storable"}},
-                       backend="h5py", h5py_module=_FakeH5)
-    cam = CAMERAS["grip_r"]
-    lg.cam(cam)
-    last = _episode(lg, n, q_len, a_len, [cam])
+def ref_tree(env_id):
+    return json.load(open(os.path.join(GOLDEN, "ref_h5_tree_%s.json" % env_id)))
+
+
+def shell_info(env_id):
+    """The constructor part of KManipEnv.info (env_base.py:201-212) as gym_shell builds it, without a device."""
+    from gym_kmanip_amd import gym_shell
+    from gym_kmanip_amd.model import CAMERAS, ENV_SPECS
+    spec = ENV_SPECS[env_id]
+    sp = gym_shell.spaces_for(env_id)
+    return {"step": 0, "episode": 0, "is_success": False, "q_keys": gym_shell.q_keys_for(env_id), "q_len": len(spec.q_pos_home),
+            "a_len": len(sp["action"]), "obs_list": list(spec.obs_list), "act_list": list(spec.act_list),
+            "cameras": [CAMERAS[o.split("/")[-1]] for o in spec.obs_list if "camera" in o], "sim": True}
+
+
+def assert_same_tree(ours, ref, path="", extra_attrs=()):
+    """Node for node: the same attrs (dtype, shape, value where the fixture keeps one), groups and datasets (shape, dtype, chunks).
+    extra_attrs: attrs ours may have on top (the batch's `env` / `steps` in `metadata`)."""
+    extra = set(extra_attrs) if path == "/metadata" else set()
+    assert set(ours["attrs"]) - extra == set(ref["attrs"]), (path, set(ours["attrs"]) ^ set(ref["attrs"]))
+    for k, r in ref["attrs"].items():
+        o = ours["attrs"][k]
+        assert o["dtype"] == r["dtype"] and o["shape"] == r["shape"], (path, k, o, r)
+        if "value" in r:
+            assert o["value"] == r["value"], (path, k, o["value"], r["value"])
+    assert set(ours["datasets"]) == set(ref["datasets"]), (path, set(ours["datasets"]) ^ set(ref["datasets"]))
+    for k, r in ref["datasets"].items():
+        assert ours["datasets"][k] == r, (path, k, ours["datasets"][k], r)
+    assert set(ours["groups"]) == set(ref["groups"]), (path, set(ours["groups"]) ^ set(ref["groups"]))
+    for k in ref["groups"]:
+        assert_same_tree(ours["groups"][k], ref["groups"][k], path + "/" + k, extra_attrs)
+
+
+@pytest.mark.parametrize("env_id", ["KManipSoloArm", "KManipDualArm", "KManipTorso", "KManipSoloArmVision"])
+def test_reference_layout_is_the_reference_loggers_tree(tmp_path, env_id):
+    """EpisodeLogger(h5py branch, reference_action_quirk=True) against tests/golden/ref_h5_tree_<id>.json -- the tree the
+    reference's own log_h5py.new / cam / step / end built inside its KManipEnv(log_h5py=True) (tests/tools/make_golden_ref.py)."""
+    ref = ref_tree(env_id)
+    cm = compile_model(env_id)
+    info = shell_info(env_id)
+    n, q_len = 3, info["q_len"]
+    assert ref["tree"]["groups"]["metadata"]["attrs"]["a_len"]["value"] == info["a_len"] != cm.act_dim
+    H5.FILES.clear()
+    lg = EpisodeLogger(str(tmp_path), n, q_len, cm.act_dim, env_ids=[2], info=info, grip_r_col=cm.act_slices["grip_r"].start,
+                       reference_action_quirk=True, backend="h5py", h5py_module=H5)
+    for cam in info["cameras"]:
+        lg.cam(cam)
+    _episode(lg, n, q_len, cm.act_dim, info["cameras"])
     (path,) = lg.end_episode()
-    f = _FakeH5.files[path]
-    assert path.endswith("episode_1_env2.hdf5") and f.closed and f.attrs["sim"] is True
-    meta = f.children["metadata"]
-    assert meta.attrs["episode"] == 1 and meta.attrs["env"] == 2 and "cameras" not in meta.attrs
-    cam_meta = meta.children["camera"].children["grip_r"].attrs
-    assert cam_meta["resolution"] == [60, 40] and cam_meta["focal_length"] == 45 and cam_meta["principal_point"] == [30, 20]
-    obs = f.children["observations"].children
-    kind, qp, _ = obs["qpos"]
-    assert kind == "dataset" and qp.shape == (MAX_EPISODE_STEPS, q_len) and qp.dtype == np.float32
-    kind, img, chunks = obs["images"].children["grip_r"]
-    assert img.shape == (MAX_EPISODE_STEPS, 40, 60, 3) and img.dtype == np.uint8 and chunks == (1, 40, 60, 3)
-    assert np.array_equal(img[-1], last["grip_r"][2].numpy())
-    assert f.children["action"][1].shape == (MAX_EPISODE_STEPS, a_len)
+    f = H5.FILES[path]
+    assert f.closed and f.rdcc_nbytes == ref["rdcc_nbytes"] and os.path.basename(path) == "episode_1_env2.hdf5"
+    ours = H5.tree(f, skip_attr_values=("cpu_time",))
+    assert_same_tree(ours, ref["tree"], extra_attrs=("env", "steps"))
+    meta = ours["groups"]["metadata"]["attrs"]
+    assert meta["env"]["value"] == 2 and meta["steps"]["value"] == MAX_EPISODE_STEPS
+    assert "reward" not in meta and ("cameras" in meta) == (not info["cameras"])      # None / dataclass lists have no HDF5 type
+
+
+def test_default_layout_differs_from_the_reference_tree_only_where_documented(tmp_path):
+    """The default layout against the same fixture: `action` is [64, act_dim] (the flat row) instead of the reference's
+    [64, number of action keys] of broadcast grip_r, and `metadata` holds the caller's info + env / steps."""
+    ref = ref_tree("KManipSoloArm")
+    cm = compile_model("KManipSoloArm")
+    H5.FILES.clear()
+    lg = EpisodeLogger(str(tmp_path), 2, 10, cm.act_dim, info={"sim": True}, backend="h5py", h5py_module=H5)
+    _episode(lg, 2, 10, cm.act_dim)
+    ours = H5.tree(H5.FILES[lg.end_episode()[0]])
+    assert ours["datasets"]["action"] == {"shape": [MAX_EPISODE_STEPS, cm.act_dim], "dtype": "float32", "chunks": None}
+    assert ref["tree"]["datasets"]["action"]["shape"] == [MAX_EPISODE_STEPS, 3]
+    assert ours["groups"]["observations"] == ref["tree"]["groups"]["observations"]
+    assert ours["attrs"] == ref["tree"]["attrs"]
+
+
+def test_reference_action_rows_hold_grip_r_only():
+    """What the fixture says about log_h5py.py:55: every logged action row is action["grip_r"] broadcast over a_len columns."""
+    z = np.load(os.path.join(GOLDEN, "ref_scripted_KManipSoloArm.npz"))
+    cm = compile_model("KManipSoloArm")
+    col = cm.act_slices["grip_r"].start
+    assert z["h5/action"].shape == (MAX_EPISODE_STEPS, 3) and z["h5/action"].dtype == np.float32
+    assert np.array_equal(z["h5/action"], np.repeat(z["action"][:, col:col + 1], 3, axis=1))
+    assert np.array_equal(z["h5/observations/qpos"], z["obs"][:, :10].astype(np.float32))
+    assert np.array_equal(z["h5/observations/qvel"], z["obs"][:, 10:20].astype(np.float32))
 
 
 def test_h5py_file_when_available(tmp_path):

@@ -134,3 +134,110 @@ def test_hip_reset_vs_reference_run(env_id):
     obs, _ = dev.observe()
     assert np.abs(obs.cpu().numpy()[:, obs_columns(cm)] - r["reset_obs"]).max() < 1e-12
     dev.k_close()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Round 5: the reference's own logger (log_h5py.py run inside KManipEnv(log_h5py=True)), the scripted-data heuristic of
+# examples/2_synthetic_data.py:28-41 evaluated on the reference env object, and info["is_success"] (env_base.py:250).
+SCRIPTED_IDS = ["KManipSoloArm", "KManipDualArm", "KManipTorso"]
+
+
+@pytest.mark.parametrize("env_id", SCRIPTED_IDS)
+def test_hip_scripted_action_vs_reference_heuristic(env_id):
+    """kmanip_scripted_action value for value: at each of the reference episode's 64 states the eer_pos columns must be the
+    reference's `raw_action` (float64 there, float32 in the flat action row: one float32 ulp), every other column untouched."""
+    r = _ref("ref_scripted_%s.npz" % env_id)
+    T = len(r["action"])
+    cm, dev, torch = _dev(env_id, T, auto_reset=False)
+    dev.set_state(r["pre_qpos"], r["pre_qvel"], r["pre_ctrl"], r["pre_warm"])
+    act = dev.scripted_action(torch.from_numpy(r["action_sampled"]).cuda()).cpu().numpy()
+    sl = cm.act_slices["eer_pos"]
+    ulp = np.spacing(np.abs(r["raw_action"]).astype(np.float32)).astype(np.float64)
+    assert (np.abs(act[:, sl].astype(np.float64) - r["raw_action"]) <= ulp).all()
+    other = np.ones(cm.act_dim, dtype=bool); other[sl] = False
+    assert np.array_equal(act[:, other], r["action_sampled"][:, other])
+    assert np.abs(np.linalg.norm(act[:, sl].astype(np.float64), axis=1) - 1).max() < 1e-6
+    # ... and the step the reference then took from that state with that action (its float64 eer_pos rounded to the row's float32)
+    dev.step_flat(torch.from_numpy(r["action"]).cuda())
+    q, v = dev.get_state()[:2]
+    # IK-limited bars (test_ref_fixtures.test_oracle_scripted_policy_vs_reference_heuristic): the reference's before_step saw the
+    # float64 heuristic vector, the flat row holds its float32 rounding; qvel of a sample within 400 x its qpos difference
+    dq, dv = np.abs(q - r["post_qpos"]).max(1), np.abs(v - r["post_qvel"]).max(1)
+    assert dq.max() < 1e-6 and (dv <= 1e-7 + 400 * dq).all(), (dq.max(), dv.max())
+    assert np.abs(dev.obs.cpu().numpy()[:, obs_columns(cm)] - r["obs"]).max() < 1e-5
+    assert np.abs(dev.reward.cpu().numpy() - r["reward"]).max() < 1e-6
+    dev.k_close()
+
+
+@pytest.mark.parametrize("env_id", SCRIPTED_IDS)
+def test_shell_is_success_vs_reference(env_id):
+    """info["is_success"] = reward > REWARD_SUCCESS_THRESHOLD (env_base.py:250) on the rigged state the reference itself called a
+    success (the cube at the right gripper site: 0.01 / (dist + 1e-6) > 2), and False on every step of its scripted episode."""
+    from gym_kmanip_amd import gym_shell
+    r = _ref("ref_scripted_%s.npz" % env_id)
+    assert bool(r["success_is_success"]) and float(r["success_reward"]) > float(r["success_threshold"]) == 2.0
+    env = gym_shell.KManipEnv(env_id, num_envs=2, seed=0)
+    env.reset()
+    st = lambda a: np.stack([a, a])
+    env.env.set_state(st(r["success_qpos"]), st(r["success_qvel"]), st(r["success_ctrl"]), st(r["success_warm"]), np.zeros(2, dtype=np.int32))
+    cm = env.env.cm
+    action = {k: np.stack([r["success_action"][sl]] * 2) for k, sl in cm.act_slices.items()}
+    obs, rew, term, trunc, info = env.step(action)
+    assert np.abs(rew - float(r["success_reward"])).max() < 1e-4 * float(r["success_reward"])      # 1 / dist at dist ~ 1 mm: relative
+    assert info["is_success"].all() and not term.any() and not trunc.any()
+    # an ordinary state of the reference's episode: not a success there, not a success here
+    k = 20
+    env.env.set_state(st(r["pre_qpos"][k]), st(r["pre_qvel"][k]), st(r["pre_ctrl"][k]), st(r["pre_warm"][k]), np.zeros(2, dtype=np.int32))
+    obs, rew, term, trunc, info = env.step({kk: np.stack([r["action"][k][sl]] * 2) for kk, sl in cm.act_slices.items()})
+    assert not r["is_success"].any() and not info["is_success"].any() and np.abs(rew - r["reward"][k]).max() < 1e-6
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", SCRIPTED_IDS + ["KManipSoloArmVision"])
+def test_episode_logger_tree_and_data_vs_reference_logger(env_id, tmp_path, monkeypatch):
+    """f-3 against the reference's OWN logger.  The reference episode of ref_scripted_<id>.npz is replayed on the device through the
+    Gymnasium-shaped shell with log_h5py=True, log_reference_layout=True and the recording h5py stand-in the reference's log_h5py
+    was run against (tests/tools/h5_recorder.py); the tree EpisodeLogger writes from its device rings must be the tree of
+    tests/golden/ref_h5_tree_<id>.json node for node (groups, attrs incl. values, dataset shapes / dtypes / chunks) and its
+    datasets must hold the reference file's numbers: `action` exactly (grip_r broadcast over a_len key columns),
+    `observations/qpos|qvel` to the float32 of the 1e-6 one-step parity bar."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import h5_recorder as H5
+    import json
+    from gym_kmanip_amd import gym_shell
+    from test_episode_log import assert_same_tree
+    ref = json.load(open(os.path.join(GOLDEN, "ref_h5_tree_%s.json" % env_id)))
+    r = _ref("ref_scripted_%s.npz" % env_id)
+    T = len(r["action"])
+    monkeypatch.setattr(gym_shell, "DATA_DIR", str(tmp_path))
+    H5.FILES.clear()
+    env = gym_shell.KManipEnv(env_id, num_envs=4, seed=0, log_h5py=True, log_prefix="sim_synth", log_backend="h5py",
+                              log_h5py_module=H5, log_reference_layout=True, log_env_ids=[1])
+    cm = env.env.cm
+    env.reset()
+    zero = np.zeros(4, dtype=np.int32)
+    rep = lambda a: np.stack([a] * 4)
+    env.env.set_state(rep(r["reset_qpos"]), rep(r["reset_qvel"]), rep(r["reset_ctrl"]), rep(r["reset_warm"]), zero)
+    for t in range(T):
+        # every step starts from the reference's own pre-step state (one-step comparison: the logged rows then differ from the
+        # reference file's by the one-step parity bar, not by an episode's accumulated drift)
+        env.env.set_state(rep(r["pre_qpos"][t]), rep(r["pre_qvel"][t]), rep(r["pre_ctrl"][t]), rep(r["pre_warm"][t]), zero + t)
+        env.step({k: rep(r["action"][t][sl]) for k, sl in cm.act_slices.items()})
+    env.close()
+    (path, f), = H5.FILES.items()
+    assert f.closed and os.path.basename(path) == "episode_1_env1.hdf5" and os.path.basename(os.path.dirname(path)).startswith(ref["log_dir_prefix"] + ".")
+    ours = H5.tree(f, skip_attr_values=("cpu_time",))
+    assert ours["groups"]["metadata"]["attrs"]["steps"]["value"] == T
+    assert_same_tree(ours, ref["tree"], extra_attrs=("env", "steps"))
+    data = H5.datasets(f)
+    assert np.array_equal(data["action"][:T], r["h5/action"][:T]) and not data["action"][T:].any()
+    for name in ("observations/qpos", "observations/qvel"):
+        # (q_vel is the velocity / MAX_Q_VEL observation: the IK-limited velocity bar 400 x 1e-6 rad / pi, q_pos 1e-6 / range)
+        assert data[name].dtype == np.float32 and np.abs(data[name][:T] - r["h5/" + name][:T]).max() < (2e-4 if name.endswith("qvel") else 2e-6), name
+    for cam in env.cameras:
+        img = data["observations/images/" + cam.name]
+        assert img.shape == (64, cam.h, cam.w, 3) and img.dtype == np.uint8 and img[:T].any()
+        if "h5/observations/images/" + cam.name in r.files:          # the small gripper frames: the surrogate scene, one grey level
+            d = np.abs(img[:T].astype(int) - r["h5/observations/images/" + cam.name][:T].astype(int))
+            assert (d > 1).mean() < 2e-3

@@ -234,6 +234,38 @@ def test_shell_info_and_spaces_vs_reference():
         assert gym_shell.KManipEnv.metadata == e["metadata"]
 
 
+@pytest.mark.parametrize("env_id", ["KManipSoloArm", "KManipDualArm", "KManipTorso"])
+def test_oracle_scripted_policy_vs_reference_heuristic(env_id):
+    """ko_scripted_eer_pos against the heuristic of examples/2_synthetic_data.py:28-41 as evaluated on the reference env object
+    (ref_scripted_<id>.npz: `raw_action`, float64), at the 64 states of the reference's own scripted episode; then every step
+    of that episode as a one-step problem through ko_step (the reference handed before_step a float64 eer_pos: the flat row's
+    float32 rounding of it moves the IK goal by < 1e-9 m)."""
+    from oracle.oracle import Oracle
+    r = _ref("ref_scripted_%s.npz" % env_id)
+    cm = compile_model(env_id, auto_reset=False)
+    T = len(r["action"])
+    o = Oracle(cm, T)
+    for t in range(T):
+        assert np.abs(o.scripted_eer_pos(r["pre_qpos"][t]) - r["raw_action"][t]).max() < 1e-12
+    sl = cm.act_slices["eer_pos"]
+    assert np.array_equal(r["action"][:, sl], r["raw_action"].astype(np.float32))
+    o.set_state(r["pre_qpos"], r["pre_qvel"], r["pre_ctrl"], r["pre_warm"], np.arange(T, dtype=np.int32))
+    obs, rew, done = o.step(r["action"])
+    q, v = o.get_state()[:2]
+    # IK-limited bars: two TRF runs on inputs that differ in the 8th digit may stop an iteration apart (ftol = xtol = gtol = 1e-8),
+    # up to 1e-6 rad on the teleported joints; a position offset dq in a kp = 1000, I = 0.01 servo joint becomes a velocity
+    # dq * sqrt(kp / I) = 316 dq within the control step -- the qvel bar of a sample is tied to ITS qpos difference
+    dq, dv = np.abs(q - r["post_qpos"]).max(1), np.abs(v - r["post_qvel"]).max(1)
+    assert dq.max() < 1e-6 and (dv <= 1e-7 + 400 * dq).all(), (dq.max(), dv.max())
+    assert np.abs(obs[:, obs_columns(cm)] - r["obs"]).max() < 1e-5 and np.abs(rew - r["reward"]).max() < 1e-6
+    assert np.array_equal(r["info_step"], np.arange(1, T + 1)) and not r["terminated"].any() and not r["is_success"].any()
+    # the rigged success state (env_base.py:250): the oracle's reward crosses the reference's threshold where the reference's did
+    o1 = Oracle(cm, 1)
+    o1.set_state(r["success_qpos"][None], r["success_qvel"][None], r["success_ctrl"][None], r["success_warm"][None], np.zeros(1, dtype=np.int32))
+    _, rew1, _ = o1.step(r["success_action"][None])
+    assert rew1[0] > M.REWARD_SUCCESS_THRESHOLD == float(r["success_threshold"]) and abs(rew1[0] - float(r["success_reward"])) < 1e-4 * rew1[0]
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/gym_kmanip"), reason="build container only: needs the reference checkout")
 def test_committed_fixtures_are_what_the_reference_produces_today(tmp_path, monkeypatch):
     """Staleness guard (build container): regenerate a slice with the reference's Python and compare with the committed files."""
@@ -249,3 +281,11 @@ def test_committed_fixtures_are_what_the_reference_produces_today(tmp_path, monk
     old = _ref("ref_run_KManipSoloArmQPos.npz")
     for k in ("action", "ctrl_set", "post_qpos", "obs", "reward"):
         assert np.array_equal(fresh[k], old[k][:6]), k
+    # round 5: the reference's own logger tree and its scripted episode, regenerated (3 steps) against the committed 64-step run
+    tree, fresh = G.gen_h5_scripted("KManipSoloArm", nstep=3)
+    old_tree = json.load(open(os.path.join(GOLDEN, "ref_h5_tree_KManipSoloArm.json")))
+    assert tree["tree"] == old_tree["tree"] and tree["file"] == old_tree["file"]
+    old = _ref("ref_scripted_KManipSoloArm.npz")
+    for k in ("raw_action", "action", "post_qpos", "reward", "h5/action"):
+        assert np.array_equal(fresh[k][:3], old[k][:3]), k
+    assert np.array_equal(fresh["success_reward"], old["success_reward"])

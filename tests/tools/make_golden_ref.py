@@ -14,10 +14,20 @@ Files (all under tests/golden/):
   ref_ik_<family>.npz      direct calls of ik_mujoco.ik / ik_res / ik_jac on seeded cases (the cases of make_golden.gen_ik:
                            random poses, a start on a bound, an infeasible start -> the "IK failed" branch)
   ref_obs_<family>.npz     get_observation / get_reward on seeded states that exercise every clip
+  ref_h5_tree_<id>.json    (round 5) the HDF5 tree the reference's OWN logger builds -- log_h5py.new / cam / step / end
+                           (log_h5py.py:13-61) running unmodified from inside KManipEnv(log_h5py=True).reset / step / close
+                           (env_base.py:231-263) against the recording h5py stand-in tests/tools/h5_recorder.py: groups, attrs
+                           (dtype, shape, value), datasets (shape, dtype, chunks), file name, flush count
+  ref_scripted_<id>.npz    (round 5) the same episode: every step's action is action_space.sample() with eer_pos overwritten
+                           by the move-toward-the-cube heuristic of examples/2_synthetic_data.py:28-41, evaluated on the
+                           reference env object; per step the state before, the sampled flat action, the heuristic's float64
+                           vector, what env.step returned (obs, reward, info) and the logger's datasets (`h5/...`); plus one
+                           rigged state whose step returns reward > REWARD_SUCCESS_THRESHOLD (info["is_success"], env_base.py:250)
   ref_touch_<family>.npz   get_reward with finger geoms that carry the names env_sim.py:171-174 looks for (the reference's
                            meshes are unnamed, so its own touch / lift terms never fire: SURVEY A.5 #5) on states with a finger
                            on the cube, the cube on / off the table
 """
+import collections
 import contextlib
 import io
 import json
@@ -309,6 +319,88 @@ def gen_touch(env_id, seed=5):
     return out
 
 
+def gen_h5_scripted(env_id, nstep=64, seed=7):
+    """One episode of the reference's KManipEnv(log_h5py=True) driven by the heuristic loop of examples/2_synthetic_data.py:28-41."""
+    import tempfile
+    import h5_recorder as H
+    k = refrun.install()[0]
+    cm = compile_model(env_id)
+    scratch = tempfile.mkdtemp(prefix="kmanip_ref_h5_")
+    H.FILES.clear()
+    with quiet():
+        env = refrun.make_env(env_id, log_dir_root=scratch, log_h5py=True, log_prefix="sim_synth")
+    ph = env.env.physics
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    rec = {n: [] for n in ("pre_qpos", "pre_qvel", "pre_ctrl", "pre_warm", "action_sampled", "raw_action", "action", "post_qpos",
+                           "post_qvel", "obs", "reward", "is_success", "info_step", "sim_time", "terminated")}
+    with quiet():
+        obs, info = env.reset(seed=seed)
+    rec_reset = dict(reset_qpos=ph.data.qpos.copy(), reset_qvel=ph.data.qvel.copy(), reset_ctrl=ph.data.ctrl.copy(),
+                     reset_warm=ph._warm.copy(), reset_obs=flat_obs(cm, obs))
+    for t in range(nstep):
+        action = env.action_space.sample(rng)
+        rec["action_sampled"].append(flat_action(cm, action))
+        # examples/2_synthetic_data.py:32-37, on the reference env object (env.unwrapped is the env itself without gym.make's wrappers)
+        cube_pos = env.env.physics.data.qpos[-7:-4].copy()
+        eer_pos = env.env.physics.data.site("eer_site_pos").xpos.copy()
+        raw_action = cube_pos - eer_pos
+        raw_action /= np.linalg.norm(raw_action)
+        action["eer_pos"] = raw_action
+        rec["raw_action"].append(raw_action.copy()); rec["action"].append(flat_action(cm, action))
+        rec["pre_qpos"].append(ph.data.qpos.copy()); rec["pre_qvel"].append(ph.data.qvel.copy())
+        rec["pre_ctrl"].append(ph.data.ctrl.copy()); rec["pre_warm"].append(ph._warm.copy())
+        with quiet():
+            obs, reward, terminated, truncated, info = env.step(action)
+        rec["post_qpos"].append(ph.data.qpos.copy()); rec["post_qvel"].append(ph.data.qvel.copy())
+        rec["obs"].append(flat_obs(cm, obs)); rec["reward"].append(reward); rec["is_success"].append(bool(info["is_success"]))
+        rec["info_step"].append(info["step"]); rec["sim_time"].append(info["sim_time"]); rec["terminated"].append(bool(terminated))
+    with quiet():
+        env.close()
+    (path, f), = H.FILES.items()
+    assert f.closed and path.startswith(scratch)
+    tree = dict(file=os.path.basename(path), log_dir_prefix=os.path.basename(os.path.dirname(path)).split(".")[0],
+                rdcc_nbytes=f.rdcc_nbytes, flushes=f.flushes, steps=nstep, tree=H.tree(f, skip_attr_values=("cpu_time",)))
+    with open(os.path.join(OUT, "ref_h5_tree_%s.json" % env_id), "w") as fp:
+        json.dump(tree, fp, indent=1)
+    out = {n: np.array(v) for n, v in rec.items()}
+    out.update(rec_reset)
+    for dpath, arr in H.datasets(f).items():
+        if "images" not in dpath or arr.shape[2] <= 64:          # the 480 x 640 frames by shape only (the tree has it)
+            out["h5/" + dpath] = arr
+    # ---- info["is_success"] = reward > REWARD_SUCCESS_THRESHOLD (env_base.py:250): the grip-distance term is 0.01 / (dist + 1e-6),
+    # so the cube's centre has to sit within 5 mm of the gripper site.  Rigged state: the cube AT the right gripper site, one step.
+    if True:
+        with quiet():
+            env2 = refrun.make_env(env_id)
+            env2.reset(seed=seed)
+        ph2 = env2.env.physics
+        site = ph2.data.site("eer_site_pos").xpos.copy()
+        best = None
+        for dz in (0.0, 0.002, 0.004, -0.002, 0.006, 0.008, 0.01):     # the cube falls ~2 mm per control step when nothing holds it
+            ph2.data.qpos[cm.nlink:cm.nlink + 3] = site + np.array([0.0, 0.0, dz])
+            ph2.data.qvel[:] = 0
+            ph2.forward()
+            pre = (ph2.data.qpos.copy(), ph2.data.qvel.copy(), ph2.data.ctrl.copy(), ph2._warm.copy())
+            a0 = collections.OrderedDict((n, np.zeros(sp.shape, dtype=np.float32)) for n, sp in env2.action_space.spaces.items())
+            with quiet():
+                o2, r2, _, _, i2 = env2.step(a0)
+            if r2 > k.REWARD_SUCCESS_THRESHOLD:
+                best = (pre, flat_action(cm, a0), r2, bool(i2["is_success"]), flat_obs(cm, o2))
+                break
+            with quiet():
+                env2.reset(seed=seed)
+        assert best is not None, "no rigged state reached reward > REWARD_SUCCESS_THRESHOLD"
+        (q, v, c, w), a, r, ok, o = best
+        assert ok is True
+        out.update(success_qpos=q, success_qvel=v, success_ctrl=c, success_warm=w, success_action=a, success_reward=r,
+                   success_is_success=ok, success_obs=o, success_threshold=k.REWARD_SUCCESS_THRESHOLD)
+    np.savez_compressed(os.path.join(OUT, "ref_scripted_%s.npz" % env_id), **out)
+    import shutil
+    shutil.rmtree(scratch, ignore_errors=True)
+    return tree, out
+
+
 PLANS = {"KManipSoloArm": [64, 16], "KManipSoloArmQPos": [40], "KManipSoloArmVision": [3],
          "KManipDualArm": [64, 8], "KManipDualArmQPos": [40], "KManipDualArmVision": [2],
          "KManipTorso": [64, 8], "KManipTorsoVision": [2]}
@@ -321,6 +413,10 @@ if __name__ == "__main__":
         r = gen_run(env_id, plan, seed=100 + i)
         print("ref_run_%s: %d steps, mean nfev %s, contacts in %d steps" % (
             env_id, len(r["action"]), r["ik_nfev"].mean(0), int((r["contact_mask"] != 0).sum())))
+    for env_id, nstep in (("KManipSoloArm", 64), ("KManipDualArm", 64), ("KManipTorso", 64), ("KManipSoloArmVision", 3)):
+        t, r = gen_h5_scripted(env_id, nstep)
+        print("ref_h5_tree_%s / ref_scripted_%s: %s, %d flushes, rewards %.3f .. %.3f, rigged success reward %.3f" % (
+            env_id, env_id, t["file"], t["flushes"], r["reward"].min(), r["reward"].max(), r["success_reward"]))
     for env_id in FAMILY:
         r = gen_ik(env_id)
         print("ref_ik_%s: nfev %s status %s" % (FAMILY[env_id], r["nfev"][:12], sorted(set(r["status"].tolist()))))

@@ -21,6 +21,11 @@ What does NOT come from the reference (it lives in the absent third-party packag
     dm_control rl.control.Environment / suite.base.Task (reset/step call order), dm_env.TimeStep/StepType -> below, restated
         from dm_control's published source
     gymnasium.Env / spaces.Box / spaces.Dict / register -> below (attribute holders)
+    h5py (File / attrs / create_group / create_dataset / row writes; round 5) -> tests/tools/h5_recorder.py, an in-memory
+        recorder: the reference's log_h5py.new / cam / step / end (log_h5py.py:13-61) then run unmodified from inside
+        KManipEnv.reset / step / close (env_base.py:231-263) and what they built is read back as a tree.  The reference puts its
+        log directory under its own package (DATA_DIR, __init__.py:12); make_env(log_dir_root=...) points that module attribute
+        at a scratch directory first -- nothing is written under /root/reference
 So a fixture made with this module pins everything the reference itself wrote (decode, casts, IK call, clips, obs/reward
 packing, reset, tuple/ info plumbing, the constants and masks of the eight ids) to the reference; MuJoCo's mj_step and
 dm_control's call order stay pinned to the build's reading of their documentation.
@@ -41,6 +46,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.abspath(os.path.join(_HERE, "..", ".."))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+import h5_recorder  # noqa: E402  (the in-memory `h5py` stand-in: log_h5py.py's calls are recorded as a tree)
 
 REGISTRY = collections.OrderedDict()     # env id -> dict(entry_point, max_episode_steps, nondeterministic, kwargs)
 IK_LOG = []                              # one (nfev, status) or (0, -2) ["IK failed"] per ik() call, appended by the observer
@@ -412,6 +420,7 @@ def install():
     control = _module("dm_control.rl.control", Environment=Environment)
     rl = _module("dm_control.rl", control=control)
     _module("dm_control", mujoco=mj, suite=suite, rl=rl)
+    _module("h5py", File=h5_recorder.File, Group=h5_recorder.Group, Dataset=h5_recorder.Dataset)
     sys.path.insert(0, REFERENCE_ROOT)
     import gym_kmanip
     from gym_kmanip import env_base, env_sim, ik_mujoco
@@ -432,9 +441,13 @@ def install():
     return gym_kmanip, env_base, env_sim, ik_mujoco
 
 
-def make_env(env_id, **overrides):
-    """gymnasium.make(env_id) minus the wrappers: the reference's KManipEnv built from its own registered kwargs."""
-    _, env_base, _, _ = install()
+def make_env(env_id, log_dir_root=None, **overrides):
+    """gymnasium.make(env_id) minus the wrappers: the reference's KManipEnv built from its own registered kwargs.
+    log_dir_root: where `log_h5py=True` may create its log directory (replaces the package-relative DATA_DIR)."""
+    k, env_base, _, _ = install()
+    if overrides.get("log_h5py") or overrides.get("log_rerun"):
+        assert log_dir_root is not None and not os.path.abspath(log_dir_root).startswith(REFERENCE_ROOT)
+        k.DATA_DIR = log_dir_root
     spec = REGISTRY[env_id]
     assert spec["entry_point"] == "gym_kmanip.env_base:KManipEnv"
     kw = dict(spec["kwargs"])
