@@ -50,6 +50,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=0, help="also render a DxD gripper-cam depth image per env each step (BASELINE config 5)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="N = 1 only: run as a one-rank RCCL job (backend nccl, world_size 1) with the per-step (reward, done) "
+                         "all-gather forced through all_gather_into_tensor(async_op=True) -- executes the device-collective path "
+                         "of the N > 1 job on a one-GPU box and prices it against the plain N = 1 line")
     ap.add_argument("--rccl-one-channel", action="store_true",
                     help="N > 1 only: NCCL_MIN/MAX_NCHANNELS=1, NCCL_NTHREADS=64 for the per-step all-gather (A/B switch; default: RCCL's own settings)")
     ap.add_argument("--no-stagger", action="store_true", help="keep all envs phase-locked (episode phase = step index for every env)")
@@ -468,9 +472,12 @@ def run_rank(args):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.rccl_world1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:      # --rccl-world1: a one-rank RCCL job on this GPU, so that the device-collective path executes
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL runs with its own defaults.  --rccl-one-channel (opt-in, never measured on two devices: DESIGN.md section 7) asks
         # for one channel of one wave for the 64 KB all-gather: k_step fills every SIMD with exactly one wave, so a collective
         # kernel that takes whole compute units pushes some of k_step's workgroups behind it; one wave can sit beside it.
@@ -500,7 +507,7 @@ def run_rank(args):
             return rc
         if not args.no_gather:
             from gym_kmanip_amd.dist import RewardDoneGather
-            gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist)
+            gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist, force_collective=args.rccl_world1)
 
     # BASELINE config 5: the gripper-cam depth render is bound to the step (kmanip_bind_step_depth): every kmanip_step call
     # ends by rendering the state it produced, on the same stream
@@ -594,7 +601,7 @@ def run_rank(args):
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
                        "collective": "async all_gather of (reward, done) per step" if gather is not None else "none",
-                       "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None, "library": version},
+                       "rccl_ranks_seen": ranks_seen, "backend": backend if dist is not None else None, "library": version},
             "roofline": {"bound": "hbm", "bound_note": "the contract's two choices are hbm | mfma; this kernel is bound by FP64 VALU issue and dependent latency (see valu), its HBM fraction is small by construction",
                          "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)" + (" + k_render (in-step depth image)" if args.depth else (" + k_render_rgb (camera observations)" if rgb_bufs else "")), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

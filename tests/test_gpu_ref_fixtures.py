@@ -161,9 +161,9 @@ def test_hip_scripted_action_vs_reference_heuristic(env_id):
     dev.step_flat(torch.from_numpy(r["action"]).cuda())
     q, v = dev.get_state()[:2]
     # IK-limited bars (test_ref_fixtures.test_oracle_scripted_policy_vs_reference_heuristic): the reference's before_step saw the
-    # float64 heuristic vector, the flat row holds its float32 rounding; qvel of a sample within 400 x its qpos difference
+    # float64 heuristic vector, the flat row holds its float32 rounding; qvel bar = the 1e-6 rad IK bar x 400 / s
     dq, dv = np.abs(q - r["post_qpos"]).max(1), np.abs(v - r["post_qvel"]).max(1)
-    assert dq.max() < 1e-6 and (dv <= 1e-7 + 400 * dq).all(), (dq.max(), dv.max())
+    assert dq.max() < 1e-6 and dv.max() < 4e-4 and np.median(dv) < 2e-6, (dq.max(), dv.max(), np.median(dv))
     assert np.abs(dev.obs.cpu().numpy()[:, obs_columns(cm)] - r["obs"]).max() < 1e-5
     assert np.abs(dev.reward.cpu().numpy() - r["reward"]).max() < 1e-6
     dev.k_close()

@@ -66,7 +66,45 @@ def test_two_ranks_match_one_rank_bitwise(tmp_path, env_id, total, steps):
     ref.k_close()
 
 
-def test_bench_self_launch_two_ranks(tmp_path):
+def test_rccl_device_collective_world1(tmp_path):
+    """RCCL executes: ONE rank, backend "nccl", on cuda:0, under the HSA_ENABLE_IPC_MODE_LEGACY=0 the ranks of an N > 1 job get.
+    RewardDoneGather(force_collective=True) keeps the world == 1 short cut out of the way, so every step goes through
+    before_step() (Work.wait() of the collective two steps back + record selection), the step launch that writes the packed
+    record, and post() = all_gather_into_tensor(async_op=True) on the DEVICE buffers -- the code path of the multi-GPU job, which
+    a gloo rehearsal (host staging, synchronous) never touches.  What the rank gathered must be what a plain run computes."""
+    import torch
+    from gym_kmanip_amd import env_hip
+    env_id, total, steps = "KManipSoloArm", 512, 70
+    _run_ranks(str(tmp_path), 1, ["--env", env_id, "--total", str(total), "--steps", str(steps), "--backend", "nccl", "--force-collective"])
+    r = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    assert str(r["backend"]) == "nccl" and str(r["ipc_legacy"]) == "0"
+    ref = env_hip.make(env_id, num_envs=total, seed=9, env_id_offset=0)
+    ref.k_reset()
+    gen = torch.Generator(); gen.manual_seed(1234)
+    for k in range(steps):
+        ref.step_flat((torch.rand((total, ref.cm.act_dim), generator=gen) * 2 - 1).cuda())
+        assert np.array_equal(r["rew"][k], ref.reward.cpu().numpy()), k
+        assert np.array_equal(r["done"][k], ref.done.cpu().numpy()), k
+    assert r["done"][63].all() and not r["done"][62].any()
+    assert np.array_equal(r["obs"], ref.obs.cpu().numpy()) and np.array_equal(r["qpos"], ref.get_state()[0])
+    ref.k_close()
+
+
+def test_bench_rccl_world1_line():
+    """`python bench.py --rccl-world1`: the N = 1 bench as a one-rank RCCL job with the per-step all-gather forced through the
+    device collective (init_process_group("nccl"), the rank-count all-reduce, bind + before_step / post around every step)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-world1", "--steps", "16", "--warmup", "4",
+                        "--envs-per-gpu", "4096", "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks_seen"] == 1
+    assert d["config"]["collective"].startswith("async all_gather") and d["value"] > 0
+
+
+@pytest.mark.parametrize("shape", ["solo_256", "config4_torso_8192"])
+def test_bench_self_launch_two_ranks(tmp_path, shape):
     """`python bench.py --gpus 2` (no torchrun) end to end: the parent spawns both ranks, rank 0 prints the one JSON line.
     One-GPU boxes rehearse it with KMANIP_BENCH_ONE_GPU=1 / KMANIP_BENCH_BACKEND=gloo (both ranks on cuda:0)."""
     import json
@@ -74,12 +112,14 @@ def test_bench_self_launch_two_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     if torch.cuda.device_count() < 2:
         env.update(KMANIP_BENCH_ONE_GPU="1", KMANIP_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
-                        "--envs-per-gpu", "256", "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    # config4_torso_8192: BASELINE config 4's per-GPU shape (KManipTorso, 8192 envs per rank; cost-sorted wave slots on)
+    cfg = ["--envs-per-gpu", "256"] if shape == "solo_256" else ["--env", "KManipTorso", "--envs-per-gpu", "8192"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2"] + cfg
+                       + ["--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["envs_per_gpu"] == 256 and d["value"] > 0 and d["steps"] == 8
+    assert d["config"]["envs_per_gpu"] == (256 if shape == "solo_256" else 8192) and d["value"] > 0 and d["steps"] == 8
     assert "collective" in d["config"] and d["config"]["collective"].startswith("async all_gather")

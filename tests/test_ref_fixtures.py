@@ -253,10 +253,11 @@ def test_oracle_scripted_policy_vs_reference_heuristic(env_id):
     obs, rew, done = o.step(r["action"])
     q, v = o.get_state()[:2]
     # IK-limited bars: two TRF runs on inputs that differ in the 8th digit may stop an iteration apart (ftol = xtol = gtol = 1e-8),
-    # up to 1e-6 rad on the teleported joints; a position offset dq in a kp = 1000, I = 0.01 servo joint becomes a velocity
-    # dq * sqrt(kp / I) = 316 dq within the control step -- the qvel bar of a sample is tied to ITS qpos difference
+    # up to 1e-6 rad on the teleported joints (the bar of every IK comparison in this suite); a position offset d in a kp = 1000,
+    # I = 0.01 servo joint becomes a velocity of up to d * sqrt(kp / I) = 316 d within the control step (explicit Euler at
+    # omega dt = 0.63 overshoots a little: 400 d) -- qvel bar = 1e-6 rad x 400 / s; the median sample sits two orders below
     dq, dv = np.abs(q - r["post_qpos"]).max(1), np.abs(v - r["post_qvel"]).max(1)
-    assert dq.max() < 1e-6 and (dv <= 1e-7 + 400 * dq).all(), (dq.max(), dv.max())
+    assert dq.max() < 1e-6 and dv.max() < 4e-4 and np.median(dv) < 2e-6, (dq.max(), dv.max(), np.median(dv))
     assert np.abs(obs[:, obs_columns(cm)] - r["obs"]).max() < 1e-5 and np.abs(rew - r["reward"]).max() < 1e-6
     assert np.array_equal(r["info_step"], np.arange(1, T + 1)) and not r["terminated"].any() and not r["is_success"].any()
     # the rigged success state (env_base.py:250): the oracle's reward crosses the reference's threshold where the reference's did

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--seed", type=int, default=9)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="issue the real all_gather_into_tensor(async_op=True) even at world_size 1 (dist.RewardDoneGather)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -35,7 +37,9 @@ def main():
     n = hi - lo
     env = env_hip.make(a.env, num_envs=n, device=dev, seed=a.seed, env_id_offset=lo)
     env.k_reset()
-    g = RewardDoneGather(n, world, torch.device("cuda", dev), dist)
+    g = RewardDoneGather(n, world, torch.device("cuda", dev), dist, force_collective=a.force_collective)
+    if a.force_collective:
+        assert g.force_collective and not g.host_stage
     g.bind(env)                                                         # the step writes the packed record itself (as bench.py runs it)
     gen = torch.Generator(); gen.manual_seed(1234)                      # CPU generator: the same stream on every rank
     rew, done = [], []
@@ -54,9 +58,12 @@ def main():
             take(prev)                                                  # flight while step k-1's result is consumed
         prev = b
     take(prev)
+    if a.force_collective:             # evidence for the test: every step's exchange was a real asynchronous collective
+        assert g.pending == [None, None] and g.k == a.steps
     st = env.get_state()
     np.savez(os.path.join(a.out, "rank%d.npz" % rank), rew=np.array(rew), done=np.array(done), obs=env.obs.cpu().numpy(),
-             qpos=st[0], qvel=st[1], ctrl=st[2], lo=lo, hi=hi)
+             qpos=st[0], qvel=st[1], ctrl=st[2], lo=lo, hi=hi, backend=dist.get_backend(),
+             ipc_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", ""))
     env.k_close()
     dist.barrier()
     dist.destroy_process_group()
