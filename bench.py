@@ -207,14 +207,56 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cm, n_envs, budget_s=12.0):
+def probe_mujoco():
+    """Run-time probe (SURVEY 8d plan (1)): is `mujoco` importable on THIS box, now?"""
+    import importlib.util
+    present = importlib.util.find_spec("mujoco") is not None
+    return {"present": present,
+            "note": "present (probed now)" if present else
+                    "absent (probed now: importlib.util.find_spec('mujoco') is None on this box) -- no MuJoCo-timed baseline; "
+                    "tools/mjcf_export.py writes the surrogate as mesh-free MJCF for a box that has it"}
+
+
+def mujoco_baseline(cm, n_envs, budget_s=10.0):
+    """Only when `mujoco` is importable (never on this pool): time MuJoCo's own mj_step on the build's mesh-free MJCF
+    (tools/mjcf_export.py) with build-owned harness code -- 10 sub-steps per control step, ctrl = a random target inside
+    ctrlrange every control step, one model, envs run back to back on one core.  It times the ENGINE under the path (rows
+    a-2 / a-9), not the reference's Python around it."""
+    import tempfile
+    import numpy as np
+    import mujoco
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import mjcf_export
+    xml = mjcf_export.export(cm.asset)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, cm.asset["name"] + ".xml")
+        open(path, "w").write(xml)
+        m = mujoco.MjModel.from_xml_path(path)
+    d = mujoco.MjData(m)
+    rng = np.random.default_rng(0)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    t0 = time.perf_counter(); steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        d.ctrl[:] = rng.uniform(lo, hi)
+        for _ in range(cm.desc.n_sub_steps):
+            mujoco.mj_step(m, d)
+        steps += 1
+        if steps % 64 == 0:
+            mujoco.mj_resetData(m, d)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env steps/s", "cores": 1, "kind": "mujoco-engine",
+            "sample": "%d control steps of one env (10 x mj_step each), mujoco %s, the exported mesh-free surrogate MJCF" % (steps, mujoco.__version__)}
+
+
+def cpu_baseline(cm, n_envs, budget_s=15.0):
     """The oracle (a C port of the reference path; the reference itself cannot run here: mujoco / dm_control / gymnasium
-    are absent from this image and from the GPU box, profiles/r02_probe_imports.txt) timed on this box's host cores
-    with OpenMP over envs, on a bounded sample of the same workload."""
+    are absent from this image and from the GPU box -- probed at run time below) timed on this box's host cores with OpenMP over
+    envs, on a bounded sample of the SAME workload: all n_envs envs of the bench line, the device's Philox action stream, as many
+    control steps as fit the time budget (the first ten are untimed so that the cubes have landed and contacts are in the sample)."""
     import numpy as np
     from oracle.oracle import Oracle
     cores = usable_cores()
-    n = min(n_envs, 1024)
+    n = n_envs
     o = Oracle(cm, n, seed=0)
     o.reset()
     for k in range(10):                   # untimed: let the cubes land so contacts are in the sample
@@ -223,12 +265,19 @@ def cpu_baseline(cm, n_envs, budget_s=12.0):
     while True:
         o.step(o.sample_action(), nthreads=cores); steps += 1       # the device's action stream (same Philox keys), drawn per step
         dt = time.perf_counter() - t0
-        if dt > budget_s or steps >= 54:
+        if dt > budget_s or steps >= 4 * EPISODE:
             break
-    return {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d control steps (episode steps 10..%d, contacts active; the device's Philox action stream), OpenMP over envs, %d threads"
-                      % (n, steps, 10 + steps, cores),
-            "mujoco": "absent on the GPU box (import probe: profiles/r02_probe_imports.txt), so no MuJoCo-timed baseline"}
+    mj = probe_mujoco()
+    out = {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+           "sample": "%d envs x %d control steps (episode steps 10..%d, contacts active, auto-reset at 64; the device's Philox action stream), OpenMP over envs, %d threads"
+                     % (n, steps, 10 + steps, cores),
+           "mujoco": mj["note"]}
+    if mj["present"]:
+        try:
+            out["mujoco_engine"] = mujoco_baseline(cm, n)
+        except Exception as e:  # noqa: BLE001
+            out["mujoco_engine"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def check_ranks_seen(ranks_seen, world, rank):

@@ -137,8 +137,12 @@ def link_mass(joint_name):
     raise ValueError(joint_name)
 
 
-def build(env_xml, name):
-    root = load_expanded(os.path.join(REF_ASSETS, env_xml))
+def build(env_xml, name, assets_dir=None):
+    """env_xml under assets_dir (default: the reference's assets).  The reference's files carry meshes only, so inertials and
+    colliders come from the surrogate rules below; a PRIMITIVE-ONLY file -- what tools/mjcf_export.py writes from the JSON this
+    function produced -- states them itself (<inertial> per link, sphere / capsule geoms with user="<order>", a box table, an
+    <option>), and then they are READ instead: export -> build is the identity on the model (tests/test_mjcf_export.py)."""
+    root = load_expanded(os.path.join(assets_dir or REF_ASSETS, env_xml))
     wb_list = root.findall("worldbody")
     links = []
     sites = {}
@@ -146,6 +150,7 @@ def build(env_xml, name):
     bodies_by_name = {}
     cube = None
     table = None
+    stated_spheres, stated_segs = {}, {}
 
     def walk(el, parent_link, rel_pos, rel_quat):
         """el: <body>; (rel_pos, rel_quat): pose of el's PARENT frame in parent_link's frame."""
@@ -173,6 +178,11 @@ def build(env_xml, name):
             return
         if bname == "table":
             table = {"pos": p.tolist()}
+            g = el.find("geom")
+            if g is not None and g.get("type") == "box":          # primitive-only file: the top face is the table rectangle
+                hs, gp = fvec(g.get("size"), 3), fvec(g.get("pos", "0 0 0"), 3)
+                table["rect"] = [p[0] + gp[0] - hs[0], p[0] + gp[0] + hs[0], p[1] + gp[1] - hs[1], p[1] + gp[1] + hs[1]]
+                table["plane_z"] = p[2] + gp[2] + hs[2]
             return
         if len(joints) == 0:
             # fixed body: fold into parent link
@@ -199,6 +209,21 @@ def build(env_xml, name):
             if parent_link >= 0:
                 links[parent_link]["_attach"].append(p.tolist())
             me_link, me_p, me_q = idx, np.zeros(3), np.array([1.0, 0, 0, 0])
+            inert = el.find("inertial")
+            if inert is not None:                                  # primitive-only file: stated, not derived
+                links[idx]["inertial"] = {"mass": float(inert.get("mass")), "com": fvec(inert.get("pos", "0 0 0"), 3).tolist(),
+                                          "diaginertia": fvec(inert.get("diaginertia"), 3).tolist()}
+            for g in el.findall("geom"):
+                if g.get("type") == "sphere" and g.get("user") is not None:
+                    nm = g.get("name")
+                    rec = {"name": nm[:-5] if nm.endswith("__seg") else nm, "link": idx, "pos": fvec(g.get("pos", "0 0 0"), 3).tolist(),
+                           "radius": float(g.get("size")), "visible": int(float(g.get("rgba", "0 0 0 1").split()[3]) > 0)}
+                    if nm.endswith("__seg"):
+                        rec["seg"] = [0.0, 0.0, 0.0]
+                    stated_spheres[int(float(g.get("user")))] = rec
+                elif g.get("type") == "capsule" and g.get("user") is not None:
+                    ft = fvec(g.get("fromto"), 6)
+                    stated_segs[int(float(g.get("user")))] = (ft[3:] - ft[:3]).tolist()
         bodies_by_name[bname] = (me_link, me_p.copy(), me_q.copy())
         for s in el.findall("site"):
             sp, sq = body_frame(s)
@@ -253,6 +278,8 @@ def build(env_xml, name):
     # ---- surrogate inertials
     for l in links:
         att = l.pop("_attach")
+        if "inertial" in l:
+            continue
         far = np.zeros(3)
         for a_ in att:
             if np.linalg.norm(a_) > np.linalg.norm(far):
@@ -270,8 +297,14 @@ def build(env_xml, name):
 
     # ---- surrogate finger colliders: one sphere per slider link, placed relative to the EE site
     spheres = []
+    if stated_spheres:                                             # primitive-only file: the colliders are stated, in `user` order
+        for k in sorted(stated_spheres):
+            rec = stated_spheres[k]
+            if k in stated_segs:
+                rec["seg"] = stated_segs[k]
+            spheres.append(rec)
     for i, l in enumerate(links):
-        if l["joint"]["type"] != "slide":
+        if stated_spheres or l["joint"]["type"] != "slide":
             continue
         par = l["parent"]
         # EE site sharing this hand: the site whose link is the slider's parent or a sibling
@@ -303,9 +336,9 @@ def build(env_xml, name):
     # table top's height and those links could only meet the table at its edge.  Collision only (visible = 0):
     # the wrist cameras sit inside / behind these spheres, where the reference's camera sees past its gripper mesh.
     for s in spheres:
-        s["visible"] = 1
+        s.setdefault("visible", 1)
     hands = []
-    for s in list(spheres):
+    for s in ([] if stated_spheres else list(spheres)):
         par = links[s["link"]]["parent"]
         if par in [h[0] for h in hands]:
             continue
@@ -343,11 +376,12 @@ def build(env_xml, name):
         "targets": targets,
         "cameras": cameras,
         "cube": cube,
-        "table": {"pos": table["pos"], "plane_z": TABLE_TOP_Z,
-                  "rect": [table["pos"][0] - 0.5 * TABLE_SIZE_XY[0], table["pos"][0] + 0.5 * TABLE_SIZE_XY[0],
-                           table["pos"][1] - 0.5 * TABLE_SIZE_XY[1], table["pos"][1] + 0.5 * TABLE_SIZE_XY[1]]},
+        "table": {"pos": table["pos"], "plane_z": table.get("plane_z", TABLE_TOP_Z),
+                  "rect": table.get("rect", [table["pos"][0] - 0.5 * TABLE_SIZE_XY[0], table["pos"][0] + 0.5 * TABLE_SIZE_XY[0],
+                                             table["pos"][1] - 0.5 * TABLE_SIZE_XY[1], table["pos"][1] + 0.5 * TABLE_SIZE_XY[1]])},
         "spheres": spheres,
-        "option": {"timestep": 0.002, "gravity": [0, 0, -9.81]},
+        "option": ({"timestep": float(root.find("option").get("timestep")), "gravity": fvec(root.find("option").get("gravity"), 3).tolist()}
+                   if root.find("option") is not None and root.find("option").get("timestep") else {"timestep": 0.002, "gravity": [0, 0, -9.81]}),
         "surrogate_note": "link inertials, finger / link spheres and the table plane are build-owned "
                           "surrogates (reference meshes absent); see tools/mjcf_extract.py",
     }
