@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.15 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.16 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -39,6 +39,10 @@ struct KHandle_ {
   int32_t* slot_env = nullptr;
   bool cost_sort = false;
   KCostWeights cost_w{18, 1, 2000, 0, 0, 100};     // work units per: IK evaluation, Newton work unit, collider near the cube; bin width
+  // heavy-first dispatch (KDeviceState::disp_*): three rotating tables, the step counter that rotates them
+  int32_t* disp_tab[3] = {nullptr, nullptr, nullptr};
+  unsigned disp_k = 0;
+  int wave_slots = 0;           // entries of st.wave_clk (one per lane group of the step launch's grid)
   std::vector<void*> allocs;
 };
 
@@ -233,7 +237,31 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   { const char* e = getenv("KMANIP_IK_UNFUSED"); h->ik_unfused = e && e[0] == '1'; }
   h->st.slot_env = nullptr;
   h->st.wave_clk = nullptr;
-  if (const char* e = getenv("KMANIP_WAVE_CLOCKS")) if (e[0] == '1') CR(dalloc((void**)&h->st.wave_clk, sizeof(unsigned long long) * N));
+  h->st.disp_in = nullptr; h->st.disp_out = nullptr; h->st.disp_zero = nullptr; h->st.disp_cap = 0; h->st.disp_heavy_epb = 1;
+  h->wave_slots = num_envs;
+  {
+    // Heavy-first dispatch: the single-arm Newton kernel at widths whose launch is about one residency round of multi-env waves
+    // (>= 2048 envs: two or four envs per wave).  KMANIP_HEAVY_DISPATCH=0 / 1 forces it off / on, KMANIP_HEAVY_EPB = heavy envs
+    // per wave (default 1), KMANIP_HEAVY_CAP = most envs dispatched as heavy (default num_envs / 16).
+    bool on = nl == 10 && desc->solver == KM_SOLVER_NEWTON && num_envs >= 2048;
+    if (const char* e = getenv("KMANIP_HEAVY_DISPATCH")) on = e[0] == '1' && nl == 10;
+    if (on) {
+      int cap = num_envs / 16 > 64 ? num_envs / 16 : 64, hepb = 1;
+      if (const char* e = getenv("KMANIP_HEAVY_CAP")) { const int v = atoi(e); if (v > 0) cap = v; }
+      if (const char* e = getenv("KMANIP_HEAVY_EPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) hepb = v; }
+      if (cap > num_envs) cap = num_envs;
+      h->st.disp_cap = cap; h->st.disp_heavy_epb = hepb;
+      std::vector<int32_t> init(KM_DISP_HDR + N, 0);
+      init[1] = num_envs;                                   // table 0: nobody heavy, the light list is the identity
+      for (int i = 0; i < num_envs; i++) init[KM_DISP_HDR + i] = i;
+      for (int t = 0; t < 3; t++) {
+        CR(dalloc((void**)&h->disp_tab[t], sizeof(int32_t) * (KM_DISP_HDR + N)));
+        if (t == 0) CR(hipMemcpy(h->disp_tab[0], init.data(), sizeof(int32_t) * (KM_DISP_HDR + N), hipMemcpyHostToDevice));
+      }
+      h->wave_slots = 4 * (cap + num_envs + 4);             // (an upper bound of 4 lane groups x the grid of any launch shape)
+    }
+  }
+  if (const char* e = getenv("KMANIP_WAVE_CLOCKS")) if (e[0] == '1') CR(dalloc((void**)&h->st.wave_clk, sizeof(unsigned long long) * h->wave_slots));
   CR(dalloc((void**)&h->slot_env, sizeof(int32_t) * N));
   CR(dalloc((void**)&h->st.work, sizeof(int32_t) * N));
   {
@@ -282,11 +310,28 @@ int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env
   KM_ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
   const size_t N = (size_t)h->num_envs;
-  if (clk) HIPCHK(h, hipMemcpy(clk, h->st.wave_clk, sizeof(unsigned long long) * N, hipMemcpyDeviceToHost));
-  if (slot_env) HIPCHK(h, hipMemcpy(slot_env, h->slot_env, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+  if (clk) HIPCHK(h, hipMemcpy(clk, h->st.wave_clk, sizeof(unsigned long long) * h->wave_slots, hipMemcpyDeviceToHost));
+  if (slot_env) {
+    if (h->disp_tab[0]) {
+      // heavy-first dispatch: rebuild the LAST launch's slot -> env map (4 slots per workgroup, -1 = empty lane group) from its table
+      std::vector<int32_t> tab(KM_DISP_HDR + N);
+      HIPCHK(h, hipMemcpy(tab.data(), h->disp_tab[(h->disp_k + 2) % 3], sizeof(int32_t) * (KM_DISP_HDR + N), hipMemcpyDeviceToHost));
+      const int epb = h->num_envs >= 4096 ? 4 : 2, hepb = h->st.disp_heavy_epb;
+      const int nh = tab[0] < h->st.disp_cap ? tab[0] : h->st.disp_cap, nhw = (nh + hepb - 1) / hepb;
+      for (int sl = 0; sl < h->wave_slots; sl++) {
+        const int b = sl / epb, grp = sl % epb;
+        int idx = -1;
+        if (b < nhw) { if (grp < hepb && b * hepb + grp < nh) idx = b * hepb + grp; }
+        else { const int i = nh + (b - nhw) * epb + grp; if (i < (int)N) idx = i; }
+        slot_env[sl] = idx >= 0 ? tab[KM_DISP_HDR + idx] : -1;
+      }
+    } else HIPCHK(h, hipMemcpy(slot_env, h->slot_env, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+  }
   if (work) HIPCHK(h, hipMemcpy(work, h->st.work, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
   return 0;
 }
+// number of entries of kmanip_dbg_wave_clocks' clk / slot_env arrays (num_envs, or more with the heavy-first dispatch)
+int kmanip_dbg_wave_slots(KHandle h) { return h ? h->wave_slots : 0; }
 
 int kmanip_observe(KHandle h, double* obs_dev, double* reward_dev, void* stream) {
   if (!h) { g_create_error = "kmanip_observe: null handle"; return -1; }
@@ -317,6 +362,11 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   if (h->cost_sort) {                        // (one small launch: counting sort of the envs by their last step's diagnostics)
     kmanip_launch_sort_envs(h->st, h->slot_env, h->cost_w, s);
     h->st.slot_env = h->slot_env;
+  }
+  h->st.disp_in = nullptr; h->st.disp_out = nullptr; h->st.disp_zero = nullptr;
+  if (h->disp_tab[0] && nchunk == 1) {       // heavy-first dispatch: this launch reads table k, fills k + 1, clears the counters of k + 2
+    h->st.disp_in = h->disp_tab[h->disp_k % 3]; h->st.disp_out = h->disp_tab[(h->disp_k + 1) % 3]; h->st.disp_zero = h->disp_tab[(h->disp_k + 2) % 3];
+    h->disp_k++;
   }
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));        // (fused path: two events per step, each costs the stream a barrier packet)
   kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);

@@ -395,6 +395,7 @@ __device__ __host__ inline float km_action_from_u32(uint32_t r) { return (float)
 
 // Device state, struct-of-arrays over envs: element (k, env) of an [n_k, num_envs] array is at
 // k * num_envs + env, so a wave reading component k for consecutive envs is fully coalesced.
+#define KM_DISP_HDR 4
 struct KDeviceState {
   double* qpos;       // [nq][N]
   double* qvel;       // [nv][N]
@@ -411,6 +412,19 @@ struct KDeviceState {
   int32_t* work;      // [N] Newton work units of the env's last control step (two-arm kernels; 0 otherwise): k_sort_envs' predictor
   unsigned long long* wave_clk;   // [N] or NULL (KMANIP_WAVE_CLOCKS=1, diagnostics): s_memtime ticks the wave that held slot s spent in k_step
   const int32_t* slot_env;   // [N] or NULL: env handled by wave slot s (k_sort_envs: predicted-cost order, heaviest first); NULL = identity
+  // Heavy-first dispatch with variable wave occupancy (round 5; single-arm Newton kernel, launches of one residency round).
+  // A dispatch table is int32[KM_DISP_HDR + N]: [0] = envs registered as HEAVY, [1] = as light, then the env list -- heavy envs
+  // from the front in arrival order, everybody else from the back.  k_step reads disp_in (NULL: classic slot mapping): workgroups
+  // [0, ceil(nh / disp_heavy_epb)) take disp_heavy_epb heavy envs each (1: a heavy env has a wave to itself), the following ones
+  // EPB light envs each; at its end every env registers itself in disp_out for the NEXT launch (heavy = a collider on or within
+  // KM_NEAR_MARGIN of the cube: the coupled Newton loop is on or about to start), and workgroup 0 clears the counters of disp_zero
+  // (the table after next).  Three tables rotate on the host; any partition of the env ids is a valid table, and an env's bits
+  // depend neither on its slot nor on its wave-mates.
+  const int32_t* disp_in;
+  int32_t* disp_out;
+  int32_t* disp_zero;
+  int disp_cap;         // at most this many envs are dispatched as heavy (the grid is sized for it); the rest of them as light
+  int disp_heavy_epb;   // heavy envs per wave (1 | 2 | 4)
   double control_dt;  // n_sub_steps * timestep
   int num_envs;
   int64_t env_id_offset;

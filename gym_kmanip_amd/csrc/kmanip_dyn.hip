@@ -2510,9 +2510,23 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   // wave slot -> env: the identity behind the XCD-aware block mapping, or -- launches of several residency rounds -- the
   // predicted-cost order of k_sort_envs with workgroup 0 first (longest-processing-time-first dispatch)
-  const int slot = (st.slot_env ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * EPB + grp;
-  if (grp >= EPB || slot >= st.num_envs) return;     // whole group exits together
-  const int env = st.slot_env ? st.slot_env[slot] : slot;
+  int slot = (st.slot_env ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * EPB + grp;
+  if (grp >= EPB) return;                              // whole group exits together
+  int env;
+  if (st.disp_in) {
+    // heavy-first dispatch (KDeviceState): the first workgroups hold the envs predicted heavy, disp_heavy_epb of them per wave
+    // (1: no wave-mates to wait for at the IK, at the solves, in the joint loop); light envs fill the following waves EPB at a time
+    const int N = st.num_envs, nh = min(st.disp_in[0], st.disp_cap), hepb = st.disp_heavy_epb;
+    const int nhw = (nh + hepb - 1) / hepb, b = blockIdx.x;
+    int idx;
+    if (b < nhw) { idx = b * hepb + grp; if (grp >= hepb || idx >= nh) return; }
+    else { idx = nh + (b - nhw) * EPB + grp; if (idx >= N) return; }
+    env = st.disp_in[KM_DISP_HDR + idx];
+    slot = b * EPB + grp;                               // (diagnostics: wave_clk is sized for the grid)
+  } else {
+    if (slot >= st.num_envs) return;
+    env = st.slot_env ? st.slot_env[slot] : slot;
+  }
   Ws<NL>& w = ws[grp];
   CReg<NL> cr;
   real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
@@ -2535,6 +2549,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   // through all of them without meeting the other waves at a launch boundary, so the batch advances at the MEAN wave
   // speed instead of the slowest wave's; the state stays in LDS between the steps of a chunk.
   const int nsteps = CHUNK ? nchunk : 1;      // (the single-step kernel keeps its register allocation: no outer loop)
+  int heavy_next = 0;                         // this env's class for the next launch's dispatch table (the state it ENDS the step in)
   for (int kc = 0; kc < nsteps; kc++) {
   if (fused) {
     if (kc > 0) {
@@ -2557,6 +2572,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     pf.ph(30);
   }
   int bad = 0;
+  heavy_next = 0;
   const int nsub = m->n_sub_steps;
   for (int s = 0; s < nsub; s++) {
     // the lane's dof index, opaque to the optimiser once per sub-step: everything derived from it (LDS addresses, per-link
@@ -2587,7 +2603,8 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
-    const int near_cube = collide_parallel<NL, G, KM_WORK_COUNTERS(NL)>(w, m, sub);
+    const int near_cube = collide_parallel<NL, G, true>(w, m, sub);
+    heavy_next = near_cube;
     if constexpr (KM_WORK_COUNTERS(NL)) { if (sub == 0 && near_cube) w.work |= 1 << 30; }     // (bit 30: a collider on or close to the cube)
     rew = env_reward<NL, G>(w, m, sub);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
@@ -2601,6 +2618,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (step_idx >= m->max_episode_steps) dn |= KM_DONE_TRUNCATED;
   if (dn && (m->auto_reset || bad)) {
     episode += 1; step_idx = 0;
+    heavy_next = 0;                               // (the respawned cube is nowhere near the home pose)
     GSYNC();
     pf.ph(31);
     reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
@@ -2616,6 +2634,14 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub == 0) {
     st.step_idx[env] = step_idx; st.episode[env] = episode;
     if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
+    if (!CHUNK && st.disp_out) {
+      // register for the next launch: heavy envs from the front of the list (at most disp_cap of them), the others from the back
+      int pos = -1;
+      if (heavy_next) { const int i = atomicAdd(&st.disp_out[0], 1); if (i < st.disp_cap) pos = i; }
+      if (pos < 0) pos = st.num_envs - 1 - atomicAdd(&st.disp_out[1], 1);
+      st.disp_out[KM_DISP_HDR + pos] = env;
+      if (blockIdx.x == 0 && grp == 0) { st.disp_zero[0] = 0; st.disp_zero[1] = 0; }
+    }
     if constexpr (KM_WORK_COUNTERS(NL)) st.work[env] = w.work;      // (the last control step's: what the next launch's slot order is predicted from)
     // (diagnostics: core-clock cycles in the low 40 bits; above them the wave's START on the constant 100 MHz clock, 24 bits)
     if (st.wave_clk) st.wave_clk[slot] = ((__builtin_amdgcn_s_memtime() - t_wave0) & 0xFFFFFFFFFFull) | ((r_wave0 & 0xFFFFFFull) << 40);
@@ -2698,7 +2724,12 @@ template <int NL, int G, int SOLVER, int EPB>
 static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, int nchunk, hipStream_t stream) {
   if (nchunk > 1) {
     if constexpr (EPB == 64 / G) hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB, true>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, act, obs, reward, done, nchunk);
-  } else hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB, false>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, act, obs, reward, done, 1);
+  } else {
+    int grid = (st.num_envs + EPB - 1) / EPB;
+    if (st.disp_in)       // room for disp_cap heavy envs at disp_heavy_epb per wave next to the light ones at EPB per wave (surplus workgroups exit at once)
+      grid = (st.disp_cap + st.disp_heavy_epb - 1) / st.disp_heavy_epb + (st.num_envs - st.disp_cap + EPB - 1) / EPB + 1;
+    hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB, false>), dim3(grid), dim3(64), 0, stream, dm, st, act, obs, reward, done, 1);
+  }
 }
 template <int NL, int G, int SOLVER, int EPB>
 static void launch_reset_e(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {

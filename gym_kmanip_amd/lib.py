@@ -25,7 +25,7 @@ EXPORTS = [
 
 
 # include/kmanip_debug.h: diagnostics, not part of the boundary (product build; the -DKM_PROFILE build adds kmanip_dbg_prof*)
-DEBUG_EXPORTS = ["kmanip_dbg_wave_clocks"]
+DEBUG_EXPORTS = ["kmanip_dbg_wave_clocks", "kmanip_dbg_wave_slots"]
 
 
 class KManipError(RuntimeError):
@@ -83,6 +83,7 @@ def load():
     lib.kmanip_destroy.argtypes = [vp]
     lib.kmanip_destroy.restype = None
     lib.kmanip_dbg_wave_clocks.argtypes = [vp, C.POINTER(C.c_ulonglong), i32p, i32p]
+    lib.kmanip_dbg_wave_slots.argtypes = [vp]
     if lib.kmanip_model_desc_size() != C.sizeof(KModelDesc):
         raise KManipError("KModelDesc layout mismatch: lib %d vs python %d"
                           % (lib.kmanip_model_desc_size(), C.sizeof(KModelDesc)))

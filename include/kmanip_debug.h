@@ -19,6 +19,9 @@ extern "C" {
  * its last step (work, HOST int32[num_envs]; zero on the single-arm kernel, which ships without the counters).  Any pointer
  * may be NULL; clk needs the environment variable (an error otherwise).  Synchronous. */
 KMANIP_API int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env, int32_t* work);
+/* Entries of the clk / slot_env arrays above: num_envs, or -- on a handle with the heavy-first dispatch (kmanip.h, launch shape),
+ * whose grid has more lane groups than envs -- 4 per workgroup of the largest grid; slot_env is -1 for a lane group that held no env. */
+KMANIP_API int kmanip_dbg_wave_slots(KHandle h);
 
 #ifdef KM_PROFILE
 /* -DKM_PROFILE build only (libkmanip_hip_prof.so, `make prof`; never shipped, never timed as the product): the in-kernel

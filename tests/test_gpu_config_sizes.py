@@ -238,6 +238,42 @@ def test_cost_sorted_wave_slots_change_nothing_but_the_order(monkeypatch):
     a.k_close(); b.k_close()
 
 
+@pytest.mark.parametrize("n,hepb", [(4096, "1"), (4096, "2"), (2048, "1")])
+def test_heavy_first_dispatch_changes_nothing_but_the_slots(monkeypatch, n, hepb):
+    """Single-arm launches of one residency round dispatch the envs predicted heavy (a collider on or near the cube at the end of
+    their last step) FIRST and with a wave to themselves (or two per wave), everybody else four (two) per wave behind them: the
+    dispatch table is a partition of the env ids rebuilt by every step, and an env's bits depend neither on its slot nor on its
+    wave-mates -- a handle with the dispatch (the default at >= 2048 envs) against one with KMANIP_HEAVY_DISPATCH=0, bit for bit,
+    across an auto-reset; the table is a permutation every step and heavy envs do occur."""
+    import ctypes as C
+    import torch
+    from gym_kmanip_amd import env_hip
+    monkeypatch.setenv("KMANIP_HEAVY_EPB", hepb)
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=5)              # heavy-first dispatch (n >= 2048)
+    monkeypatch.setenv("KMANIP_HEAVY_DISPATCH", "0")
+    b = env_hip.make("KManipSoloArm", num_envs=n, seed=5)
+    monkeypatch.delenv("KMANIP_HEAVY_DISPATCH")
+    S = a.L.kmanip_dbg_wave_slots(a.h)
+    assert S > n and b.L.kmanip_dbg_wave_slots(b.h) == n
+    a.k_reset(); b.k_reset()
+    ph = (40 + np.arange(n) % 24).astype(np.int32)
+    a.set_state(step=ph); b.set_state(step=ph)
+    slot = np.zeros(S, dtype=np.int32)
+    nheavy, epb = [], 4 if n >= 4096 else 2
+    for k in range(30):
+        act = a.sample_action().clone()
+        a.step_flat(act); b.step_flat(act)
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward) and torch.equal(a.done, b.done), k
+        assert a.L.kmanip_dbg_wave_clocks(a.h, None, slot.ctypes.data_as(C.POINTER(C.c_int32)), None) == 0
+        assert np.array_equal(np.sort(slot[slot >= 0]), np.arange(n)), k         # every env exactly once
+        per_wave = (slot[:(S // epb) * epb].reshape(-1, epb) >= 0).sum(1)
+        nheavy.append(int(((per_wave > 0) & (per_wave <= int(hepb)) & (per_wave < epb)).sum()))
+    assert all(np.array_equal(x, y) for x, y in zip(a.get_state(), b.get_state()))
+    assert np.array_equal(a.get_diag()[0], b.get_diag()[0])
+    assert max(nheavy) > 0, nheavy                                               # some envs were dispatched as heavy
+    a.k_close(); b.k_close()
+
+
 def test_interleaved_batches_are_the_envs_of_one_big_batch():
     """pipeline.InterleavedBatches: K handles on K streams, stepped round-robin without synchronising.  Batch i is, bit for bit,
     envs [i * n, (i + 1) * n) of one K * n-env handle (global-id RNG keys), and the stream-pairing probe of the constructor
