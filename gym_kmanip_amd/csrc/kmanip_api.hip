@@ -240,11 +240,14 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.disp_in = nullptr; h->st.disp_out = nullptr; h->st.disp_zero = nullptr; h->st.disp_cap = 0; h->st.disp_heavy_epb = 1;
   h->wave_slots = num_envs;
   {
-    // Heavy-first dispatch: the single-arm Newton kernel at widths whose launch is about one residency round of multi-env waves
-    // (>= 2048 envs: two or four envs per wave).  KMANIP_HEAVY_DISPATCH=0 / 1 forces it off / on, KMANIP_HEAVY_EPB = heavy envs
-    // per wave (default 1), KMANIP_HEAVY_CAP = most envs dispatched as heavy (default num_envs / 16).
-    bool on = nl == 10 && desc->solver == KM_SOLVER_NEWTON && num_envs >= 2048;
-    if (const char* e = getenv("KMANIP_HEAVY_DISPATCH")) on = e[0] == '1' && nl == 10;
+    // Heavy-first dispatch (experiment, KMANIP_HEAVY_DISPATCH=1): the single-arm Newton kernel at widths whose launch is about one
+    // residency round of multi-env waves (>= 2048 envs: two or four envs per wave).  KMANIP_HEAVY_EPB = heavy envs per wave
+    // (default 1), KMANIP_HEAVY_CAP = most envs dispatched as heavy (default num_envs / 16).
+    // OFF by default: measured on the headline config (profiles/r05_heavy_dispatch.txt) a coupled env alone in a
+    // wave ends after 1.0-1.2 M cycles against 1.4-1.5 M in a four-env wave, but the only predictor with enough recall (a collider
+    // within 1.5 cm of the cube: 99 %) flags 12 % of the envs, the extra 35 % of waves start late, and the launch gets slower.
+    bool on = false;
+    if (const char* e = getenv("KMANIP_HEAVY_DISPATCH")) on = e[0] == '1' && nl == 10 && desc->solver == KM_SOLVER_NEWTON && num_envs >= 2048;
     if (on) {
       int cap = num_envs / 16 > 64 ? num_envs / 16 : 64, hepb = 1;
       if (const char* e = getenv("KMANIP_HEAVY_CAP")) { const int v = atoi(e); if (v > 0) cap = v; }
@@ -306,7 +309,8 @@ int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stre
 // Diagnostics (include/kmanip_debug.h, not part of the boundary; KMANIP_WAVE_CLOCKS=1 at create): per wave slot, the ticks its wave spent in the last
 // k_step, the env it held, that env's work counter and IK evaluation counts -- HOST arrays of num_envs entries.  Synchronous.
 int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env, int32_t* work) {
-  if (!h || !h->st.wave_clk) return -1;
+  if (!h) return -1;
+  if (clk && !h->st.wave_clk) { h->err = "kmanip_dbg_wave_clocks: clk needs KMANIP_WAVE_CLOCKS=1 at create"; return -1; }
   KM_ENTER(h);
   HIPCHK(h, hipDeviceSynchronize());
   const size_t N = (size_t)h->num_envs;

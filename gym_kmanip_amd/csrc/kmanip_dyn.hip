@@ -104,6 +104,7 @@ struct ConRec {
   real f[6];       // edge forces
 };
 
+#define KM_WS_PAD(NL) ((NL) <= 10 ? 13 : 1)      // doubles of padding at the end of Ws (see the note on row strides in it)
 template <int NL>
 struct Ws {
   static constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ, NS = Dim<NL>::NS, NC = Dim<NL>::NC;
@@ -116,9 +117,13 @@ struct Ws {
     struct { real Ge[NC][6][4]; } p;
 #endif
   };
-  real Minv[NL][NL];       // joint-space inertia, overwritten by its inverse
+  // Row strides of everything a lane reads or writes at [its index][k] are ODD numbers of doubles (round 5): ds_write_b64 banks
+  // are (a / 4) mod 32 inside each 16-lane group and ds_read_b64 banks (a / 4) mod 64 inside each 32-lane half, so a stride of 10
+  // (or 6) doubles puts lanes i and i + 8 of an env on one bank; and sizeof(Ws<10>) is 128 mod 256 bytes, which puts the two envs
+  // of a 32-lane half on opposite halves of the bank row for every odd-stride and unit-stride access (KM_WS_PAD below).
+  real Minv[NL][NL | 1];   // joint-space inertia, overwritten by its inverse
   union {
-    struct { union { real bsc[NL][9]; real comp[NL][10]; }; real FN[NL][6]; } f;   // bias-pass scratch | composite inertias; bias wrenches
+    struct { union { real bsc[NL][9]; real comp[NL][11]; }; real FN[NL][7]; } f;   // bias-pass scratch | composite inertias (10 used); bias wrenches (6 used)
 #if KM_VAR_SOLVER == KM_SOLVER_PGS
     real stage[4][NV];                               // staging of basis rows for B = M^-1 J^T
     ConRec rec[NC];                                  // solver records (built last; Newton keeps a slot's constants in its lane)
@@ -146,7 +151,9 @@ struct Ws {
   // contact geometry per slot
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
   int slot_sph[NC];        // sphere index held by each active sphere slot (4..NC-1)
+  real pad_[KM_WS_PAD(NL)];
 };
+static_assert(KM_VAR_NL != 10 || KM_VAR_SOLVER != 1 || sizeof(Ws<KM_VAR_NL>) % 256 == 128, "Ws<10>: consecutive envs 128 bytes apart modulo the 256-byte bank row");
 
 // One-row groups (round 3): lane c < NC OWNS contact slot c for the Newton solve -- its regulariser, friction coefficients and
 // reference offsets live in that lane's registers, the slot's pyramid edges are evaluated there (all slots at once, one per
@@ -1909,7 +1916,8 @@ __device__ __forceinline__ void newton_hessian_sl(const Ws<NL>& w, int sub, cons
 template <int NL, int G, int S, bool JOINT = false>
 __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, const CReg<NL>& cr,
                                                real mdiag, real a_s, real& a, real& Mr, real cost, real& grad, int& qf, int& ql,
-                                               real (&u)[4], real (&W)[7], Prof& pf, bool two = false, real cost_b = 0) {
+                                               real (&u)[4], real (&W)[7], Prof& pf, bool two = false, real cost_b = 0, int iter0 = 0,
+                                               int* resume = nullptr, real* rcost = nullptr, int* riter = nullptr) {
   static_assert(!JOINT || (S == KM_SUB_ALL && G == 16), "the joint loop is the whole-problem loop of the one-row groups");
   constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC, NSS = Dim<NL>::NSS;
   using SS = SubSet<NL, S>;
@@ -1959,7 +1967,16 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
     enter(KM_SUB_CUBE); cost = cost_b;
     if (small()) return;
   }
-  for (int iter = 0; ; iter++) {
+  for (int iter = iter0; ; iter++) {
+    if constexpr (JOINT) {
+      // Round 5: the joint loop runs only while a COUPLED env of the wave is still iterating.  Its uncoupled mates ride along for
+      // free until then; what is left of their problems afterwards (measured: a mate's arm + cube iterations in sequence outlast the
+      // coupled env's by about one iteration per sub-step, at the whole-problem iteration's price) they finish in their own arm / cube
+      // loops -- a third of the cost per iteration, and bit for bit the same iterates: an uncoupled env's arithmetic in here IS that
+      // of its own loops (which is what keeps an env's bits independent of its wave-mates), so where an iteration runs changes nothing.
+      // The hand-over carries the problem the group is on, its cost so far and its iteration count.
+      if (!__any(!two)) { *resume = prob; *rcost = cost; *riter = iter; return; }
+    }
     real p = 0;
     // The arm problem's quadratic rows are usually just single-dof rows (the two slider friction-loss rows; now and then a
     // joint at its limit) -- no sphere on the table.  Its Hessian is then M + diag(delta) with at most two nonzero deltas, and
@@ -2221,13 +2238,20 @@ __device__ __forceinline__ real solve_newton_sl(Ws<NL>& w, const LModel<NL>& lm,
   constexpr uint32_t FC_MASK = ((1u << Dim<NL>::NSS) - 1u) << 4;           // sphere-cube slots couple arm and cube
   const bool coupled = (act & FC_MASK) != 0;                               // (group-uniform)
   if constexpr (G == 16) {
+    // what this group still has to run in its own loops: its arm problem and then its cube problem (an uncoupled env in a wave
+    // without a coupled one), or -- after a joint loop -- whatever the joint loop handed back (nothing for the coupled env itself)
+    int resume = KM_SUB_ARM, riter = 0;
+    real rcost = cost0;
     if (__any(coupled)) {
       // a coupled env in the wave: its whole-problem loop and the wave-mates' arm and cube loops share one instruction stream
-      newton_loop_sl<NL, G, KM_SUB_ALL, true>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, coupled ? cost0 + cost1 : cost0, grad, qf, ql, u, W, pf, !coupled, cost1);
-    } else {
-      newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost0, grad, qf, ql, u, W, pf);
-      newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, cost1, grad, qf, ql, u, W, pf);
+      // for as long as the coupled env iterates
+      resume = 0;
+      newton_loop_sl<NL, G, KM_SUB_ALL, true>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, coupled ? cost0 + cost1 : cost0, grad, qf, ql, u, W, pf, !coupled, cost1,
+                                              0, &resume, &rcost, &riter);
     }
+    if (resume == KM_SUB_ARM) newton_loop_sl<NL, G, KM_SUB_ARM>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, rcost, grad, qf, ql, u, W, pf, false, 0, riter);
+    if (resume != 0) newton_loop_sl<NL, G, KM_SUB_CUBE>(w, lm, m, sub, cr, mdiag, a_s, a, Mr, resume == KM_SUB_ARM ? cost1 : rcost, grad, qf, ql, u, W, pf,
+                                                        false, 0, resume == KM_SUB_ARM ? 0 : riter);
   } else {
     // two-row groups keep the separate loops: their cube block runs the one-row code in the second DPP row while the whole
     // problem runs the two-row code -- different operation order, so a joint loop would make an env's bits depend on its wave-mates
@@ -2277,7 +2301,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
     bbase = row ? split : 0;
     bli = (split && c < (row ? NL - split : split)) ? bbase + c : -1;
     if (split) {                                 // entries between the blocks: never written below, read as part of the rows
-      for (int e = sub; e < NL * NL; e += G) (&w.Minv[0][0])[e] = 0.0;
+      for (int e = sub; e < (int)(sizeof(w.Minv) / sizeof(real)); e += G) (&w.Minv[0][0])[e] = 0.0;      // (the padded rows whole)
     }
   }
   if constexpr (G == 16) bias_bodies_rows<NL, NL>(w, lm, m, sub < NL ? sub : -1, 0, sub == NL, FN);

@@ -243,16 +243,16 @@ def test_heavy_first_dispatch_changes_nothing_but_the_slots(monkeypatch, n, hepb
     """Single-arm launches of one residency round dispatch the envs predicted heavy (a collider on or near the cube at the end of
     their last step) FIRST and with a wave to themselves (or two per wave), everybody else four (two) per wave behind them: the
     dispatch table is a partition of the env ids rebuilt by every step, and an env's bits depend neither on its slot nor on its
-    wave-mates -- a handle with the dispatch (the default at >= 2048 envs) against one with KMANIP_HEAVY_DISPATCH=0, bit for bit,
+    wave-mates -- a handle with the dispatch (KMANIP_HEAVY_DISPATCH=1) against one without, bit for bit,
     across an auto-reset; the table is a permutation every step and heavy envs do occur."""
     import ctypes as C
     import torch
     from gym_kmanip_amd import env_hip
     monkeypatch.setenv("KMANIP_HEAVY_EPB", hepb)
-    a = env_hip.make("KManipSoloArm", num_envs=n, seed=5)              # heavy-first dispatch (n >= 2048)
-    monkeypatch.setenv("KMANIP_HEAVY_DISPATCH", "0")
-    b = env_hip.make("KManipSoloArm", num_envs=n, seed=5)
+    monkeypatch.setenv("KMANIP_HEAVY_DISPATCH", "1")
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=5)              # heavy-first dispatch (an opt-in experiment: DESIGN.md 3.4c)
     monkeypatch.delenv("KMANIP_HEAVY_DISPATCH")
+    b = env_hip.make("KManipSoloArm", num_envs=n, seed=5)
     S = a.L.kmanip_dbg_wave_slots(a.h)
     assert S > n and b.L.kmanip_dbg_wave_slots(b.h) == n
     a.k_reset(); b.k_reset()
