@@ -297,12 +297,12 @@ class Workload:
     the loop this imitates samples them: examples/2_log_with_h5py.py:22-26)."""
     BANK_MAX = 4096                       # steps laid out ahead in HBM at most (4096 x 4096 envs x 7 x 4 B = 470 MB)
 
-    def __init__(self, torch, env_id, n, device_index, rank, off, solver, solver_iterations, stagger=True):
+    def __init__(self, torch, env_id, n, device_index, rank, off, solver, solver_iterations, stagger=True, ik_max_nfev=0):
         from gym_kmanip_amd import env_hip
         from gym_kmanip_amd.model import compile_model
         import numpy as np
         self.torch = torch
-        self.cm = compile_model(env_id, auto_reset=True, solver_iterations=solver_iterations, solver=solver)
+        self.cm = compile_model(env_id, auto_reset=True, solver_iterations=solver_iterations, solver=solver, ik_max_nfev=ik_max_nfev)
         self.n = n
         self.env = env_hip.KManipEnvHip(self.cm, num_envs=n, device=device_index, seed=0, env_id_offset=off)
         self.act = torch.empty((n, self.cm.act_dim), dtype=torch.float32, device="cuda")

@@ -78,6 +78,7 @@ struct DevBuf {
   } while (0)
 
 static int validate(const KModelDesc* d, std::string& err) {
+  if (d->ik_max_nfev < 0) { err = "ik_max_nfev must be 0 (the reference's 100 n) or a positive cap"; return -1; }
   if (d->nlink != 10 && d->nlink != 20) { err = "nlink must be 10 or 20 (KManipSoloArm / DualArm / Torso)"; return -1; }
   if (d->nsphere < 0 || d->nsphere > KM_MAX_SPHERES || d->nsphere > 6 * (d->nlink / 10)) { err = "too many collision spheres (at most 6 per 10 links: one collision lane each)"; return -1; }
   for (int s = 0; s < d->nsphere; s++)

@@ -428,7 +428,7 @@ __device__ __forceinline__ real lane_strictly_feasible(real x, real lb, real ub,
 template <int N>
 __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_out) {
   const real ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
-  const int max_nfev = 100 * N;
+  const int max_nfev = P.m->ik_max_nfev > 0 ? P.m->ik_max_nfev : 100 * N;      // (KModelDesc::ik_max_nfev: opt-in cap, 0 = SciPy's default)
   const real jreg2 = 2 * P.m->ik_jac_reg * P.m->ik_jac_reg;
   real ft[6], Jc[6], ft_new[6], Jn[6], e[N];
 #pragma unroll

@@ -133,7 +133,7 @@ class KModelDesc(C.Structure):
         ("nlink", C.c_int32), ("narm", C.c_int32), ("nsphere", C.c_int32), ("act_dim", C.c_int32),
         ("obs_dim", C.c_int32), ("max_episode_steps", C.c_int32), ("n_sub_steps", C.c_int32),
         ("solver_iterations", C.c_int32), ("touch_reward_enabled", C.c_int32), ("auto_reset", C.c_int32),
-        ("act_col", C.c_int32 * len(KM_ACT_KEYS)), ("solver", C.c_int32),
+        ("act_col", C.c_int32 * len(KM_ACT_KEYS)), ("solver", C.c_int32), ("ik_max_nfev", C.c_int32), ("pad0_", C.c_int32),
         ("link_parent", C.c_int32 * KM_MAX_LINKS), ("jnt_type", C.c_int32 * KM_MAX_LINKS),
         ("forcelimited", C.c_int32 * KM_MAX_LINKS), ("pad1_", C.c_int32 * KM_MAX_LINKS),
         ("link_pos", (C.c_double * 3) * KM_MAX_LINKS), ("link_quat", (C.c_double * 4) * KM_MAX_LINKS),
@@ -264,7 +264,8 @@ def invweight0(d: "KModelDesc"):
 
 
 def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool = False,
-                  solver: str = "newton", solver_iterations: int = 100, solver_tolerance: float = 1e-8) -> CompiledModel:
+                  solver: str = "newton", solver_iterations: int = 100, solver_tolerance: float = 1e-8,
+                  ik_max_nfev: int = 0) -> CompiledModel:
     spec = ENV_SPECS[env_id_or_spec] if isinstance(env_id_or_spec, str) else env_id_or_spec
     asset = load_asset(spec.asset)
     links = asset["links"]
@@ -276,6 +277,7 @@ def compile_model(env_id_or_spec, *, auto_reset: bool = True, touch_reward: bool
     d.n_sub_steps = int(round(CONTROL_TIMESTEP / MJ_TIMESTEP))
     d.solver = SOLVERS[solver]
     d.solver_iterations = solver_iterations
+    d.ik_max_nfev = int(ik_max_nfev)      # 0 = the reference's least_squares default (100 n); > 0: opt-in cap (include/kmanip.h)
     d.solver_tolerance = solver_tolerance
     d.touch_reward_enabled = int(touch_reward)
     d.auto_reset = int(auto_reset)

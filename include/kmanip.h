@@ -90,6 +90,13 @@ typedef struct KModelDesc {
   int32_t auto_reset;            /* 1: envs whose done byte is set are reset inside kmanip_step    */
   int32_t act_col[KM_ACT_NKEYS]; /* first column of each action key, -1 if the key is absent       */
   int32_t solver;                /* KM_SOLVER_NEWTON (MuJoCo's default, what the reference runs) or KM_SOLVER_PGS */
+  /* OPT-IN, NOT THE REFERENCE: cap on the function evaluations of one ik() call.  0 (default) = the reference's
+   * scipy.optimize.least_squares default max_nfev = 100 * n (ik_mujoco.py:129-135 passes none): a start in a flat region lets the
+   * TRF crawl for 350-650 evaluations, and a batch's launch waits for it (one launch in ~40 at 4096 envs runs 2-7 x long).  A
+   * throughput caller may bound it (e.g. 64): the IK then returns its best accepted point with status 0, like SciPy at max_nfev;
+   * every parity test and the bench's headline run with 0. */
+  int32_t ik_max_nfev;
+  int32_t pad0_;
 
   /* ---- kinematic tree (link i <-> dof i <-> qpos i <-> actuator i), parents before children */
   int32_t link_parent[KM_MAX_LINKS];       /* -1 = fixed to world                                  */

@@ -520,7 +520,7 @@ static double select_step(const double* x, const double* Jh, int m, int n, const
 static int trf_bounds(IkProb* P, double* x, int* nfev_out) {
   const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
   int n = P->n, m = 6 + 2 * n, R = m + n;
-  int max_nfev = 100 * n;
+  int max_nfev = P->m->ik_max_nfev > 0 ? P->m->ik_max_nfev : 100 * n;   /* least_squares default; KModelDesc.ik_max_nfev: opt-in cap */
   double f[TRF_MMAX], f_new[TRF_MMAX], J[TRF_MMAX * KM_MAX_IK], g[KM_MAX_IK] = {0};
   double v[KM_MAX_IK], dv[KM_MAX_IK], d[KM_MAX_IK], diag_h[KM_MAX_IK], g_h[KM_MAX_IK];
   double Jaug[TRF_RMAX * KM_MAX_IK], Jh[TRF_MMAX * KM_MAX_IK], faug[TRF_RMAX];

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): which launches of the bench workload are slow, and why.  Replays bench.py's desynchronised workload,
-times every kmanip_step with events and prints, for the slow ones, the IK evaluation counts (kmanip_get_diag) of the batch."""
+times every kmanip_step with events and prints, for the slow ones, the IK evaluation counts (kmanip_get_diag) of the batch.
+   python tests/tools/slow_launches.py [launches] [ik_max_nfev]     (ik_max_nfev: the opt-in cap of KModelDesc, 0 = the reference's 100 n)"""
 import os, sys
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
@@ -9,7 +10,9 @@ import torch
 import bench
 
 args = bench.parse_args(["--no-variants", "--no-cpu-baseline"])
-w = bench.Workload(torch, "KManipSoloArm", 4096, 0, 0, 0, "newton", 100)
+cap = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+w = bench.Workload(torch, "KManipSoloArm", 4096, 0, 0, 0, "newton", 100, ik_max_nfev=cap)
+print("KManipSoloArm @ 4096 envs, ik_max_nfev = %d%s" % (cap, " (the reference's default, 100 n)" if cap == 0 else " (opt-in cap)"))
 env = w.env
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 w.lay_out(steps)                      # bench.py's action stream (Philox keyed (seed; env id, episode, step))
