@@ -245,6 +245,7 @@ __device__ __forceinline__ void rgb_scene(const KDeviceModel* dm, const RenderSc
 // every wave ran both paths -- 0.155 ms against round 3's 0.089; dropped.)
 struct DepthScene { real ol[3], DX[3], DY[3], DZ[3]; real oc[KM_RENDER_MAXVIS][3], cc[KM_RENDER_MAXVIS]; int nvis; };
 
+template <bool COLFIXED>      // COLFIXED: blockDim.x is a whole number of image rows (the launcher knows)
 __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
                                                       float* __restrict__ depth) {
   __shared__ RenderScene sc;
@@ -297,11 +298,26 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
   float* __restrict__ out = depth + (size_t)env * npix;
   int r = threadIdx.x / width, c = threadIdx.x - r * width;         // row / column advance incrementally (no division in the loop)
   const int dr = blockDim.x / width, dc = blockDim.x - dr * width;
+  // Round 5: when the workgroup's stride is a whole number of image rows (64-wide images: 128 lanes = two rows) a lane keeps its
+  // COLUMN for the whole loop, so everything that is linear in the pixel coordinates has a per-lane constant part -- the ray
+  // direction in the world and in the cube frame cost one FMA per component and pixel instead of two or three
+  constexpr bool colfixed = COLFIXED;
+  const real dxl = (c + 0.5 - hw) * inv_f;
+  real ex[3], bx[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) { ex[a] = X[a] * dxl - Z[a]; bx[a] = DX[a] * dxl - DZ[a]; }
   for (int p = threadIdx.x; p < npix; p += blockDim.x) {
-    const real dx = (c + 0.5 - hw) * inv_f, dy = -(r + 0.5 - hh) * inv_f;
+    const real dx = colfixed ? dxl : (c + 0.5 - hw) * inv_f, dy = -(r + 0.5 - hh) * inv_f;
     c += dc; r += dr;
     if (c >= width) { c -= width; r++; }
-    const real d0 = X[0] * dx + Y[0] * dy - Z[0], d1 = X[1] * dx + Y[1] * dy - Z[1], d2 = X[2] * dx + Y[2] * dy - Z[2];
+    real d0, d1, d2, dl0, dl1, dl2;
+    if constexpr (colfixed) {
+      d0 = __builtin_fma(Y[0], dy, ex[0]); d1 = __builtin_fma(Y[1], dy, ex[1]); d2 = __builtin_fma(Y[2], dy, ex[2]);
+      dl0 = __builtin_fma(DY[0], dy, bx[0]); dl1 = __builtin_fma(DY[1], dy, bx[1]); dl2 = __builtin_fma(DY[2], dy, bx[2]);
+    } else {
+      d0 = X[0] * dx + Y[0] * dy - Z[0]; d1 = X[1] * dx + Y[1] * dy - Z[1]; d2 = X[2] * dx + Y[2] * dy - Z[2];
+      dl0 = DX[0] * dx + DY[0] * dy - DZ[0]; dl1 = DX[1] * dx + DY[1] * dy - DZ[1]; dl2 = DX[2] * dx + DY[2] * dy - DZ[2];
+    }
     real best = zfar;
     // table top: the rectangle table_rect at z = table_z
     if (d2 != 0) {
@@ -312,14 +328,13 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
     // cube box: slab test in the cube frame -- only for rays that meet the box's bounding sphere (six operations decide it; a
     // wave is one image row or two, so the test is coherent)
     const real a2 = d0 * d0 + d1 * d1 + d2 * d2;
-    const real bq = DX[0] * dx + DY[0] * dy, bq1 = DX[1] * dx + DY[1] * dy, bq2 = DX[2] * dx + DY[2] * dy;   // (reused below)
-    const real bc = (bq - DZ[0]) * ol[0] + (bq1 - DZ[1]) * ol[1] + (bq2 - DZ[2]) * ol[2];
+    const real bc = dl0 * ol[0] + dl1 * ol[1] + dl2 * ol[2];       // (ray direction in the cube frame) . (origin in the cube frame)
     if (bc * bc - a2 * cube_cc >= 0) {
       real t0 = -INFINITY, t1 = INFINITY;
       bool ok = true;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const real dl = (a == 0 ? bq : (a == 1 ? bq1 : bq2)) - DZ[a];
+        const real dl = a == 0 ? dl0 : (a == 1 ? dl1 : dl2);
         if (dl != 0) {
           const real inv = frcp(dl);
           const real ta = (-hf[a] - ol[a]) * inv, tb = (hf[a] - ol[a]) * inv;
@@ -337,8 +352,9 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
       if (s < nvis) {
         const real b = d0 * soc[s][0] + d1 * soc[s][1] + d2 * soc[s][2], disc = b * b - a2 * scc[s];
         if (disc >= 0) {
-          const real t = (-b - km_sqrt(disc)) * frcp(a2);
-          if (t > 0 && t < best) best = t;
+          // nearest root; compared before the division: t < best  <=>  -b - sqrt(disc) < best * a2  (a2 > 0)
+          const real num = -b - km_sqrt(disc);
+          if (num > 0 && num < best * a2) best = num * frcp(a2);
         }
       }
     }
@@ -460,13 +476,25 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
     const float k0 = g.tz - g.o[2], sg = k0 < 0.0f ? -1.0f : 1.0f, thr = k0 != 0.0f ? fabsf(k0) / g.zfar : INFINITY;
     const float Xzs = sg * g.X[2], Yzs = sg * g.Y[2], Zzs = sg * g.Z[2], lam = -0.4f * sg, c1 = 0.4f + g.tab_L;
     const int nobj = g.nsph;
+    // Round 5: the loop was bound by instruction issue, not by its stores (~95 instructions a quad: 0.38 of its 0.45 ms).  A lane
+    // keeps its image row while the block walks the tile columns, so the row's table span (20 instructions) and its ray constants
+    // are computed once per tile ROW; and a quad that lies wholly inside the span and above the horizon -- nearly all of them --
+    // shades its four pixels without the three per-pixel tests.
+    float lo = 0, hi = 0, dy = 0, rz = 0, rd = 0;
+    bool row_ok = false;              // every pixel of this row that is inside the span also passes the horizon test
     for (int tile = 0; tile < ntile; tile++) {
       const int r = (tr << 4) + ty, qc = (tc << 4) + tx, c = qc << 2, q = r * wq + qc;
+      if (tc == 0) {
+        dy = -(r + 0.5f - hh) * inv_f;
+        rgb_table_span(g, dy, lo, hi);
+        rz = Yzs * dy - Zzs; rd = dy * dy + 1.0f;
+        // s dz is linear in dx: above the threshold on the whole clipped span iff it is at both ends (+- a pixel of slack)
+        const float xa = fmaxf(lo, (0.5f - hw) * inv_f) - inv_f, xb = fminf(hi, (width - 0.5f - hw) * inv_f) + inv_f;
+        row_ok = (Xzs * xa + rz > thr) && (Xzs * xb + rz > thr);
+      }
       if (++tc == tcols) { tc = 0; tr++; }
       if (r >= height || qc >= wq) continue;
-      const float dy = -(r + 0.5f - hh) * inv_f, dx0 = (c + 0.5f - hw) * inv_f;
-      float lo, hi;
-      rgb_table_span(g, dy, lo, hi);
+      const float dx0 = (c + 0.5f - hw) * inv_f;
       uint32_t w0, w1, w2;
       if (r >= g.ubox[0] && r <= g.ubox[1] && c + 3 >= g.ubox[2] && c <= g.ubox[3]) {
         uint32_t objs = 0;                                  // objects whose bounding rectangle this quad touches
@@ -479,15 +507,24 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
       } else if (!(dx0 + 3.0f * inv_f > lo && dx0 < hi)) {
         w0 = 0; w1 = 0; w2 = 0;                                                        // beside the table: background
       } else {
-        const float rz = Yzs * dy - Zzs, rd = dy * dy + 1.0f;
         uint32_t v[4];
+        if (row_ok && dx0 > lo && dx0 + 3.0f * inv_f < hi) {                  // the whole quad is table: no per-pixel tests
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const float dx = (c + i + 0.5f - hw) * inv_f;
-          const float sdz = Xzs * dx + rz, dd = dx * dx + rd;
-          const float a = __builtin_amdgcn_fmed3f(sdz * __builtin_amdgcn_rsqf(dd) * lam, 0.0f, 1.0f);
-          const float I = __builtin_amdgcn_fmed3f(a + c1, 0.0f, 1.0f);
-          v[i] = (sdz > thr && dx > lo && dx < hi) ? (uint32_t)(51.0f * I + 0.5f) : 0u;   // table rgba .2 .2 .2: 255 * 0.2 = 51
+          for (int i = 0; i < 4; i++) {
+            const float dx = dx0 + (float)i * inv_f;
+            const float sdz = Xzs * dx + rz, dd = dx * dx + rd;
+            const float a = __builtin_amdgcn_fmed3f(sdz * __builtin_amdgcn_rsqf(dd) * lam, 0.0f, 1.0f);
+            v[i] = (uint32_t)(__builtin_amdgcn_fmed3f(a + c1, 0.0f, 1.0f) * 51.0f + 0.5f);  // table rgba .2 .2 .2: 255 * 0.2 = 51
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float dx = (c + i + 0.5f - hw) * inv_f;
+            const float sdz = Xzs * dx + rz, dd = dx * dx + rd;
+            const float a = __builtin_amdgcn_fmed3f(sdz * __builtin_amdgcn_rsqf(dd) * lam, 0.0f, 1.0f);
+            const float I = __builtin_amdgcn_fmed3f(a + c1, 0.0f, 1.0f);
+            v[i] = (sdz > thr && dx > lo && dx < hi) ? (uint32_t)(51.0f * I + 0.5f) : 0u;
+          }
         }
         // grey pixels: the three dwords are byte replications of the four values
         w0 = __builtin_amdgcn_perm(v[1], v[0], 0x04000000u);                         // v0 v0 v0 v1
@@ -512,7 +549,8 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
                                 hipStream_t stream) {
   // 128 lanes per env: two waves -- 2048 envs x 2 waves fill the chip's 4096 wave slots (120 registers: four waves per SIMD) in one round
-  hipLaunchKernelGGL(k_render_depth, dim3(st.num_envs), dim3(128), 0, stream, dm, st, cam, height, width, depth);
+  if (width > 0 && 128 % width == 0) hipLaunchKernelGGL(k_render_depth<true>, dim3(st.num_envs), dim3(128), 0, stream, dm, st, cam, height, width, depth);
+  else hipLaunchKernelGGL(k_render_depth<false>, dim3(st.num_envs), dim3(128), 0, stream, dm, st, cam, height, width, depth);
 }
 void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, const KRenderJobs& jobs, hipStream_t stream) {
   hipLaunchKernelGGL(k_render_rgb, dim3(st.num_envs, jobs.n), dim3(256), 0, stream, dm, st, jobs);
