@@ -50,6 +50,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=0, help="also render a DxD gripper-cam depth image per env each step (BASELINE config 5)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="K > 1: the (reward, done) records of K steps per all-gather (dist.BlockRewardDoneGather) instead of one per step")
+    ap.add_argument("--gather-serial", action="store_true",
+                    help="N > 1 (or --rccl-world1): the step's stream waits for its own (reward, done) all-gather before the next step "
+                         "instead of overlapping it with the next step (A/B switch; dist.RewardDoneGather(overlap=False))")
     ap.add_argument("--rccl-world1", action="store_true",
                     help="N = 1 only: run as a one-rank RCCL job (backend nccl, world_size 1) with the per-step (reward, done) "
                          "all-gather forced through all_gather_into_tensor(async_op=True) -- executes the device-collective path "
@@ -67,6 +72,23 @@ def parse_args(argv=None):
 
 # --------------------------------------------------------------------------------------------------------------------
 # multi-GPU self-launch: the parent never initialises HIP and never execs
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File descriptor 1 -> 2 for the duration (native libraries' prints included): rank 0's stdout carries ONE JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def free_port():
     s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
     s.bind(("127.0.0.1", 0))
@@ -535,7 +557,8 @@ def run_rank(args):
             os.environ["NCCL_MAX_NCHANNELS"] = "1"
             os.environ["NCCL_NTHREADS"] = "64"
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        with stdout_to_stderr():      # RCCL prints a five-line version banner to STDOUT when its communicator is created
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     if args.envs_total:
         assert args.envs_total % world == 0, "--envs-total must be a multiple of the GPU count (equal shards for the gather)"
@@ -550,13 +573,19 @@ def run_rank(args):
     gather = None
     ranks_seen = 1
     if dist is not None:
-        t = torch.ones(1, device="cuda"); dist.all_reduce(t); ranks_seen = int(t.item())      # RCCL really spans all ranks
+        with stdout_to_stderr():      # (the communicator is created lazily, by the first collective)
+            t = torch.ones(1, device="cuda"); dist.all_reduce(t); ranks_seen = int(t.item())      # RCCL really spans all ranks
         rc = check_ranks_seen(ranks_seen, world, rank)
         if rc:
             return rc
         if not args.no_gather:
-            from gym_kmanip_amd.dist import RewardDoneGather
-            gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist, force_collective=args.rccl_world1)
+            from gym_kmanip_amd.dist import BlockRewardDoneGather, RewardDoneGather
+            if args.gather_every > 1:
+                gather = BlockRewardDoneGather(n, world, torch.device("cuda", local_rank), dist, block=args.gather_every,
+                                               force_collective=args.rccl_world1)
+            else:
+                gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist, force_collective=args.rccl_world1,
+                                          overlap=not args.gather_serial)
 
     # BASELINE config 5: the gripper-cam depth render is bound to the step (kmanip_bind_step_depth): every kmanip_step call
     # ends by rendering the state it produced, on the same stream
@@ -649,7 +678,7 @@ def run_rank(args):
                        "envs_per_gpu": n, "depth_image": ("%dx%d float32 grip_r" % (args.depth, args.depth)) if args.depth else None,
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
-                       "collective": "async all_gather of (reward, done) per step" if gather is not None else "none",
+                       "collective": (("async all_gather of (reward, done) per step" if args.gather_every <= 1 else "async all_gather of (reward, done), %d steps per exchange" % args.gather_every) + ("" if not args.gather_serial else ", step waits for its own exchange")) if gather is not None else "none",
                        "rccl_ranks_seen": ranks_seen, "backend": backend if dist is not None else None, "library": version},
             "roofline": {"bound": "hbm", "bound_note": "the contract's two choices are hbm | mfma; this kernel is bound by FP64 VALU issue and dependent latency (see valu), its HBM fraction is small by construction",
                          "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)" + (" + k_render (in-step depth image)" if args.depth else (" + k_render_rgb (camera observations)" if rgb_bufs else "")), "achieved": achieved,

@@ -162,3 +162,41 @@ def test_a_step_without_an_exchange_keeps_the_two_sides_in_phase():
         b = g.post()
         r, _ = g.result(b)
         assert torch.equal(r[:n], torch.arange(n, dtype=torch.float64) + 1000.0 * (eng.k - 1)), k
+
+
+def _block_worker(rank, world, port, n_total, steps, K, out_dir):
+    import torch
+    import torch.distributed as dist
+    from gym_kmanip_amd.dist import BlockRewardDoneGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_total, world, rank)
+    g = BlockRewardDoneGather(hi - lo, world, torch.device("cpu"), dist, block=K)
+    rew_blocks, done_blocks = [], []
+    for k in range(steps):
+        # a stand-in engine: reward / done are functions of (global env id, step), so the gathered blocks are checkable
+        rew = torch.arange(lo, hi, dtype=torch.float64) * 1000 + k
+        done = torch.tensor([(e + k) % 5 == 0 for e in range(lo, hi)], dtype=torch.float64)
+        b = g.post(rew, done)
+        assert (b is not None) == (k % K == K - 1)
+        if b is not None:
+            r, d = g.result(b)
+            rew_blocks.append(r.numpy().copy()); done_blocks.append(d.numpy().copy())
+    if rank == 1:
+        np.savez(os.path.join(out_dir, "blocks.npz"), rew=np.array(rew_blocks), done=np.array(done_blocks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_block_gather_two_ranks(tmp_path):
+    """dist.BlockRewardDoneGather: K steps per exchange, both ranks see every rank's records in global env order."""
+    import torch.multiprocessing as mp
+    n_total, steps, K, world = 10, 12, 3, 2
+    mp.spawn(_block_worker, args=(world, _free_port(), n_total, steps, K, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "blocks.npz"))
+    assert got["rew"].shape == (steps // K, K, n_total)
+    for blk in range(steps // K):
+        for j in range(K):
+            k = blk * K + j
+            assert np.array_equal(got["rew"][blk, j], np.arange(n_total) * 1000.0 + k)
+            assert np.array_equal(got["done"][blk, j], np.array([(e + k) % 5 == 0 for e in range(n_total)], dtype=np.uint8))

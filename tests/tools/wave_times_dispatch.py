@@ -21,7 +21,8 @@ for k in range(L):
     e.L.kmanip_dbg_wave_clocks(e.h, clk.ctypes.data_as(C.POINTER(C.c_ulonglong)), slot.ctypes.data_as(C.POINTER(C.c_int32)) if disp else None, None)
     if not disp:
         slot = np.arange(S, dtype=np.int32)
-    nf = e.get_diag()[1].max(1)
+    dg = e.get_diag()
+    nf = dg[1].max(1); coupled_now = (dg[0] & 0xFFF00) != 0          # (end-of-step state: a sphere on the cube)
     start = ((clk >> np.uint64(40)) & np.uint64(0xFFFFFF)).astype(np.int64)
     ticks = (clk & np.uint64(0xFFFFFFFFFF)).astype(np.float64)
     sl = slot[:(S // epb) * epb].reshape(-1, epb); tk = ticks[:(S // epb) * epb].reshape(-1, epb); st = start[:(S // epb) * epb].reshape(-1, epb)
@@ -37,6 +38,10 @@ for k in range(L):
         heavy_w.append(w[hv]); light_w.append(w[~hv]); nheavy.append(int(hv.sum()))
     late.append((s0 > 2000).sum())        # waves that started more than 20 us after the first
     mx = np.argmax(w)
+    top = np.argsort(w)[::-1][:4]
+    envs_of = sl[used]
+    tops = "; ".join("%.0f nfev %s cpl %s" % (w[i], nf[envs_of[i][envs_of[i] >= 0]], coupled_now[envs_of[i][envs_of[i] >= 0]].astype(int)) for i in top)
+    print("   top 4 waves: " + tops)
     print("launch %2d: waves %4d  max %.0f (%s, %d env(s), nfev %s, started +%d us)  mean %.0f  p99 %.0f   late-started waves %d%s" % (
         k, len(w), w[mx], "heavy" if disp and c[mx] < epb else "light", c[mx], nf[sl[used][mx][sl[used][mx] >= 0]], s0[mx] // 100, w.mean(), np.percentile(w, 99), late[-1],
         "   heavy waves %d: mean %.0f max %.0f | light: mean %.0f p99 %.0f max %.0f" % (nheavy[-1], heavy_w[-1].mean() if nheavy[-1] else 0, heavy_w[-1].max() if nheavy[-1] else 0,
