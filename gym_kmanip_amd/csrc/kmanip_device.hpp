@@ -299,6 +299,21 @@ __device__ __forceinline__ void dppfma_acc3(real& acc, real x0, real t0, real x1
   KM_RUN(WAIT, KM_DPPF("", 0, 1, 4, 7) KM_DPPF("", 0, 2, 5, 7) KM_DPPF("", 0, 3, 6, 7),
          : "+&v"(acc) : "v"(x0), "v"(x1), "v"(x2), "v"(t0), "v"(t1), "v"(t2), "n"(K));
 }
+// acc (-)= bcast_K(x0) * t0 + bcast_K(x1) * t1 (one accumulator, two sources, one lane K), in this order
+template <int K, bool WAIT = true>
+__device__ __forceinline__ void dppfma_acc2n(real& acc, real x0, real t0, real x1, real t1) {
+  KM_RUN(WAIT, KM_DPPF("-", 0, 1, 3, 5) KM_DPPF("-", 0, 2, 4, 5), : "+&v"(acc) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K));
+}
+template <int K, bool WAIT = true>
+__device__ __forceinline__ void dppfma_acc2(real& acc, real x0, real t0, real x1, real t1) {
+  KM_RUN(WAIT, KM_DPPF("", 0, 1, 3, 5) KM_DPPF("", 0, 2, 4, 5), : "+&v"(acc) : "v"(x0), "v"(x1), "v"(t0), "v"(t1), "n"(K));
+}
+// acc -= bcast_P(x) * t0 + bcast_Q(x) * t1: two lanes of ONE distributed vector (x must not be acc: a run never reads through DPP
+// what it writes)
+template <int P, int Q, bool WAIT = true>
+__device__ __forceinline__ void dppfma_row2n(real& acc, real x, real t0, real t1) {
+  KM_RUN(WAIT, KM_DPPF("-", 0, 1, 2, 4) KM_DPPF("-", 0, 1, 3, 5), : "+&v"(acc) : "v"(x), "v"(t0), "v"(t1), "n"(P), "n"(Q));
+}
 // acc += sum_i bcast_{K_i}(x) * t_i, i = 0..3: four lanes of ONE distributed vector against four coefficients (a row-times-
 // vector product), in this order
 template <int K0, int K1, int K2, int K3, bool WAIT = true>

@@ -273,43 +273,117 @@ __device__ __forceinline__ real tr_bwd(const TrFac<N>& F, real z) {
   return z * F.invd;
 }
 
+// ---- Round 5: the same factorisation with 2 x 2 BLOCK pivots (A = L D L^T, L unit block-lower-triangular, D block-diagonal).
+// A lone IK problem is a chain of dependent operations on 8 lanes, and a straggler (35-45 evaluations, one wave in ~100, which then
+// ends its launch) spends most of them in More's secular iteration: one factorisation and three triangular solves per trial
+// alpha.  The scalar Cholesky pays one reciprocal-square-root chain per pivot and two dependent operations per pivot and solve;
+// here a block costs ONE reciprocal (of its determinant) and ONE run of two broadcast-FMAs per solve -- 4 sequential steps for
+// n = 7 instead of 7.  Lane c keeps row c of L (h[j], j below its block), row c of L^T (ut[j]) and its row of D^-1 of its own
+// block (dd on the diagonal, dx towards the block partner c ^ 1).  Not the same roundoff as the scalar factor -- inside the
+// 1e-6 rad / nfev +- 1 bars of every IK comparison (the oracle factorises by SVD anyway).
+template <int N> struct TrFacB { real h[N], ut[N], dd, dx; };
+template <int N>
+__device__ __forceinline__ bool ldl_coop(const real (&arow)[N], const real (&e)[N], real alpha, int c, TrFacB<N>& F) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) { F.h[j] = __builtin_fma(e[j], alpha, arow[j]); F.ut[j] = 0; }
+  F.dd = 0; F.dx = 0;
+  static_for<0, N / 2>([&](auto kc) {
+    constexpr int p = 2 * decltype(kc)::value, q = p + 1;
+    const real a = bcast8<p>(F.h[p]), b = bcast8<q>(F.h[p]), cc = bcast8<q>(F.h[q]);
+    const real det = __builtin_fma(a, cc, -(b * b));
+    ok = ok && a > 0 && det > 0;                          // (uniform over the problem; a failed factor is never used)
+    const real rdet = frcp(det);
+    const real ia = cc * rdet, ib = -(b * rdet), ic = a * rdet;            // D^-1 of the block
+    F.dd = __builtin_fma(e[p], ia, __builtin_fma(e[q], ic, F.dd));
+    F.dx = __builtin_fma(e[p] + e[q], ib, F.dx);
+    // rows below the block: their two multipliers; rows on and above it keep exact zeros
+    const real l1 = c > q ? __builtin_fma(F.h[p], ia, F.h[q] * ib) : 0.0, l2 = c > q ? __builtin_fma(F.h[p], ib, F.h[q] * ic) : 0.0;
+    static_for<q + 1, N>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      // h[j] -= A[j][p] l1 + A[j][q] l2 (the UNSCALED entries of lane j: h[p], h[q] are overwritten after the runs);
+      // ut[j] += L[j][p] [c == p] + L[j][q] [c == q]
+      dppfma_acc2n<j, j == q + 1>(F.h[j], F.h[p], l1, F.h[q], l2);
+      dppfma_acc2<j, false>(F.ut[j], l1, e[p], l2, e[q]);
+    });
+    F.h[p] = l1; F.h[q] = l2;
+    // the next block's broadcasts (compiler-generated DPP moves) read what the last runs just wrote
+    if constexpr (q + 1 < N) dpp_settle(F.h[q + 1]);
+    if constexpr (q + 2 < N) dpp_settle(F.h[q + 2]);
+  });
+  if constexpr (N & 1) {
+    constexpr int r = N - 1;
+    const real d = bcast8<r>(F.h[r]);
+    ok = ok && d > 0;
+    F.dd = __builtin_fma(e[r], frcp(d), F.dd);
+    F.h[r] = 0;
+  }
+  return ok;
+}
+// z = L^-1 b (unit block-lower-triangular: a block's two components are final when the blocks before it are done)
+template <int N>
+__device__ __forceinline__ real ldl_fwd(const TrFacB<N>& F, real b) {
+  static_for<0, N / 2>([&](auto kc) {
+    constexpr int p = 2 * decltype(kc)::value, q = p + 1;
+    if constexpr (q + 1 < N) { const real zb = b; dppfma_row2n<p, q>(b, zb, F.h[p], F.h[q]); }      // rows below: b -= z_p L[.][p] + z_q L[.][q]
+  });
+  return b;
+}
+// w = D^-1 z, all blocks at once: the block partner's component arrives by a quad_perm swap of neighbouring lanes
+template <int N>
+__device__ __forceinline__ real ldl_mid(const TrFacB<N>& F, real z) {
+  const real zp = dpp_f64<0xB1>(z);                      // quad_perm [1,0,3,2]: lane c ^ 1
+  return __builtin_fma(F.dd, z, F.dx * zp);
+}
+// x = L^-T w: from the last pivot up; rows above a block subtract its two components through their row of L^T
+template <int N>
+__device__ __forceinline__ real ldl_bwd(const TrFacB<N>& F, real x) {
+  if constexpr (N & 1) { const real xb = x; dppfma1<true, N - 1>(x, xb, F.ut[N - 1]); }
+  static_for<0, N / 2>([&](auto kc) {
+    constexpr int k = N / 2 - 1 - decltype(kc)::value, p = 2 * k, q = p + 1;
+    if constexpr (k > 0) { const real xb = x; dppfma_row2n<p, q>(x, xb, F.ut[p], F.ut[q]); }
+  });
+  return x;
+}
+
 // scipy common.py solve_lsq_trust_region on the normal matrix: p = argmin of the model in the ball |p| <= Delta by More's
 // iteration on the secular equation, phi = |p(alpha)| - Delta, phi' = -|L^-1 p|^2 / |p| (SciPy evaluates the same two
 // numbers from its SVD).  g_h, p: this lane's components.
 template <int N>
 __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], const real (&e)[N], int c, real g_h, real Delta, real& alpha, real& p) {
-  TrFac<N> F;
+  TrFacB<N> F;
   const real ng = -g_h;
-  const bool full_rank = chol_coop<N>(arow, e, 0.0, c, F);
+  // |L_chol^-1 v|^2 = v^T A^-1 v = z^T D^-1 z with z = L^-1 v (what SciPy reads off its SVD as phi')
+  auto solve = [&](real rhs) { return ldl_bwd<N>(F, ldl_mid<N>(F, ldl_fwd<N>(F, rhs))); };
+  auto ainv_norm2 = [&](real v) { const real z = ldl_fwd<N>(F, v); return gsum8(z * ldl_mid<N>(F, z)); };
+  const bool full_rank = ldl_coop<N>(arow, e, 0.0, c, F);
   real pn = 0;
   if (full_rank) {
-    p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
+    p = solve(ng);
     pn = km_sqrt(gsum8(p * p));
     if (pn <= Delta) { alpha = 0.0; return; }
   }
   const real iDelta = frcp(Delta);
   real alpha_upper = km_sqrt(gsum8(g_h * g_h)) * iDelta, alpha_lower = 0.0;
   if (full_rank) {
-    const real q = tr_fwd<N>(F, p);
-    const real phi = pn - Delta, phip = -gsum8(q * q) * frcp(pn);
+    const real phi = pn - Delta, phip = -ainv_norm2(p) * frcp(pn);
     alpha_lower = -phi * frcp(phip);
   }
   if (!full_rank && alpha == 0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
   for (int it = 0; it < 10; it++) {
     if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-    chol_coop<N>(arow, e, alpha, c, F);
-    p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
+    ldl_coop<N>(arow, e, alpha, c, F);
+    p = solve(ng);
     pn = km_sqrt(gsum8(p * p));
-    const real q = tr_fwd<N>(F, p);
-    const real phi = pn - Delta, phip = -gsum8(q * q) * frcp(pn);
+    const real phi = pn - Delta, phip = -ainv_norm2(p) * frcp(pn);
     if (phi < 0) alpha_upper = alpha;
     const real ratio = phi * frcp(phip);
     alpha_lower = fmax(alpha_lower, alpha - ratio);
     alpha -= (phi + Delta) * ratio * iDelta;
     if (fabs(phi) < 0.01 * Delta) break;
   }
-  chol_coop<N>(arow, e, alpha, c, F);
-  p = tr_bwd<N>(F, tr_fwd<N>(F, ng));
+  ldl_coop<N>(arow, e, alpha, c, F);
+  p = solve(ng);
   p *= Delta * rsqrt_nr(gsum8(p * p));
 }
 
