@@ -48,6 +48,14 @@ def load():
         raise KManipError(
             "libkmanip_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no CPU fallback for the simulation path." % LIB_PATH)
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); this library links against the same SONAME.  Whichever is
+    # loaded FIRST serves the whole process, and a process that loaded /opt/rocm's copy first and torch's afterwards ends up with
+    # two runtimes, the second of which sees no device ("no ROCm-capable device is detected" from kmanip_create after
+    # `build(); smoke()` in one process).  The host side of this package is torch-based anyway: load torch's runtime first.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001  (a torch-less C caller binds the ABI directly)
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32p, u8p, f64p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_float)
     lib.kmanip_model_desc_size.restype = C.c_int
