@@ -31,6 +31,7 @@ struct KHandle_ {
   double* rd_rec[2] = {nullptr, nullptr};   // kmanip_bind_reward_done_record: the two record buffers
   int rd_sel = 0;                           // kmanip_select_reward_done_record: the one the next kmanip_step fills
   int timed_steps = 0;
+  bool last_step_timed = false; // the last kmanip_step recorded its events (the ring was not full): a render that follows may add its leg
   // render target bound to the step (BASELINE config 5: "depth render in the step"): kmanip_step then also renders
   int step_cam = -1, step_h = 0, step_w = 0;
   float* step_depth = nullptr;
@@ -352,6 +353,7 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   KM_ENTER(h);
   hipStream_t s = (hipStream_t)stream;
   const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
+  h->last_step_timed = tm;
   hipEvent_t* ev = tm ? &h->ev[4 * (size_t)h->timed_steps] : nullptr;
   // product path: ONE launch, before_step (decode + IK) fused into k_step so that no device-wide barrier sits between
   // an env's IK and its physics; the split launches remain for A/B timing (KMANIP_IK_UNFUSED=1)
@@ -419,6 +421,12 @@ int kmanip_render_rgb_multi(KHandle h, int ncam, const int* cams, const int* hei
   }
   KM_ENTER(h);
   kmanip_launch_render_rgb(h->dmodel, h->st, jobs, (hipStream_t)stream);
+  // kernel timing (kmanip_enable_timing): the camera observations rendered right after a timed step are that step's render leg --
+  // its start is the event the step recorded after k_step, so the render costs the stream ONE more event, not a pair around it
+  if (h->timing && h->last_step_timed && h->timed_steps > 0 && !h->ev_render[h->timed_steps - 1]) {
+    HIPCHK(h, hipEventRecord(h->ev[4 * (size_t)(h->timed_steps - 1) + 3], (hipStream_t)stream));
+    h->ev_render[h->timed_steps - 1] = 1;
+  }
   HIPCHK(h, hipGetLastError());
   return 0;
 }

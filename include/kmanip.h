@@ -287,11 +287,12 @@ KMANIP_API int kmanip_set_seed(KHandle h, uint64_t seed, int restart_episodes);
 KMANIP_API int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nfev, int32_t* ik_status);
 
 /* Kernel timing with HIP events recorded on the launch stream (bench.py roofline leg).  While enabled, every kmanip_step
- * records an event before and after k_step, one more after the bound in-step render, and -- only on the KMANIP_IK_UNFUSED=1 A/B
+ * records an event before and after k_step, one more after the bound in-step render (or after the first kmanip_render_rgb[_multi]
+ * call that follows the step: the camera observations of a *Vision id), and -- only on the KMANIP_IK_UNFUSED=1 A/B
  * path -- one before its stand-alone decode/IK launches (an event record costs the stream about 5 us, so the product path takes
  * the two it needs), into a ring of `KM_TIMING_SLOTS` steps.  kmanip_timing_summary synchronises the device and returns the
- * summed durations in milliseconds of the three legs (stand-alone IK: 0 on the product path; k_step; k_render of
- * kmanip_bind_step_depth: 0 when nothing is bound) over the recorded steps, then clears the ring.  Any output pointer may be NULL. */
+ * summed durations in milliseconds of the three legs (stand-alone IK: 0 on the product path; k_step; the step's render:
+ * kmanip_bind_step_depth's or the RGB render called after the step, 0 without one) over the recorded steps, then clears the ring.  Any output pointer may be NULL. */
 #define KM_TIMING_SLOTS 1024
 KMANIP_API int kmanip_enable_timing(KHandle h, int enable);
 KMANIP_API int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, double* render_ms_sum, int32_t* nsteps);
