@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
         w1 = __builtin_amdgcn_perm(v[2], v[1], 0x04040000u);                         // v1 v1 v2 v2
         w2 = __builtin_amdgcn_perm(v[3], v[2], 0x04040400u);                         // v2 v3 v3 v3
       }
-      out32[3 * q] = w0; out32[3 * q + 1] = w1; out32[3 * q + 2] = w2;
+      out32[3 * q] = w0; out32[3 * q + 1] = w1; out32[3 * q + 2] = w2;       // (one global_store_dwordx3; non-temporal stores measured 11 % slower)
     }
   } else {
     for (int p = threadIdx.x; p < npix; p += blockDim.x) {
