@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--seed", type=int, default=9)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=1, help="K > 1: dist.BlockRewardDoneGather, K steps per exchange")
     ap.add_argument("--force-collective", action="store_true",
                     help="issue the real all_gather_into_tensor(async_op=True) even at world_size 1 (dist.RewardDoneGather)")
     a = ap.parse_args()
@@ -27,7 +28,7 @@ def main():
     import torch
     import torch.distributed as dist
     from gym_kmanip_amd import env_hip
-    from gym_kmanip_amd.dist import RewardDoneGather, shard_range
+    from gym_kmanip_amd.dist import BlockRewardDoneGather, RewardDoneGather, shard_range
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = 0 if a.same_device else int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(dev)
@@ -37,7 +38,12 @@ def main():
     n = hi - lo
     env = env_hip.make(a.env, num_envs=n, device=dev, seed=a.seed, env_id_offset=lo)
     env.k_reset()
-    g = RewardDoneGather(n, world, torch.device("cuda", dev), dist, force_collective=a.force_collective)
+    K = a.gather_every
+    if K > 1:
+        assert a.steps % K == 0
+        g = BlockRewardDoneGather(n, world, torch.device("cuda", dev), dist, block=K, force_collective=a.force_collective)
+    else:
+        g = RewardDoneGather(n, world, torch.device("cuda", dev), dist, force_collective=a.force_collective)
     if a.force_collective:
         assert g.force_collective and not g.host_stage
     g.bind(env)                                                         # the step writes the packed record itself (as bench.py runs it)
@@ -46,7 +52,10 @@ def main():
 
     def take(b):
         r_all, d_all = g.result(b)
-        rew.append(r_all.cpu().numpy().copy()); done.append(d_all.cpu().numpy().copy())
+        if K > 1:                                                       # a block: K steps at once
+            rew.extend(r_all.cpu().numpy().copy()); done.extend(d_all.cpu().numpy().copy())
+        else:
+            rew.append(r_all.cpu().numpy().copy()); done.append(d_all.cpu().numpy().copy())
 
     prev = None
     for k in range(a.steps):
@@ -54,6 +63,8 @@ def main():
         g.before_step()                                                 # (ordering invariant: gym_kmanip_amd/dist.py)
         env.step_flat(act_all[lo:hi].contiguous().cuda())
         b = g.post(env.reward, env.done)
+        if b is None:                                                   # (block mode: no exchange completed by this step)
+            continue
         if prev is not None:                                            # pipelined like bench.py: step k's exchange is in
             take(prev)                                                  # flight while step k-1's result is consumed
         prev = b
