@@ -279,8 +279,12 @@ __device__ __forceinline__ real tr_bwd(const TrFac<N>& F, real z) {
 // alpha.  The scalar Cholesky pays one reciprocal-square-root chain per pivot and two dependent operations per pivot and solve;
 // here a block costs ONE reciprocal (of its determinant) and ONE run of two broadcast-FMAs per solve -- 4 sequential steps for
 // n = 7 instead of 7.  Lane c keeps row c of L (h[j], j below its block), row c of L^T (ut[j]) and its row of D^-1 of its own
-// block (dd on the diagonal, dx towards the block partner c ^ 1).  Not the same roundoff as the scalar factor -- inside the
-// 1e-6 rad / nfev +- 1 bars of every IK comparison (the oracle factorises by SVD anyway).
+// block (dd on the diagonal, dx towards the block partner c ^ 1).  The block's determinant and the multipliers' numerators are
+// compensated differences of products: a block of two nearly dependent Jacobian columns (the Torso's usual case) cancels most of
+// their leading digits, and with plain FMAs the worst one-step deviation from the oracle over 0.8 M Torso samples grew from 1e-11
+// to 8e-9 rad (still inside the IK bars; with the compensation it is 4e-12 again).  Measured on one box, same run: k_step 0.5942 ms
+// with the scalar Cholesky (-DKM_IK_CHOLESKY), 0.5917 ms with the blocks -- the IK is a fifth of a wave and the factorisation a
+// fifth of the IK.
 template <int N> struct TrFacB { real h[N], ut[N], dd, dx; };
 template <int N>
 __device__ __forceinline__ bool ldl_coop(const real (&arow)[N], const real (&e)[N], real alpha, int c, TrFacB<N>& F) {
@@ -291,14 +295,21 @@ __device__ __forceinline__ bool ldl_coop(const real (&arow)[N], const real (&e)[
   static_for<0, N / 2>([&](auto kc) {
     constexpr int p = 2 * decltype(kc)::value, q = p + 1;
     const real a = bcast8<p>(F.h[p]), b = bcast8<q>(F.h[p]), cc = bcast8<q>(F.h[q]);
-    const real det = __builtin_fma(a, cc, -(b * b));
+    // a cc - b^2 by Kahan's difference of products (the rounding error of b * b recovered with one FMA): an ill-conditioned block --
+    // two nearly dependent Jacobian columns, the Torso's usual case -- cancels most of the leading digits here
+    const real bb = b * b, det = __builtin_fma(a, cc, -bb) - __builtin_fma(b, b, -bb);
     ok = ok && a > 0 && det > 0;                          // (uniform over the problem; a failed factor is never used)
     const real rdet = frcp(det);
     const real ia = cc * rdet, ib = -(b * rdet), ic = a * rdet;            // D^-1 of the block
     F.dd = __builtin_fma(e[p], ia, __builtin_fma(e[q], ic, F.dd));
     F.dx = __builtin_fma(e[p] + e[q], ib, F.dx);
-    // rows below the block: their two multipliers; rows on and above it keep exact zeros
-    const real l1 = c > q ? __builtin_fma(F.h[p], ia, F.h[q] * ib) : 0.0, l2 = c > q ? __builtin_fma(F.h[p], ib, F.h[q] * ic) : 0.0;
+    // rows below the block: their two multipliers (h_p cc - h_q b) / det and (a h_q - b h_p) / det, the numerators again as
+    // differences of products with the rounding error of the subtracted product recovered (the entries of D^-1 of a nearly
+    // singular block are huge and of opposite sign: h_p ia + h_q ib would cancel); rows on and above the block keep exact zeros
+    const real hp = F.h[p], hq = F.h[q];
+    const real m1 = hq * b, n1 = __builtin_fma(hp, cc, -m1) - __builtin_fma(hq, b, -m1);
+    const real m2 = b * hp, n2 = __builtin_fma(a, hq, -m2) - __builtin_fma(b, hp, -m2);
+    const real l1 = c > q ? n1 * rdet : 0.0, l2 = c > q ? n2 * rdet : 0.0;
     static_for<q + 1, N>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // h[j] -= A[j][p] l1 + A[j][q] l2 (the UNSCALED entries of lane j: h[p], h[q] are overwritten after the runs);
@@ -351,12 +362,20 @@ __device__ __forceinline__ real ldl_bwd(const TrFacB<N>& F, real x) {
 // numbers from its SVD).  g_h, p: this lane's components.
 template <int N>
 __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], const real (&e)[N], int c, real g_h, real Delta, real& alpha, real& p) {
-  TrFacB<N> F;
   const real ng = -g_h;
+#ifdef KM_IK_CHOLESKY      // A/B build: the scalar Cholesky of rounds 3-4 (chol_coop / tr_fwd / tr_bwd above)
+  TrFac<N> F;
+  auto factor = [&](real al) { return chol_coop<N>(arow, e, al, c, F); };
+  auto solve = [&](real rhs) { return tr_bwd<N>(F, tr_fwd<N>(F, rhs)); };
+  auto ainv_norm2 = [&](real v) { const real q = tr_fwd<N>(F, v); return gsum8(q * q); };
+#else
+  TrFacB<N> F;
+  auto factor = [&](real al) { return ldl_coop<N>(arow, e, al, c, F); };
   // |L_chol^-1 v|^2 = v^T A^-1 v = z^T D^-1 z with z = L^-1 v (what SciPy reads off its SVD as phi')
   auto solve = [&](real rhs) { return ldl_bwd<N>(F, ldl_mid<N>(F, ldl_fwd<N>(F, rhs))); };
   auto ainv_norm2 = [&](real v) { const real z = ldl_fwd<N>(F, v); return gsum8(z * ldl_mid<N>(F, z)); };
-  const bool full_rank = ldl_coop<N>(arow, e, 0.0, c, F);
+#endif
+  const bool full_rank = factor(0.0);
   real pn = 0;
   if (full_rank) {
     p = solve(ng);
@@ -372,7 +391,7 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], const real 
   if (!full_rank && alpha == 0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
   for (int it = 0; it < 10; it++) {
     if (alpha < alpha_lower || alpha > alpha_upper) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-    ldl_coop<N>(arow, e, alpha, c, F);
+    factor(alpha);
     p = solve(ng);
     pn = km_sqrt(gsum8(p * p));
     const real phi = pn - Delta, phip = -ainv_norm2(p) * frcp(pn);
@@ -382,7 +401,7 @@ __device__ __forceinline__ void solve_tr_coop(const real (&arow)[N], const real 
     alpha -= (phi + Delta) * ratio * iDelta;
     if (fabs(phi) < 0.01 * Delta) break;
   }
-  ldl_coop<N>(arow, e, alpha, c, F);
+  factor(alpha);
   p = solve(ng);
   p *= Delta * rsqrt_nr(gsum8(p * p));
 }
