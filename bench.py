@@ -52,6 +52,15 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="K > 1: the (reward, done) records of K steps per all-gather (dist.BlockRewardDoneGather) instead of one per step")
+    ap.add_argument("--gather-direct", choices=["auto", "off", "stream", "side"], default="auto",
+                    help="issue the (reward, done) all-gather as ncclAllGather through dist.RcclDirect -- on the step's own stream, or on a "
+                         "side stream tied to it by two events -- instead of through torch.distributed's wrapper (off).  auto: side on "
+                         "RCCL (the wrapper costs the step's stream 36 us per exchange on one MI355X, the side stream 19 us: "
+                         "profiles/r05_rccl_direct.txt), off on gloo")
+    ap.add_argument("--gather-depth", type=int, default=0,
+                    help="ring of (reward, done) record buffers (dist.RewardDoneGather(depth=...)): a rank may run that many steps ahead "
+                         "of the slowest one before it waits.  0: 16 on RCCL across ranks (an IK crawl is up to seven steps long; "
+                         "tools/scaling_model.py), 2 otherwise")
     ap.add_argument("--gather-serial", action="store_true",
                     help="N > 1 (or --rccl-world1): the step's stream waits for its own (reward, done) all-gather before the next step "
                          "instead of overlapping it with the next step (A/B switch; dist.RewardDoneGather(overlap=False))")
@@ -573,12 +582,33 @@ def run_rank(args):
             return rc
         if not args.no_gather:
             from gym_kmanip_amd.dist import BlockRewardDoneGather, RewardDoneGather
-            if args.gather_every > 1:
-                gather = BlockRewardDoneGather(n, world, torch.device("cuda", local_rank), dist, block=args.gather_every,
-                                               force_collective=args.rccl_world1)
-            else:
-                gather = RewardDoneGather(n, world, torch.device("cuda", local_rank), dist, force_collective=args.rccl_world1,
-                                          overlap=not args.gather_serial)
+            direct = args.gather_direct
+            if direct == "auto":
+                direct = "side" if backend == "nccl" else "off"
+
+            depth = args.gather_depth if args.gather_depth > 0 else (16 if (backend == "nccl" and world > 1 and not args.gather_serial) else 2)
+
+            def make_gather(direct):
+                d = direct if direct != "off" else False
+                if args.gather_every > 1:
+                    return BlockRewardDoneGather(n, world, torch.device("cuda", local_rank), dist, block=args.gather_every,
+                                                 force_collective=args.rccl_world1, direct=d)
+                return RewardDoneGather(n, world, torch.device("cuda", local_rank), dist, force_collective=args.rccl_world1,
+                                        overlap=not args.gather_serial, direct=d, depth=depth)
+            ok = 1
+            try:
+                with stdout_to_stderr():
+                    gather = make_gather(direct)
+            except Exception as ex:      # (librccl.so not where torch keeps it, a symbol missing: the same on every rank)
+                sys.stderr.write("bench.py: rank %d: direct RCCL exchange unavailable (%s)\n" % (rank, ex))
+                ok = 0
+            t = torch.tensor([ok], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:       # all ranks together: the exchange goes through torch.distributed's wrapper instead
+                if args.gather_direct != "auto":
+                    return 5
+                direct = "off"
+                gather = make_gather(direct)
+            args.gather_direct = direct
 
     # BASELINE config 5: the gripper-cam depth render is bound to the step (kmanip_bind_step_depth): every kmanip_step call
     # ends by rendering the state it produced, on the same stream
@@ -663,7 +693,7 @@ def run_rank(args):
                        "envs_per_gpu": n, "depth_image": ("%dx%d float32 grip_r" % (args.depth, args.depth)) if args.depth else None,
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
-                       "collective": (("async all_gather of (reward, done) per step" if args.gather_every <= 1 else "async all_gather of (reward, done), %d steps per exchange" % args.gather_every) + ("" if not args.gather_serial else ", step waits for its own exchange")) if gather is not None else "none",
+                       "collective": (("async all_gather of (reward, done) per step" if args.gather_every <= 1 else "async all_gather of (reward, done), %d steps per exchange" % args.gather_every) + ("" if not args.gather_serial else ", step waits for its own exchange") + ("" if (args.gather_every > 1 or gather is None) else ", ring of %d records" % gather.depth) + ("" if args.gather_direct == "off" else ", ncclAllGather issued directly (%s)" % ("the step's stream" if args.gather_direct == "stream" else "side stream"))) if gather is not None else "none",
                        "rccl_ranks_seen": ranks_seen, "backend": backend if dist is not None else None, "library": version},
             "roofline": {"bound": "hbm", "bound_note": "the contract's two choices are hbm | mfma; this kernel is bound by FP64 VALU issue and dependent latency (see valu), its HBM fraction is small by construction",
                          "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)" + (" + k_render (in-step depth image)" if args.depth else (" + k_render_rgb (camera observations)" if rgb_bufs else "")), "achieved": achieved,
@@ -744,6 +774,8 @@ def run_rank(args):
         pass
     if dist is not None:
         dist.barrier()
+        if gather is not None:
+            gather.close()
         dist.destroy_process_group()
     return 0
 

@@ -145,6 +145,31 @@ def test_bound_record_is_not_overwritten_before_its_gather_completed():
     assert torch.equal(g.result((steps - 2) & 1)[0][:n], torch.arange(n, dtype=torch.float64) + 1000.0 * (steps - 2))
 
 
+@pytest.mark.parametrize("depth", [3, 8])
+def test_deeper_ring_lets_a_rank_run_ahead_but_never_past_its_own_records(depth):
+    """RewardDoneGather(depth=D): step k writes rec[k % D], which the exchange of step k - D read -- that one, and no later one,
+    has to be complete before the launch; D - 1 exchanges stay in flight (a rank may run that far ahead of a crawling peer)."""
+    import torch
+    n, world, steps = 5, 2, 3 * depth + 2
+    log = []
+    g = RewardDoneGather(n, world, torch.device("cpu"), _LazyDist(world, log), depth=depth)
+    eng = _BoundEngine(n, log)
+    g.bind(eng)
+    for k in range(steps):
+        b = g.before_step()
+        assert b == k % depth
+        eng.step()
+        assert g.post() == b
+        assert sum(w is not None for w in g.pending) == min(k + 1, depth)      # nothing was waited for early
+    writes = {e[2]: i for i, e in enumerate(log) if e[0] == "write"}
+    waits = {e[1]: i for i, e in enumerate(log) if e[0] == "wait"}
+    for j in range(steps - depth):
+        assert waits[j] < writes[j + depth], (j, log)                           # the invariant
+        assert waits[j] > writes[j + depth - 1], (j, log)                       # and not a step earlier than it must
+    for k in range(steps - depth, steps):                                       # the ring holds the last D steps
+        assert torch.equal(g.result(k % depth)[0], (torch.arange(n, dtype=torch.float64) + 1000.0 * k).repeat(world)), k
+
+
 def test_a_step_without_an_exchange_keeps_the_two_sides_in_phase():
     """the engine used to flip its own buffer parity on every step, so one evaluation step without a post() made
     every later post() gather the stale buffer.  The engine keeps no counter now: before_step() selects the buffer."""
@@ -200,3 +225,40 @@ def test_block_gather_two_ranks(tmp_path):
             k = blk * K + j
             assert np.array_equal(got["rew"][blk, j], np.arange(n_total) * 1000.0 + k)
             assert np.array_equal(got["done"][blk, j], np.array([(e + k) % 5 == 0 for e in range(n_total)], dtype=np.uint8))
+
+
+def _share_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from gym_kmanip_amd.dist import share_bytes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    raw = bytes((7 * i) % 256 if i % 5 else 0 for i in range(128))       # NUL bytes inside, like a real ncclUniqueId
+    got = share_bytes(raw if rank == 0 else None, 128, dist, torch)
+    with open(os.path.join(out_dir, "id%d.bin" % rank), "wb") as f:
+        f.write(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unique_id_bytes_reach_every_rank(tmp_path):
+    """dist.share_bytes: what carries rank 0's 128-byte ncclUniqueId to the other ranks before dist.RcclDirect's
+    ncclCommInitRank -- every rank ends up with rank 0's bytes, embedded NULs included."""
+    import torch.multiprocessing as mp
+    mp.spawn(_share_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    want = bytes((7 * i) % 256 if i % 5 else 0 for i in range(128))
+    for r in range(3):
+        assert open(os.path.join(str(tmp_path), "id%d.bin" % r), "rb").read() == want
+
+
+def test_direct_exchange_is_a_device_path_only():
+    """direct=... asks for RCCL on device records: without anything to exchange it is inert; on host records it refuses."""
+    import torch
+    from gym_kmanip_amd.dist import BlockRewardDoneGather, RewardDoneGather
+    g = RewardDoneGather(4, 1, "cpu", None, direct="side")
+    assert g.direct is None and g.side is None
+    g.post(torch.arange(4.0, dtype=torch.float64), torch.zeros(4, dtype=torch.float64))
+    assert torch.equal(g.result(0)[0], torch.arange(4.0, dtype=torch.float64))
+    for cls in (RewardDoneGather, BlockRewardDoneGather):
+        with pytest.raises(RuntimeError, match="device path"):
+            cls(4, 2, "cpu", None, direct="stream")

@@ -66,20 +66,24 @@ def test_two_ranks_match_one_rank_bitwise(tmp_path, env_id, total, steps):
     ref.k_close()
 
 
-@pytest.mark.parametrize("every", [1, 7])
-def test_rccl_device_collective_world1(tmp_path, every):
+@pytest.mark.parametrize("every,direct,depth", [(1, "off", 2), (7, "off", 2), (1, "stream", 2), (1, "side", 2), (7, "side", 2),
+                                                (1, "side", 16), (1, "off", 5)])
+def test_rccl_device_collective_world1(tmp_path, every, direct, depth):
     """RCCL executes: ONE rank, backend "nccl", on cuda:0, under the HSA_ENABLE_IPC_MODE_LEGACY=0 the ranks of an N > 1 job get.
     RewardDoneGather(force_collective=True) keeps the world == 1 short cut out of the way, so every step goes through
     before_step() (Work.wait() of the collective two steps back + record selection), the step launch that writes the packed
     record, and post() = all_gather_into_tensor(async_op=True) on the DEVICE buffers -- the code path of the multi-GPU job, which
     a gloo rehearsal (host staging, synchronous) never touches.  What the rank gathered must be what a plain run computes.
     every = 7: dist.BlockRewardDoneGather -- the engine's record re-bound to row j of a [7, n, 2] block every step, one
-    asynchronous all-gather per seven steps, two blocks in flight."""
+    asynchronous all-gather per seven steps, two blocks in flight.
+    direct = "stream" / "side": the same exchange as ncclAllGather through dist.RcclDirect (ctypes on torch's librccl.so, a
+    communicator of its own made from an ncclUniqueId) on the step's stream / on the gather's side stream with its two events.
+    depth > 2: the ring of record buffers that lets a rank run ahead of a crawling peer (the record is re-bound every step)."""
     import torch
     from gym_kmanip_amd import env_hip
     env_id, total, steps = "KManipSoloArm", 512, 70
     _run_ranks(str(tmp_path), 1, ["--env", env_id, "--total", str(total), "--steps", str(steps), "--backend", "nccl", "--force-collective",
-                                  "--gather-every", str(every)])
+                                  "--gather-every", str(every), "--direct", direct, "--depth", str(depth)])
     r = np.load(os.path.join(str(tmp_path), "rank0.npz"))
     assert str(r["backend"]) == "nccl" and str(r["ipc_legacy"]) == "0"
     ref = env_hip.make(env_id, num_envs=total, seed=9, env_id_offset=0)

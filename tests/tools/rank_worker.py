@@ -23,7 +23,11 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1, help="K > 1: dist.BlockRewardDoneGather, K steps per exchange")
     ap.add_argument("--force-collective", action="store_true",
                     help="issue the real all_gather_into_tensor(async_op=True) even at world_size 1 (dist.RewardDoneGather)")
+    ap.add_argument("--direct", choices=["off", "stream", "side"], default="off",
+                    help="ncclAllGather through dist.RcclDirect on the step's stream / on the gather's side stream")
+    ap.add_argument("--depth", type=int, default=2, help="dist.RewardDoneGather(depth=...): ring of record buffers")
     a = ap.parse_args()
+    direct = a.direct if a.direct != "off" else False
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -41,11 +45,12 @@ def main():
     K = a.gather_every
     if K > 1:
         assert a.steps % K == 0
-        g = BlockRewardDoneGather(n, world, torch.device("cuda", dev), dist, block=K, force_collective=a.force_collective)
+        g = BlockRewardDoneGather(n, world, torch.device("cuda", dev), dist, block=K, force_collective=a.force_collective, direct=direct)
     else:
-        g = RewardDoneGather(n, world, torch.device("cuda", dev), dist, force_collective=a.force_collective)
+        g = RewardDoneGather(n, world, torch.device("cuda", dev), dist, force_collective=a.force_collective, direct=direct, depth=a.depth)
     if a.force_collective:
         assert g.force_collective and not g.host_stage
+        assert (g.direct is not None) == bool(direct) and (g.side is not None) == (direct == "side")
     g.bind(env)                                                         # the step writes the packed record itself (as bench.py runs it)
     gen = torch.Generator(); gen.manual_seed(1234)                      # CPU generator: the same stream on every rank
     rew, done = [], []
@@ -70,12 +75,13 @@ def main():
         prev = b
     take(prev)
     if a.force_collective:             # evidence for the test: every step's exchange was a real asynchronous collective
-        assert g.pending == [None, None] and g.k == a.steps
+        assert all(w is None for w in g.pending) and g.k == a.steps
     st = env.get_state()
     np.savez(os.path.join(a.out, "rank%d.npz" % rank), rew=np.array(rew), done=np.array(done), obs=env.obs.cpu().numpy(),
              qpos=st[0], qvel=st[1], ctrl=st[2], lo=lo, hi=hi, backend=dist.get_backend(),
              ipc_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", ""))
     env.k_close()
+    g.close()
     dist.barrier()
     dist.destroy_process_group()
 

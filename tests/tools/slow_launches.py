@@ -32,6 +32,8 @@ for k in range(steps):
             slow_envs.setdefault(j, []).append(k)
 
 r = np.array(rows, dtype=np.float64)
+if os.environ.get("KM_LAUNCH_DUMP"):       # one launch time per line (ms), for tools/scaling_model.py
+    np.savetxt(os.environ["KM_LAUNCH_DUMP"], r[:, 0], fmt="%.4f", header="k_step launch times (ms), KManipSoloArm @ 4096 envs, bench.py's workload, ik_max_nfev %d" % cap)
 print("launch ms: mean %.3f  p50 %.3f  p90 %.3f  p99 %.3f  max %.3f" % (r[:, 0].mean(), *np.percentile(r[:, 0], [50, 90, 99]), r[:, 0].max()))
 print("  (end-of-step state) max IK nfev per launch: p50 %d p90 %d max %d; envs with a sphere-cube contact: mean %.1f" % (
     *np.percentile(r[:, 1], [50, 90]), r[:, 1].max(), r[:, 2].mean()))
