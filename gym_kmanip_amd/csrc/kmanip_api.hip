@@ -85,6 +85,9 @@ static int validate(const KModelDesc* d, std::string& err) {
   for (int s = 0; s < d->nsphere; s++)
     if (d->sphere_link[s] < 0 || d->sphere_link[s] >= d->nlink || !(d->sphere_radius[s] > 0)) { err = "collision sphere on a missing link or with radius <= 0"; return -1; }
   if (d->obs_dim != 2 * d->nlink + 7) { err = "obs_dim != 2*nlink+7"; return -1; }
+  // (+-INFINITY is the infinite plane; a NaN bound would pass the depth renderer's min-chain rectangle test)
+  if (std::isnan(d->table_rect[0]) || std::isnan(d->table_rect[1]) || std::isnan(d->table_rect[2]) || std::isnan(d->table_rect[3]) ||
+      !(d->table_rect[0] <= d->table_rect[1]) || !(d->table_rect[2] <= d->table_rect[3])) { err = "table_rect must be x_lo <= x_hi, y_lo <= y_hi (no NaN; +-INFINITY = infinite plane)"; return -1; }
   if (d->n_sub_steps < 1 || d->solver_iterations < 0) { err = "bad n_sub_steps / solver_iterations"; return -1; }
   for (const double* si : {d->con_def_solimp, d->con_cube_solimp}) {
     const double power = si[4] < 1 ? 1 : si[4];

@@ -300,43 +300,61 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
   const int dr = blockDim.x / width, dc = blockDim.x - dr * width;
   // Round 5: when the workgroup's stride is a whole number of image rows (64-wide images: 128 lanes = two rows) a lane keeps its
   // COLUMN for the whole loop, so everything that is linear in the pixel coordinates has a per-lane constant part -- the ray
-  // direction in the world and in the cube frame cost one FMA per component and pixel instead of two or three
+  // direction in the world and in the cube frame cost one FMA per component and pixel instead of two or three.
+  // The loop is bound by the NUMBER of float64 instructions a pixel issues (a wave is one image row; 85 VALU instructions for a
+  // pixel that sees the table only, ISA count): what a ray rarely needs is computed where it is needed -- the direction in the
+  // cube frame and the slab reciprocals behind the bounding-sphere test (itself in the world frame: a rotation changes neither
+  // dot product), 1 / |d|^2 behind a sphere hit -- the table's rectangle test is one min-chain instead of four compare-and-
+  // combine pairs, reciprocals take one Newton step (v_rcp_f64 is good to 2^-23: one step gives 2^-46, the depth bar is 1e-6 m),
+  // and the final clamp is one v_med3_f32 after the conversion (rounding is monotonic: the same float as clamping first).
   constexpr bool colfixed = COLFIXED;
   const real dxl = (c + 0.5 - hw) * inv_f;
   real ex[3], bx[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) { ex[a] = X[a] * dxl - Z[a]; bx[a] = DX[a] * dxl - DZ[a]; }
+  const real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]};   // (|rel| = |ol|)
+  const float znf = (float)znear, zff = (float)zfar;
+  const real row0 = hh - 0.5;                            // dy = (row0 - r) / f, r counted in float64 (exact)
+  real rd = (real)r;
+  const real drd = (real)dr;
+  auto rcp1 = [](real x) { real q = __builtin_amdgcn_rcp(x); return q + q * (1.0 - x * q); };
+  // sqrt(x), x >= 0, to 2^-46: v_rsq_f64 (2^-23) and one coupled step (g ~ sqrt x, h ~ 1 / (2 sqrt x): g += g (1/2 - g h))
+  auto sqrt1 = [](real x) { const real y = __builtin_amdgcn_rsq(fmax(x, 1e-300)); const real g = x * y, h = 0.5 * y; return g + g * (0.5 - g * h); };
   for (int p = threadIdx.x; p < npix; p += blockDim.x) {
-    const real dx = colfixed ? dxl : (c + 0.5 - hw) * inv_f, dy = -(r + 0.5 - hh) * inv_f;
-    c += dc; r += dr;
-    if (c >= width) { c -= width; r++; }
-    real d0, d1, d2, dl0, dl1, dl2;
-    if constexpr (colfixed) {
-      d0 = __builtin_fma(Y[0], dy, ex[0]); d1 = __builtin_fma(Y[1], dy, ex[1]); d2 = __builtin_fma(Y[2], dy, ex[2]);
-      dl0 = __builtin_fma(DY[0], dy, bx[0]); dl1 = __builtin_fma(DY[1], dy, bx[1]); dl2 = __builtin_fma(DY[2], dy, bx[2]);
-    } else {
-      d0 = X[0] * dx + Y[0] * dy - Z[0]; d1 = X[1] * dx + Y[1] * dy - Z[1]; d2 = X[2] * dx + Y[2] * dy - Z[2];
-      dl0 = DX[0] * dx + DY[0] * dy - DZ[0]; dl1 = DX[1] * dx + DY[1] * dy - DZ[1]; dl2 = DX[2] * dx + DY[2] * dy - DZ[2];
+    real dx, dy;
+    if constexpr (colfixed) { dx = dxl; dy = (row0 - rd) * inv_f; rd += drd; }
+    else {
+      dx = (c + 0.5 - hw) * inv_f; dy = -(r + 0.5 - hh) * inv_f;
+      c += dc; r += dr;
+      if (c >= width) { c -= width; r++; }
     }
+    real d0, d1, d2;
+    if constexpr (colfixed) { d0 = __builtin_fma(Y[0], dy, ex[0]); d1 = __builtin_fma(Y[1], dy, ex[1]); d2 = __builtin_fma(Y[2], dy, ex[2]); }
+    else { d0 = X[0] * dx + Y[0] * dy - Z[0]; d1 = X[1] * dx + Y[1] * dy - Z[1]; d2 = X[2] * dx + Y[2] * dy - Z[2]; }
+    // table top: the rectangle table_rect at z = table_z.  d2 == 0 makes t infinite or NaN, which fails `t > 0 && t < zfar`; the
+    // min-chain is then never looked at (table_rect holds no NaN: kmanip_create checks)
     real best = zfar;
-    // table top: the rectangle table_rect at z = table_z
-    if (d2 != 0) {
-      const real t = k0 * frcp(d2);
-      const real hx = ox + t * d0, hy = oy + t * d1;
-      if (t > 0 && t < best && hx >= rx0 && hx <= rx1 && hy >= ry0 && hy <= ry1) best = t;
+    {
+      const real t = k0 * rcp1(d2);
+      const real hx = __builtin_fma(t, d0, ox), hy = __builtin_fma(t, d1, oy);
+      const real in = fmin(fmin(hx - rx0, rx1 - hx), fmin(hy - ry0, ry1 - hy));
+      if (t > 0 && t < zfar && in >= 0) best = t;
     }
     // cube box: slab test in the cube frame -- only for rays that meet the box's bounding sphere (six operations decide it; a
     // wave is one image row or two, so the test is coherent)
     const real a2 = d0 * d0 + d1 * d1 + d2 * d2;
-    const real bc = dl0 * ol[0] + dl1 * ol[1] + dl2 * ol[2];       // (ray direction in the cube frame) . (origin in the cube frame)
+    const real bc = d0 * rel[0] + d1 * rel[1] + d2 * rel[2];
     if (bc * bc - a2 * cube_cc >= 0) {
+      real dlv[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) dlv[a] = colfixed ? __builtin_fma(DY[a], dy, bx[a]) : DX[a] * dx + DY[a] * dy - DZ[a];
       real t0 = -INFINITY, t1 = INFINITY;
       bool ok = true;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const real dl = a == 0 ? dl0 : (a == 1 ? dl1 : dl2);
+        const real dl = dlv[a];
         if (dl != 0) {
-          const real inv = frcp(dl);
+          const real inv = rcp1(dl);
           const real ta = (-hf[a] - ol[a]) * inv, tb = (hf[a] - ol[a]) * inv;
           t0 = fmax(t0, fmin(ta, tb)); t1 = fmin(t1, fmax(ta, tb));
         } else if (ol[a] < -hf[a] || ol[a] > hf[a]) ok = false;
@@ -346,19 +364,21 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
         if (t < best) best = t;
       }
     }
-    // the visible spheres (finger tips)
+    // the visible spheres (finger tips): from the gripper camera they fill most of the image, so nearly every wave (one image
+    // row) takes the hit path of every sphere -- 1 / |d|^2 once per pixel, a one-step square root
+    const real ia2 = rcp1(a2);
 #pragma unroll
     for (int s = 0; s < KM_RENDER_MAXVIS; s++) {
       if (s < nvis) {
         const real b = d0 * soc[s][0] + d1 * soc[s][1] + d2 * soc[s][2], disc = b * b - a2 * scc[s];
         if (disc >= 0) {
           // nearest root; compared before the division: t < best  <=>  -b - sqrt(disc) < best * a2  (a2 > 0)
-          const real num = -b - km_sqrt(disc);
-          if (num > 0 && num < best * a2) best = num * frcp(a2);
+          const real num = -b - sqrt1(disc);
+          if (num > 0 && num < best * a2) best = num * ia2;
         }
       }
     }
-    out[p] = (float)fmin(fmax(best, znear), zfar);
+    out[p] = __builtin_amdgcn_fmed3f((float)best, znf, zff);
   }
 }
 

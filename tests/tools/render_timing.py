@@ -27,3 +27,10 @@ for h, w in ((64, 64), (8, 8)):
 bufs = e.render_cameras()
 ms = t(lambda: e.render_cameras(out=bufs))
 print("rgb   all cameras of the observation (%s) in one launch  %.4f ms  %.2f TB/s" % ("+".join(bufs), ms, sum(b.numel() for b in bufs.values()) / ms / 1e9))
+# the ceiling for a write-only stream on this box: a plain fill of the same number of bytes (torch's fill kernel, dword stores)
+big = torch.empty(sum(b.numel() for b in bufs.values()) // 4, dtype=torch.int32, device="cuda")
+ms = t(lambda: big.fill_(7))
+print("fill  %d MB with one value (torch fill_)  %.4f ms  %.2f TB/s" % (big.numel() * 4 // 2**20, ms, big.numel() * 4 / ms / 1e9))
+src = torch.empty_like(big)
+ms = t(lambda: big.copy_(src))
+print("copy  the same bytes device to device (read + write)  %.4f ms  %.2f TB/s written, %.2f TB/s moved" % (ms, big.numel() * 4 / ms / 1e9, 2 * big.numel() * 4 / ms / 1e9))
