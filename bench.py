@@ -506,8 +506,26 @@ def measure_config(torch, env_id, n, local_rank, steps, warmup, depth=0, solver=
     bpe = algorithmic_bytes_per_env_step(cm, depth, rgb=bool(rgb_bufs))
     kern_s = (dyn_ms + rnd_ms) / max(nt, 1) * 1e-3
     achieved = bpe * n / kern_s / 1e9
+    behind = None
+    if rgb_bufs:
+        # the same steps with the cameras rendered BEHIND them (pipeline.RenderBehind: qpos snapshot + a second stream) -- the
+        # shape of a data-generation loop whose policy acts on the state and logs the images.  Not the line above: there every
+        # step's images exist before the next step starts.
+        from gym_kmanip_amd.pipeline import RenderBehind
+        rb = RenderBehind(env)
+        w.lay_out(warmup + steps)
+        for _ in range(warmup):
+            w.step(); rb.after_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step(); rb.after_step()
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        behind = {"what": "the same steps, every step's cameras rendered from a qpos snapshot on a second stream while the next step runs (pipeline.RenderBehind)",
+                  "value": n * steps / dtb, "unit": "env steps/s", "steps": steps, "ms_per_step": dtb / steps * 1e3}
     w.close()
-    return {"workload": "%s, %d envs, 1 GPU%s, desynchronised" % (env_id, n, (", %dx%d float32 grip_r depth in the step" % (depth, depth)) if depth else
+    return {**({"render_behind": behind} if behind else {}), "workload": "%s, %d envs, 1 GPU%s, desynchronised" % (env_id, n, (", %dx%d float32 grip_r depth in the step" % (depth, depth)) if depth else
                                                                  ((", uint8 RGB cameras %s after the step" % "+".join(cm.cameras)) if rgb_bufs else "")),
             "value": n * steps / dt, "unit": "env steps/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

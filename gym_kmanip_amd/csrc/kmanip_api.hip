@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.18 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.19 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -31,6 +31,8 @@ struct KHandle_ {
   double* rd_rec[2] = {nullptr, nullptr};   // kmanip_bind_reward_done_record: the two record buffers
   int rd_sel = 0;                           // kmanip_select_reward_done_record: the one the next kmanip_step fills
   int timed_steps = 0;
+  double* qpos_snap[2] = {nullptr, nullptr};   // kmanip_snapshot_render_state: copies of qpos the renders can read instead of the live state
+  int render_src = -1;                         // kmanip_set_render_source: -1 = live state, 0 / 1 = that snapshot
   bool last_step_timed = false; // the last kmanip_step recorded its events (the ring was not full): a render that follows may add its leg
   // render target bound to the step (BASELINE config 5: "depth render in the step"): kmanip_step then also renders
   int step_cam = -1, step_h = 0, step_w = 0;
@@ -406,8 +408,33 @@ int kmanip_render_depth(KHandle h, int cam, int height, int width, float* depth_
   if (!h || !depth_dev || cam < 0 || cam >= KM_MAX_CAMS || height <= 0 || width <= 0) { if (h) h->err = "kmanip_render_depth: bad arguments"; return -1; }
   if (!h->desc.cam_present[cam]) { h->err = "kmanip_render_depth: this model has no such camera"; return -1; }
   KM_ENTER(h);
-  kmanip_launch_render_depth(h->dmodel, h->st, cam, height, width, depth_dev, (hipStream_t)stream);
+  KDeviceState st = h->st;
+  if (h->render_src >= 0) st.qpos = h->qpos_snap[h->render_src];
+  kmanip_launch_render_depth(h->dmodel, st, cam, height, width, depth_dev, (hipStream_t)stream);
   HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int kmanip_snapshot_render_state(KHandle h, int slot, void* stream) {
+  if (!h) { g_create_error = "kmanip_snapshot_render_state: null handle"; return -1; }
+  if (slot < 0 || slot > 1) { h->err = "kmanip_snapshot_render_state: slot must be 0 or 1"; return -1; }
+  KM_ENTER(h);
+  const size_t bytes = sizeof(double) * (size_t)(h->desc.nlink + 7) * h->num_envs;
+  if (!h->qpos_snap[slot]) {
+    void* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    h->qpos_snap[slot] = (double*)p;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->qpos_snap[slot], h->st.qpos, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int kmanip_set_render_source(KHandle h, int slot) {
+  if (!h) { g_create_error = "kmanip_set_render_source: null handle"; return -1; }
+  if (slot < -1 || slot > 1) { h->err = "kmanip_set_render_source: slot must be -1 (live state), 0 or 1"; return -1; }
+  if (slot >= 0 && !h->qpos_snap[slot]) { h->err = "kmanip_set_render_source: no snapshot was taken into that slot"; return -1; }
+  h->render_src = slot;
   return 0;
 }
 
@@ -423,10 +450,13 @@ int kmanip_render_rgb_multi(KHandle h, int ncam, const int* cams, const int* hei
     jobs.cam[i] = cams[i]; jobs.height[i] = heights[i]; jobs.width[i] = widths[i]; jobs.rgb[i] = rgb_dev[i];
   }
   KM_ENTER(h);
-  kmanip_launch_render_rgb(h->dmodel, h->st, jobs, (hipStream_t)stream);
+  KDeviceState st = h->st;
+  if (h->render_src >= 0) st.qpos = h->qpos_snap[h->render_src];
+  kmanip_launch_render_rgb(h->dmodel, st, jobs, (hipStream_t)stream);
   // kernel timing (kmanip_enable_timing): the camera observations rendered right after a timed step are that step's render leg --
   // its start is the event the step recorded after k_step, so the render costs the stream ONE more event, not a pair around it
-  if (h->timing && h->last_step_timed && h->timed_steps > 0 && !h->ev_render[h->timed_steps - 1]) {
+  // (a render of a SNAPSHOT runs behind the steps, on a stream of its own: it is no leg of the step's stream)
+  if (h->timing && h->render_src < 0 && h->last_step_timed && h->timed_steps > 0 && !h->ev_render[h->timed_steps - 1]) {
     HIPCHK(h, hipEventRecord(h->ev[4 * (size_t)(h->timed_steps - 1) + 3], (hipStream_t)stream));
     h->ev_render[h->timed_steps - 1] = 1;
   }

@@ -269,6 +269,15 @@ class KManipEnvHip:
         self._check(self.L.kmanip_render_rgb_multi(self.h, n, ci, hh, ww, pp, self._stream()), "kmanip_render_rgb_multi")
         return bufs
 
+    def snapshot_render_state(self, slot: int):
+        """Copy qpos -- all a render reads of the state -- into snapshot `slot` (0 / 1) on the current stream
+        (kmanip_snapshot_render_state); `set_render_source(slot)` then points the render_* calls at it."""
+        self._check(self.L.kmanip_snapshot_render_state(self.h, int(slot), self._stream()), "kmanip_snapshot_render_state")
+
+    def set_render_source(self, slot: int = -1):
+        """-1: the render_* calls read the live state (default); 0 / 1: that snapshot (pipeline.RenderBehind)."""
+        self._check(self.L.kmanip_set_render_source(self.h, int(slot)), "kmanip_set_render_source")
+
     def bind_step_depth(self, cam="grip_r", height: int = 64, width: int = 64, out=None):
         """BASELINE config 5: every step_flat / k_step from now on also renders `cam` into the returned buffer
         (float32 [num_envs, height, width]), in the same C call.  bind_step_depth(None) unbinds."""

@@ -20,7 +20,7 @@ _lib = None
 EXPORTS = [
     "kmanip_model_desc_size", "kmanip_create", "kmanip_reset", "kmanip_step", "kmanip_step_chunk", "kmanip_get_state",
     "kmanip_set_state", "kmanip_get_episode", "kmanip_set_episode", "kmanip_get_counters", "kmanip_bind_sim_time", "kmanip_bind_reward_done_record", "kmanip_select_reward_done_record", "kmanip_observe", "kmanip_set_seed", "kmanip_get_diag", "kmanip_timing_summary", "kmanip_enable_timing", "kmanip_ik", "kmanip_ik_eval",
-    "kmanip_render_depth", "kmanip_render_rgb", "kmanip_render_rgb_multi", "kmanip_bind_step_depth", "kmanip_scripted_action", "kmanip_sample_action", "kmanip_num_envs", "kmanip_last_error", "kmanip_version", "kmanip_destroy",
+    "kmanip_render_depth", "kmanip_render_rgb", "kmanip_render_rgb_multi", "kmanip_snapshot_render_state", "kmanip_set_render_source", "kmanip_bind_step_depth", "kmanip_scripted_action", "kmanip_sample_action", "kmanip_num_envs", "kmanip_last_error", "kmanip_version", "kmanip_destroy",
 ]
 
 
@@ -81,6 +81,8 @@ def load():
     lib.kmanip_render_depth.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.kmanip_render_rgb.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.kmanip_render_rgb_multi.argtypes = [vp, C.c_int, i32p, i32p, i32p, C.POINTER(vp), vp]
+    lib.kmanip_snapshot_render_state.argtypes = [vp, C.c_int, vp]
+    lib.kmanip_set_render_source.argtypes = [vp, C.c_int]
     lib.kmanip_bind_step_depth.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.kmanip_scripted_action.argtypes = [vp, vp, vp]
     lib.kmanip_sample_action.argtypes = [vp, vp, C.c_int, vp]

@@ -119,3 +119,64 @@ class InterleavedBatches:
             # sim_time = steps since the env's last reset x control_timestep (kmanip_bind_sim_time), from the restored counters
             e.sim_time.copy_(torch.from_numpy(c[4].astype("float64") * (self.cm.desc.n_sub_steps * self.cm.desc.timestep)))
         torch.cuda.synchronize(self.device)
+
+
+class RenderBehind:
+    """Camera images rendered BEHIND the steps, on a stream of their own (include/kmanip.h: kmanip_snapshot_render_state).
+
+    For a loop whose policy does not look at the images -- the reference's scripted data generation (examples/2_synthetic_data.py:
+    28-41 acts on the state and LOGS the cameras) or an open-loop action chunk.  After step k the step's stream copies qpos (all a
+    render reads) into snapshot k & 1; the render stream waits for that copy and renders the snapshot into image set k & 1 while
+    step k + 1 already runs: one 2048-env single-arm step is 1024 single-wave workgroups that end between 0.45 and 1.0 of the launch,
+    and the render's workgroups take the SIMDs they free.  KManipSoloArmVision @ 2048 envs: 0.96 ms per step in sequence, 0.67 ms
+    this way (profiles/r05_render_behind.txt).  The images of step k are those a render right after step k would have produced,
+    bit for bit (tests/test_check_env_gpu.py).
+
+        rb = RenderBehind(env)                       # env: KManipEnvHip of a *Vision id
+        for t in range(T):
+            env.step_flat(policy_from_state(env.obs))
+            rb.after_step()                          # snapshot + render of step t, behind
+            if t: log(rb.images(t - 1))              # dict name -> uint8 [n, h, w, 3]; current stream ordered after that render
+    """
+
+    def __init__(self, env, cams=None):
+        torch = _torch()
+        self.torch, self.env, self.cams = torch, env, cams
+        self.k = 0
+        self.stream = torch.cuda.Stream(device=env.device)
+        self.bufs = [env.render_cameras(cams), env.render_cameras(cams)]          # two image sets (allocated by a first render each)
+        self.copied = [torch.cuda.Event() for _ in range(2)]
+        self.rendered = [torch.cuda.Event() for _ in range(2)]
+        self._used = [False, False]
+
+    def after_step(self):
+        """Call right after the step whose images are wanted, on the step's stream.  Returns the step's index."""
+        torch, env = self.torch, self.env
+        s = self.k & 1
+        cur = torch.cuda.current_stream(env.device)
+        if self._used[s]:
+            cur.wait_event(self.rendered[s])          # the render of step k - 2 read snapshot s: it must be done before the copy
+        env.snapshot_render_state(s)
+        self.copied[s].record(cur)
+        self.stream.wait_event(self.copied[s])
+        env.set_render_source(s)
+        try:
+            with torch.cuda.stream(self.stream):
+                env.render_cameras(self.cams, out=self.bufs[s])
+        finally:
+            env.set_render_source(-1)
+        self.rendered[s].record(self.stream)
+        self._used[s] = True
+        self.k += 1
+        return self.k - 1
+
+    def images(self, step: int):
+        """Image set of `step` (one of the last two after_step calls); the current stream waits for its render."""
+        if not (self.k - 2 <= step < self.k) or step < 0:
+            raise ValueError("RenderBehind keeps the images of the last two steps (asked for %d, at %d)" % (step, self.k))
+        s = step & 1
+        self.torch.cuda.current_stream(self.env.device).wait_event(self.rendered[s])
+        return self.bufs[s]
+
+    def synchronize(self):
+        self.stream.synchronize()

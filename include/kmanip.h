@@ -335,6 +335,18 @@ KMANIP_API int kmanip_render_rgb(KHandle h, int cam, int height, int width, uint
 KMANIP_API int kmanip_render_rgb_multi(KHandle h, int ncam, const int* cams, const int* heights, const int* widths, uint8_t* const* rgb_dev,
                             void* stream);
 
+/* Rendering BEHIND the steps (a data-generation loop whose policy does not look at the images: the reference's scripted heuristic,
+ * examples/2_synthetic_data.py:28-41, logs them and acts on the state).  A render reads nothing of the state but qpos:
+ * kmanip_snapshot_render_state copies qpos into snapshot `slot` (0 or 1) on `stream` -- the step's stream, after the step whose
+ * images are wanted -- and kmanip_set_render_source(h, slot) makes the kmanip_render_* calls that follow read that copy
+ * (-1: the live state again, the default; host-side switch, not stream-ordered).  The caller can then issue the render on a
+ * SECOND stream while the next kmanip_step runs on the first: the render's workgroups take the SIMDs the step's early-finishing
+ * waves free (one 2048-env step + head and grip images: 0.96 ms in sequence, 0.67 ms this way; gym_kmanip_amd/pipeline.py
+ * RenderBehind).  Ordering is the caller's: the render stream waits for the copy (an event), and a slot is not overwritten before
+ * the render that reads it has finished.  kmanip_bind_step_depth's in-step render always reads the live state. */
+KMANIP_API int kmanip_snapshot_render_state(KHandle h, int slot, void* stream);
+KMANIP_API int kmanip_set_render_source(KHandle h, int slot);
+
 /* BASELINE config 5 ("64x64 gripper-cam depth render in the step"): bind a caller-owned device buffer
  * float[num_envs, height, width]; every kmanip_step then ends by rendering camera `cam` of the state it produced into it,
  * on the step's stream (one C call per control step).  depth_dev == NULL unbinds. */

@@ -288,3 +288,48 @@ def test_all_cameras_in_one_launch_equal_the_single_renders():
         for cam, img in multi.items():
             assert torch.equal(img, e.render_rgb(cam)), (env_id, cam)
         e.k_close()
+
+
+def test_render_behind_gives_the_images_of_its_step():
+    """pipeline.RenderBehind (kmanip_snapshot_render_state / kmanip_set_render_source): the images rendered on the second stream
+    while the next step already runs are, bit for bit, those a render right after their own step produces -- RGB of every camera
+    and the depth image; the live state is what the renders read again afterwards."""
+    import torch
+    from gym_kmanip_amd import env_hip
+    from gym_kmanip_amd.pipeline import RenderBehind
+    n, steps = 96, 9
+    a = env_hip.make("KManipSoloArmVision", num_envs=n, seed=5)
+    b = env_hip.make("KManipSoloArmVision", num_envs=n, seed=5)
+    a.k_reset(); b.k_reset()
+    acts = [a.sample_action(ahead=k).clone() for k in range(steps)]
+    rb = RenderBehind(a)
+    want = []
+    for k in range(steps):
+        b.step_flat(acts[k])
+        want.append({c: img.clone() for c, img in b.render_cameras().items()})
+    got = []
+    for k in range(steps):
+        a.step_flat(acts[k])
+        assert rb.after_step() == k
+        if k:
+            got.append({c: img.clone() for c, img in rb.images(k - 1).items()})      # (while step k's render is in flight)
+    got.append({c: img.clone() for c, img in rb.images(steps - 1).items()})
+    torch.cuda.synchronize()
+    assert any(not torch.equal(want[0][c], want[steps - 1][c]) for c in want[0])     # the scene moved: a stale snapshot would show
+    for k in range(steps):
+        for c in want[k]:
+            assert torch.equal(got[k][c], want[k][c]), (k, c)
+    with pytest.raises(ValueError):
+        rb.images(steps - 3)
+    # depth through a snapshot, and back to the live state
+    d_live = a.render_depth("grip_r", 64, 64).clone()
+    a.snapshot_render_state(0)
+    a.step_flat(acts[0]); b.step_flat(acts[0])
+    a.set_render_source(0)
+    assert torch.equal(a.render_depth("grip_r", 64, 64), d_live)
+    a.set_render_source(-1)
+    assert torch.equal(a.render_depth("grip_r", 64, 64), b.render_depth("grip_r", 64, 64))
+    assert not torch.equal(a.render_depth("grip_r", 64, 64), d_live)
+    with pytest.raises(RuntimeError):
+        b.set_render_source(1)                  # no snapshot was ever taken on b
+    a.k_close(); b.k_close()

@@ -88,16 +88,19 @@ fi
 ls $OUT
 if has rccl; then
   # the N > 1 job's device-collective path as a one-rank RCCL job on this GPU
-  for v in "plain:" "rccl_overlap:--rccl-world1" "rccl_serial:--rccl-world1 --gather-serial" "rccl_one_channel:--rccl-world1 --rccl-one-channel" "rccl_every8:--rccl-world1 --gather-every 8" "rccl_every64:--rccl-world1 --gather-every 64"; do
+  for v in "plain:" "rccl_wrapper:--rccl-world1 --gather-direct off" "rccl_wrapper_serial:--rccl-world1 --gather-direct off --gather-serial" "rccl_wrapper_one_channel:--rccl-world1 --gather-direct off --rccl-one-channel" "rccl_direct_stream:--rccl-world1 --gather-direct stream" "rccl_direct_side:--rccl-world1" "rccl_direct_side_ring16:--rccl-world1 --gather-depth 16" "rccl_every8:--rccl-world1 --gather-every 8" "rccl_every64:--rccl-world1 --gather-every 64"; do
     tag=${v%%:*}; fl=${v#*:}
     python3 bench.py $fl --no-variants --no-cpu-baseline > $OUT/rccl_$tag.json 2> $OUT/rccl_$tag.err
   done
   python3 - <<PY > $OUT/rccl_world1.txt
 import json
-print("KManipSoloArm @ 4096 envs, 1024 timed launches, python bench.py <flags> --no-variants --no-cpu-baseline")
-for t, fl in (("plain", "(no process group)"), ("rccl_overlap", "--rccl-world1"), ("rccl_serial", "--rccl-world1 --gather-serial"), ("rccl_one_channel", "--rccl-world1 --rccl-one-channel"), ("rccl_every8", "--rccl-world1 --gather-every 8"), ("rccl_every64", "--rccl-world1 --gather-every 64")):
+print("KManipSoloArm @ 4096 envs, 1024 timed launches, python bench.py <flags> --no-variants --no-cpu-baseline   (--gather-direct auto = side on RCCL)")
+for t, fl in (("plain", "(no process group)"), ("rccl_wrapper", "--rccl-world1 --gather-direct off"), ("rccl_wrapper_serial", "--rccl-world1 --gather-direct off --gather-serial"),
+              ("rccl_wrapper_one_channel", "--rccl-world1 --gather-direct off --rccl-one-channel"), ("rccl_direct_stream", "--rccl-world1 --gather-direct stream"),
+              ("rccl_direct_side", "--rccl-world1"), ("rccl_direct_side_ring16", "--rccl-world1 --gather-depth 16"),
+              ("rccl_every8", "--rccl-world1 --gather-every 8"), ("rccl_every64", "--rccl-world1 --gather-every 64")):
     d = json.loads(open("$OUT/rccl_%s.json" % t).read().strip().split("\n")[-1])
-    print("%-40s value %.4g env steps/s  ms/step %.4f  k_step %.4f ms  gap between launches %.4f ms" % (fl, d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_avg"]["k_step"], d["roofline"]["kernel_ms_avg"]["launch_gap"]))
+    print("%-52s value %.4g env steps/s  ms/step %.4f  k_step %.4f ms  gap between launches %.4f ms" % (fl, d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_avg"]["k_step"], d["roofline"]["kernel_ms_avg"]["launch_gap"]))
 PY
   echo "rccl done"
 fi
