@@ -507,12 +507,14 @@ def measure_config(torch, env_id, n, local_rank, steps, warmup, depth=0, solver=
     kern_s = (dyn_ms + rnd_ms) / max(nt, 1) * 1e-3
     achieved = bpe * n / kern_s / 1e9
     behind = None
-    if rgb_bufs:
+    if rgb_bufs or depth:
         # the same steps with the cameras rendered BEHIND them (pipeline.RenderBehind: qpos snapshot + a second stream) -- the
         # shape of a data-generation loop whose policy acts on the state and logs the images.  Not the line above: there every
         # step's images exist before the next step starts.
         from gym_kmanip_amd.pipeline import RenderBehind
-        rb = RenderBehind(env)
+        if depth:
+            env.bind_step_depth(None)                 # (the in-step render of the line above is unbound: the image is rendered behind instead)
+        rb = RenderBehind(env, cams=None if rgb_bufs else [], depth=("grip_r", depth, depth) if depth else None)
         w.lay_out(warmup + steps)
         for _ in range(warmup):
             w.step(); rb.after_step()
@@ -522,7 +524,7 @@ def measure_config(torch, env_id, n, local_rank, steps, warmup, depth=0, solver=
             w.step(); rb.after_step()
         torch.cuda.synchronize()
         dtb = time.perf_counter() - t0
-        behind = {"what": "the same steps, every step's cameras rendered from a qpos snapshot on a second stream while the next step runs (pipeline.RenderBehind)",
+        behind = {"what": "the same steps, every step's %s rendered from a qpos snapshot on a second stream while the next step runs (pipeline.RenderBehind)" % ("cameras" if rgb_bufs else "depth image"),
                   "value": n * steps / dtb, "unit": "env steps/s", "steps": steps, "ms_per_step": dtb / steps * 1e3}
     w.close()
     return {**({"render_behind": behind} if behind else {}), "workload": "%s, %d envs, 1 GPU%s, desynchronised" % (env_id, n, (", %dx%d float32 grip_r depth in the step" % (depth, depth)) if depth else

@@ -139,15 +139,24 @@ class RenderBehind:
             if t: log(rb.images(t - 1))              # dict name -> uint8 [n, h, w, 3]; current stream ordered after that render
     """
 
-    def __init__(self, env, cams=None):
+    def __init__(self, env, cams=None, depth=None):
+        """cams: RGB cameras (default: the env id's camera observations; [] for none).  depth: (camera, height, width) of a float32
+        depth image rendered with them (BASELINE config 5's 64 x 64 gripper image), under the key "depth"."""
         torch = _torch()
-        self.torch, self.env, self.cams = torch, env, cams
+        self.torch, self.env, self.cams, self.depth = torch, env, cams, depth
         self.k = 0
         self.stream = torch.cuda.Stream(device=env.device)
-        self.bufs = [env.render_cameras(cams), env.render_cameras(cams)]          # two image sets (allocated by a first render each)
+        self.bufs = [self._render(None), self._render(None)]                      # two image sets (allocated by a first render each)
         self.copied = [torch.cuda.Event() for _ in range(2)]
         self.rendered = [torch.cuda.Event() for _ in range(2)]
         self._used = [False, False]
+
+    def _render(self, out):
+        bufs = dict(self.env.render_cameras(self.cams, out=out)) if (self.cams is None or len(self.cams)) else {}
+        if self.depth is not None:
+            cam, h, w = self.depth
+            bufs["depth"] = self.env.render_depth(cam, h, w, out=None if out is None else out["depth"])
+        return bufs
 
     def after_step(self):
         """Call right after the step whose images are wanted, on the step's stream.  Returns the step's index."""
@@ -162,7 +171,7 @@ class RenderBehind:
         env.set_render_source(s)
         try:
             with torch.cuda.stream(self.stream):
-                env.render_cameras(self.cams, out=self.bufs[s])
+                self._render(self.bufs[s])
         finally:
             env.set_render_source(-1)
         self.rendered[s].record(self.stream)

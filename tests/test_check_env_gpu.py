@@ -302,11 +302,12 @@ def test_render_behind_gives_the_images_of_its_step():
     b = env_hip.make("KManipSoloArmVision", num_envs=n, seed=5)
     a.k_reset(); b.k_reset()
     acts = [a.sample_action(ahead=k).clone() for k in range(steps)]
-    rb = RenderBehind(a)
+    rb = RenderBehind(a, depth=("grip_r", 64, 64))
     want = []
     for k in range(steps):
         b.step_flat(acts[k])
         want.append({c: img.clone() for c, img in b.render_cameras().items()})
+        want[-1]["depth"] = b.render_depth("grip_r", 64, 64).clone()
     got = []
     for k in range(steps):
         a.step_flat(acts[k])
