@@ -138,6 +138,7 @@ class EpisodeLogger:
         self.qvel = torch.zeros((T, num_envs, q_len), dtype=torch.float32, device=device)
         self.action = torch.zeros((T, num_envs, self.log_a_len), dtype=torch.float32, device=device)
         self.cams = {}                 # name -> (Cam, ring uint8 [T, len(env_ids), h, w, c])
+        self._frames_due = set()       # rows logged with images_later=True whose frames have not arrived
         self._sel = torch.as_tensor(self.env_ids, dtype=torch.long, device=device)
         self.t = 0
         self.episode = 0
@@ -150,9 +151,11 @@ class EpisodeLogger:
         ring = torch.zeros((MAX_EPISODE_STEPS, len(self.env_ids), cam.h, cam.w, cam.c), dtype=torch.uint8, device=self.device)
         self.cams[cam.name] = (cam, ring)
 
-    def step(self, act_flat, obs_q_pos, obs_q_vel, images: Optional[Dict[str, Any]] = None) -> None:
+    def step(self, act_flat, obs_q_pos, obs_q_vel, images: Optional[Dict[str, Any]] = None, images_later: bool = False) -> int:
         """Append one control step (log_h5py.step): device-to-device copies only.  `images`: camera name -> uint8
-        [num_envs, h, w, 3] (e.g. KManipEnvHip.render_rgb) for every registered camera."""
+        [num_envs, h, w, 3] (e.g. KManipEnvHip.render_rgb) for every registered camera.  images_later: the frames of this step
+        are still being rendered (pipeline.RenderBehind): hand them to `late_images(t, images)` with the returned row index t
+        before end_episode().  Returns t."""
         if self.t >= MAX_EPISODE_STEPS:
             raise RuntimeError("episode longer than MAX_EPISODE_STEPS: call end_episode() at the TimeLimit boundary")
         if self.t == 0 and self.cpu_time0 is None:
@@ -164,12 +167,27 @@ class EpisodeLogger:
             self.action[self.t].copy_(act_flat[:, self.grip_r_col:self.grip_r_col + 1].expand(-1, self.log_a_len))
         else:
             self.action[self.t].copy_(act_flat)
+        if images_later:
+            self._frames_due.add(self.t)
+        else:
+            self._put_frames(self.t, images)
+        self.t += 1
+        return self.t - 1
+
+    def _put_frames(self, t, images):
         for name, (cam, ring) in self.cams.items():
             if images is None or name not in images and cam.log_name not in images:
                 raise KeyError("no frame for registered camera %r in this step" % name)
             img = images[name] if name in images else images[cam.log_name]
-            ring[self.t].copy_(img.index_select(0, self._sel))
-        self.t += 1
+            ring[t].copy_(img.index_select(0, self._sel))
+
+    def late_images(self, t: int, images: Dict[str, Any]) -> None:
+        """The frames of row t, logged with `step(..., images_later=True)` (copies on the CURRENT stream: call it after
+        RenderBehind.images(), which orders that stream behind the render)."""
+        if t not in self._frames_due:
+            raise KeyError("row %d is not waiting for frames" % t)
+        self._put_frames(t, images)
+        self._frames_due.discard(t)
 
     def _metadata(self, e):
         if not self.quirk:
@@ -190,6 +208,8 @@ class EpisodeLogger:
 
     def end_episode(self):
         """Write `episode_<n>_env<e>` files for the selected envs (one PCIe crossing for the whole batch)."""
+        if self._frames_due:
+            raise RuntimeError("end_episode(): rows %s were logged with images_later=True and their frames never arrived" % sorted(self._frames_due))
         self.episode += 1
         qpos = self.qpos.cpu().numpy(); qvel = self.qvel.cpu().numpy(); action = self.action.cpu().numpy()
         frames = {name: ring.cpu().numpy() for name, (cam, ring) in self.cams.items()}

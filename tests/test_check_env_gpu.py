@@ -334,3 +334,25 @@ def test_render_behind_gives_the_images_of_its_step():
     with pytest.raises(RuntimeError):
         b.set_render_source(1)                  # no snapshot was ever taken on b
     a.k_close(); b.k_close()
+
+
+def test_synthetic_data_example_logs_the_same_frames_behind_and_in_sequence(tmp_path):
+    """examples/synthetic_data.py on a *Vision id: the frames rendered behind the steps (RenderBehind + EpisodeLogger.late_images)
+    give, file for file and byte for byte, the datasets the in-sequence render gives."""
+    from gym_kmanip_amd.examples import synthetic_data
+    common = ["--env", "KManipSoloArmVision", "--num-envs", "32", "--episodes", "1", "--log-envs", "0", "5"]
+    da = synthetic_data.main(common + ["--log-dir", str(tmp_path / "behind")])
+    db = synthetic_data.main(common + ["--log-dir", str(tmp_path / "seq"), "--render-in-sequence"])
+    fa, fb = sorted(os.listdir(da)), sorted(os.listdir(db))
+    assert fa == fb and len(fa) == 2
+    def read_episode(path):          # (.npz where h5py is not installed -- this image -- else the reference's .hdf5)
+        if path.endswith(".npz"):
+            return np.load(path)
+        import h5py
+        return h5py.File(path, "r")
+    for name in fa:
+        a, b = read_episode(os.path.join(da, name)), read_episode(os.path.join(db, name))
+        for k in ("observations/images/head", "observations/images/grip_r", "observations/qpos", "observations/qvel", "action"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (name, k)
+        head = np.asarray(a["observations/images/head"])
+        assert head.shape == (64, 480, 640, 3) and head.any() and not np.array_equal(head[0], head[-1])

@@ -184,3 +184,33 @@ def test_reference_action_quirk(tmp_path):
     assert (z["action"][0] == a[1, col].item()).all()
     with pytest.raises(ValueError):
         EpisodeLogger(str(tmp_path), 2, 10, cm.act_dim, reference_action_quirk=True, backend="npz")
+
+
+def test_frames_that_arrive_a_step_late(tmp_path):
+    """step(..., images_later=True) + late_images(t, frames): the shape of a loop that renders behind its steps
+    (pipeline.RenderBehind) -- the file is the one in-step frames give; frames that never arrive stop end_episode()."""
+    from gym_kmanip_amd.model import CAMERAS
+    cam = CAMERAS["grip_r"]
+    gen = torch.Generator(); gen.manual_seed(5)
+    rows = [(torch.rand((4, 7), generator=gen), torch.rand((4, 10), generator=gen), torch.rand((4, 10), generator=gen),
+             {"grip_r": torch.randint(0, 255, (4, cam.h, cam.w, 3), generator=gen, dtype=torch.uint8)}) for _ in range(6)]
+    os.makedirs(tmp_path / "a"); os.makedirs(tmp_path / "b")
+    a = EpisodeLogger(str(tmp_path / "a"), 4, 10, 7, env_ids=[2], info={"sim": True}, backend="npz")
+    b = EpisodeLogger(str(tmp_path / "b"), 4, 10, 7, env_ids=[2], info={"sim": True}, backend="npz")
+    a.cam(cam); b.cam(cam)
+    due = None
+    for act, qp, qv, img in rows:
+        a.step(act, qp, qv, images=img)
+        t = b.step(act, qp, qv, images_later=True)
+        if due is not None:
+            b.late_images(*due)
+        due = (t, img)
+    with pytest.raises(RuntimeError, match="never arrived"):
+        b.end_episode()
+    with pytest.raises(KeyError):
+        b.late_images(0, rows[0][3])                  # row 0 has its frames already
+    b.late_images(*due)
+    za, zb = np.load(a.end_episode()[0]), np.load(b.end_episode()[0])
+    for k in ("observations/images/grip_r", "observations/qpos", "action"):
+        assert np.array_equal(za[k], zb[k]), k
+    assert za["observations/images/grip_r"][:6].any()
