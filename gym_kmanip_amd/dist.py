@@ -8,6 +8,7 @@ tests) and double-buffered so that it overlaps the next control step.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Tuple
 
 
@@ -297,21 +298,22 @@ class RcclDirect:
     torch.distributed issues a collective on a stream of its own and ties it to the caller's stream with an event record and a
     stream wait on either side; on one MI355X that costs the step's stream about 30 us per exchange (profiles/r05_rccl_world1.txt)
     -- around a 64 KB all-gather whose kernel runs for a few microseconds.  Put on the step's own stream the exchange needs no
-    cross-stream synchronisation at all: it simply runs after k_step, before the next one.
+    cross-stream synchronisation at all: it simply runs after k_step, before the next one (2 us); on a side stream of the
+    caller's, with one event each way, 14 us (profiles/r05_rccl_direct.txt).
     The communicator is created from an ncclUniqueId that rank 0 generates and the other ranks receive through the existing
     torch.distributed process group (any backend: 128 bytes, once)."""
 
     NCCL_FLOAT64 = 8
 
-    class _UniqueId(__import__("ctypes").Structure):
-        _fields_ = [("internal", __import__("ctypes").c_ubyte * 128)]
+    class _UniqueId(C.Structure):           # rccl.h: typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId, 128 bytes
+        _fields_ = [("internal", C.c_ubyte * 128)]
 
     def __init__(self, world: int, rank: int, dist=None, lib_path: Optional[str] = None):
-        import ctypes as C
         import os
         import torch
         path = lib_path or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self.C, self.torch = C, torch
+        self.torch = torch
+        self.comm = None
         self.L = L = C.CDLL(path)
         L.ncclGetUniqueId.argtypes = [C.POINTER(self._UniqueId)]
         L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self._UniqueId, C.c_int]
@@ -337,10 +339,11 @@ class RcclDirect:
     def all_gather(self, send, recv, stream):
         """recv[world * n, ...] <- every rank's send[n, ...] (float64, contiguous, on the device), enqueued on `stream`."""
         assert send.dtype == self.torch.float64 and send.is_contiguous() and recv.is_contiguous() and recv.numel() == self.world * send.numel()
-        self._chk(self.L.ncclAllGather(self.C.c_void_p(send.data_ptr()), self.C.c_void_p(recv.data_ptr()), send.numel(), self.NCCL_FLOAT64,
-                                       self.comm, self.C.c_void_p(stream.cuda_stream)), "ncclAllGather")
+        self._chk(self.L.ncclAllGather(C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel(), self.NCCL_FLOAT64,
+                                       self.comm, C.c_void_p(stream.cuda_stream)), "ncclAllGather")
 
     def destroy(self):
+        """Give the communicator back (after the streams it was used on have drained: the gathers' close() synchronises)."""
         if self.comm:
             self.L.ncclCommDestroy(self.comm)
             self.comm = None
