@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.19 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.20 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -43,6 +43,8 @@ struct KHandle_ {
   bool cost_sort = false;
   KCostWeights cost_w{18, 1, 2000, 0, 0, 100};     // work units per: IK evaluation, Newton work unit, collider near the cube; bin width
   // heavy-first dispatch (KDeviceState::disp_*): three rotating tables, the step counter that rotates them
+  uint8_t* spread_flags[2] = {nullptr, nullptr};   // SPREAD (KDeviceState::spread_*): the two flag arrays, rotated by every single-step launch
+  unsigned spread_k = 0;
   int32_t* disp_tab[3] = {nullptr, nullptr, nullptr};
   unsigned disp_k = 0;
   int wave_slots = 0;           // entries of st.wave_clk (one per lane group of the step launch's grid)
@@ -244,21 +246,43 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   { const char* e = getenv("KMANIP_IK_UNFUSED"); h->ik_unfused = e && e[0] == '1'; }
   h->st.slot_env = nullptr;
   h->st.wave_clk = nullptr;
+  h->st.spread_in = nullptr; h->st.spread_out = nullptr;
   h->st.disp_in = nullptr; h->st.disp_out = nullptr; h->st.disp_zero = nullptr; h->st.disp_cap = 0; h->st.disp_heavy_epb = 1;
   h->wave_slots = num_envs;
   {
-    // Heavy-first dispatch (experiment, KMANIP_HEAVY_DISPATCH=1): the single-arm Newton kernel at widths whose launch is about one
-    // residency round of multi-env waves (>= 2048 envs: two or four envs per wave).  KMANIP_HEAVY_EPB = heavy envs per wave
-    // (default 1), KMANIP_HEAVY_CAP = most envs dispatched as heavy (default num_envs / 16).
-    // OFF by default: measured on the headline config (profiles/r05_heavy_dispatch.txt) a coupled env alone in a
-    // wave ends after 1.0-1.2 M cycles against 1.4-1.5 M in a four-env wave, but the only predictor with enough recall (a collider
-    // within 1.5 cm of the cube: 99 %) flags 12 % of the envs, the extra 35 % of waves start late, and the launch gets slower.
+    // Which envs share a wave (the single-arm Newton kernel at widths whose launch is about one residency round of multi-env waves).
+    // Every step notes which envs end it with a collider on or within 1.5 cm of the cube ("heavy": 12 % of the envs, 99 % of the
+    // next step's coupled ones); the next launch uses that to choose its wave-mates.  An env's bits do not depend on its slot or
+    // its wave-mates (tests), so this is scheduling only.
+    //  * SPREAD (default at >= 2048 envs: two or four envs per wave; KMANIP_SPREAD=0 turns it off): flags, one byte per env
+    //    (KDeviceState::spread_*).  A wave reads the 64 flags of its block of 64 consecutive envs in one ballot and the block's
+    //    waves deal its envs out so that no wave holds two heavy ones (a wave with two coupled envs runs the joint loop for the
+    //    longer of their iteration counts: those waves ended the launches).  k_step 0.5933 -> 0.5771 ms at 4096 envs, 0.5361 ->
+    //    0.5302 ms at 2048 (profiles/r05_spread_dispatch.txt).  A permutation INSIDE each block whatever the flags say: the cache
+    //    lines a block touches are those of the identity map (a first version dealt from launch-wide lists filled by atomics in
+    //    completion order: 0.5853 ms, HBM traffic 5.6 -> 17 MB a launch).
+    //  * HEAVY-FIRST with variable occupancy (experiment, KMANIP_HEAVY_DISPATCH=1 KMANIP_HEAVY_EPB=1|2|4|0, KMANIP_HEAVY_CAP = most
+    //    envs dispatched as heavy, default num_envs / 16): launch-wide lists (KDeviceState::disp_*), heavy envs first and
+    //    KMANIP_HEAVY_EPB to a wave (0: the list-based spread).  Loses (profiles/r05_heavy_dispatch.txt): a coupled env
+    //    alone in a wave ends after 1.0-1.2 M cycles against 1.4-1.5 M in a four-env wave, but 12 % flagged envs are 35 % more waves
+    //    than SIMD slots, whose late starters end last.
+    //  * KMANIP_HEAVY_DISPATCH=0: neither; the identity map.
+    const bool single_newton = nl == 10 && desc->solver == KM_SOLVER_NEWTON;
+    bool spread = single_newton && num_envs >= 2048 && num_envs % 64 == 0 && !getenv("KMANIP_HEAVY_DISPATCH");
+    if (const char* e = getenv("KMANIP_SPREAD")) spread = spread && e[0] == '1';
+    if (const char* e = getenv("KMANIP_COST_SORT")) if (e[0] == '1') spread = false;      // (the sorted slot order is a map of its own)
+    if (spread) for (int t = 0; t < 2; t++) CR(dalloc((void**)&h->spread_flags[t], (size_t)num_envs));
     bool on = false;
-    if (const char* e = getenv("KMANIP_HEAVY_DISPATCH")) on = e[0] == '1' && nl == 10 && desc->solver == KM_SOLVER_NEWTON && num_envs >= 2048;
+    int hepb = 1;
+    if (const char* e = getenv("KMANIP_HEAVY_DISPATCH")) on = single_newton && num_envs >= 2048 && e[0] == '1';
     if (on) {
-      int cap = num_envs / 16 > 64 ? num_envs / 16 : 64, hepb = 1;
+      int cap = num_envs / 16 > 64 ? num_envs / 16 : 64;
       if (const char* e = getenv("KMANIP_HEAVY_CAP")) { const int v = atoi(e); if (v > 0) cap = v; }
-      if (const char* e = getenv("KMANIP_HEAVY_EPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) hepb = v; }
+      if (const char* e = getenv("KMANIP_HEAVY_EPB")) { const int v = atoi(e); if (v == 0 || v == 1 || v == 2 || v == 4) hepb = v; }
+      if (hepb == 0) {                 // SPREAD: at most one heavy env per wave, every wave of the plain grid can take one
+        const int waves = num_envs / (num_envs >= 4096 ? 4 : 2);
+        if (!getenv("KMANIP_HEAVY_CAP") || cap > waves) cap = waves;
+      }
       if (cap > num_envs) cap = num_envs;
       h->st.disp_cap = cap; h->st.disp_heavy_epb = hepb;
       std::vector<int32_t> init(KM_DISP_HDR + N, 0);
@@ -268,7 +292,7 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
         CR(dalloc((void**)&h->disp_tab[t], sizeof(int32_t) * (KM_DISP_HDR + N)));
         if (t == 0) CR(hipMemcpy(h->disp_tab[0], init.data(), sizeof(int32_t) * (KM_DISP_HDR + N), hipMemcpyHostToDevice));
       }
-      h->wave_slots = 4 * (cap + num_envs + 4);             // (an upper bound of 4 lane groups x the grid of any launch shape)
+      if (hepb > 0) h->wave_slots = 4 * (cap + num_envs + 4);      // (an upper bound of 4 lane groups x the grid of any launch shape; SPREAD keeps the plain grid)
     }
   }
   if (const char* e = getenv("KMANIP_WAVE_CLOCKS")) if (e[0] == '1') CR(dalloc((void**)&h->st.wave_clk, sizeof(unsigned long long) * h->wave_slots));
@@ -328,15 +352,29 @@ int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env
       std::vector<int32_t> tab(KM_DISP_HDR + N);
       HIPCHK(h, hipMemcpy(tab.data(), h->disp_tab[(h->disp_k + 2) % 3], sizeof(int32_t) * (KM_DISP_HDR + N), hipMemcpyDeviceToHost));
       const int epb = h->num_envs >= 4096 ? 4 : 2, hepb = h->st.disp_heavy_epb;
-      const int nh = tab[0] < h->st.disp_cap ? tab[0] : h->st.disp_cap, nhw = (nh + hepb - 1) / hepb;
+      const int nh = tab[0] < h->st.disp_cap ? tab[0] : h->st.disp_cap, nhw = hepb ? (nh + hepb - 1) / hepb : 0;
       for (int sl = 0; sl < h->wave_slots; sl++) {
         const int b = sl / epb, grp = sl % epb;
         int idx = -1;
-        if (b < nhw) { if (grp < hepb && b * hepb + grp < nh) idx = b * hepb + grp; }
+        if (hepb == 0) { const int i = b < nh ? (grp == 0 ? b : nh + (epb - 1) * b + grp - 1) : epb * b + grp; if (i < (int)N) idx = i; }
+        else if (b < nhw) { if (grp < hepb && b * hepb + grp < nh) idx = b * hepb + grp; }
         else { const int i = nh + (b - nhw) * epb + grp; if (i < (int)N) idx = i; }
         slot_env[sl] = idx >= 0 ? tab[KM_DISP_HDR + idx] : -1;
       }
-    } else HIPCHK(h, hipMemcpy(slot_env, h->slot_env, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    } else if (h->spread_flags[0]) {
+      // SPREAD: the LAST launch's map from the flags it read (slot = wave index in slot space x envs per wave + lane group)
+      std::vector<uint8_t> fl(N);
+      HIPCHK(h, hipMemcpy(fl.data(), h->spread_flags[(h->spread_k + 1) & 1], N, hipMemcpyDeviceToHost));
+      int epb = h->num_envs >= 4096 ? 4 : 2;
+      if (const char* e = getenv("KMANIP_EPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) epb = v < epb ? v : epb; }
+      for (size_t blk = 0; blk < N / 64; blk++) {
+        unsigned long long M = 0;
+        for (int i = 0; i < 64; i++) M |= (unsigned long long)(fl[blk * 64 + i] != 0) << i;
+        for (int j = 0; j < 64 / epb; j++)
+          for (int g = 0; g < epb; g++) slot_env[blk * 64 + j * epb + g] = (int32_t)(blk * 64) + spread_pick(M, j, g, epb);
+      }
+    } else if (h->cost_sort) HIPCHK(h, hipMemcpy(slot_env, h->slot_env, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
+    else for (size_t i = 0; i < N; i++) slot_env[i] = (int32_t)i;                     // the identity map
   }
   if (work) HIPCHK(h, hipMemcpy(work, h->st.work, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
   return 0;
@@ -374,6 +412,11 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   if (h->cost_sort) {                        // (one small launch: counting sort of the envs by their last step's diagnostics)
     kmanip_launch_sort_envs(h->st, h->slot_env, h->cost_w, s);
     h->st.slot_env = h->slot_env;
+  }
+  h->st.spread_in = nullptr; h->st.spread_out = nullptr;
+  if (h->spread_flags[0] && nchunk == 1) {       // SPREAD: this launch reads the flags the last single-step launch wrote, and writes the other array
+    h->st.spread_in = h->spread_flags[h->spread_k & 1]; h->st.spread_out = h->spread_flags[(h->spread_k + 1) & 1];
+    h->spread_k++;
   }
   h->st.disp_in = nullptr; h->st.disp_out = nullptr; h->st.disp_zero = nullptr;
   if (h->disp_tab[0] && nchunk == 1) {       // heavy-first dispatch: this launch reads table k, fills k + 1, clears the counters of k + 2

@@ -48,6 +48,39 @@ typedef double real;
 // env order the rest.  Giving each XCD a CONTIGUOUS range of env blocks keeps those neighbours behind the same L2, so a line is
 // fetched from HBM once instead of once per XCD (measured: FETCH_SIZE per k_step launch 5.6 MB -> 3.2 MB, profiles/r02f_pmc_hbm.json).  A bijection
 // of [0, nblocks) for any nblocks; the results do not depend on it (envs are independent).
+// position of the k-th (0-based) set bit of x (popcount(x) > k)
+__host__ __device__ inline int select64(unsigned long long x, int k) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const unsigned long long lowm = (1ull << w) - 1ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int c = __popcll(x & lowm);
+#else
+    const int c = __builtin_popcountll(x & lowm);
+#endif
+    if (k >= c) { k -= c; pos += w; x >>= w; }
+  }
+  return pos;
+}
+// SPREAD: the env (index inside its 64-env block) that lane group `grp` of the block's wave `j` takes, from the block's heavy mask M.
+// Waves j < nh1 = min(popcount(M), waves per block) take the j-th heavy env into group 0 and light envs into the others; "light" =
+// everything but the first nh1 heavy envs.  EPB envs per wave, 64 / EPB waves per block.
+__host__ __device__ inline int spread_pick(unsigned long long M, int j, int grp, int EPB) {
+  const int WPB = 64 / EPB;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int nhb = __popcll(M);
+#else
+  const int nhb = __builtin_popcountll(M);
+#endif
+  const int nh1 = nhb < WPB ? nhb : WPB;
+  unsigned long long H = M;
+  if (nhb > WPB) { const int pos = select64(M, WPB - 1); H = M & ((2ull << pos) - 1ull); }
+  const unsigned long long L = ~H;
+  if (j < nh1) return grp == 0 ? select64(H, j) : select64(L, (EPB - 1) * j + grp - 1);
+  return select64(L, (EPB - 1) * nh1 + EPB * (j - nh1) + grp);
+}
+
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
   const int x = b & 7, i = b >> 3, base = nblocks >> 3, rem = nblocks & 7;
   return x * base + (x < rem ? x : rem) + i;
@@ -435,6 +468,12 @@ struct KDeviceState {
   // KM_NEAR_MARGIN of the cube: the coupled Newton loop is on or about to start), and workgroup 0 clears the counters of disp_zero
   // (the table after next).  Three tables rotate on the host; any partition of the env ids is a valid table, and an env's bits
   // depend neither on its slot nor on its wave-mates.
+  // SPREAD (the default of the four-envs-per-wave single-arm launch; kmanip_api.hip): one byte per env, "heavy at the end of its last
+  // step", written by every step into spread_out and read by the next launch from spread_in.  A wave looks at the 64 flags of ITS
+  // block of 64 consecutive envs (one ballot) and deals the block's envs to the block's waves so that no wave holds two heavy ones:
+  // a permutation inside the block, whatever the flags are -- the block's cache lines are the ones the identity map touches.
+  const uint8_t* spread_in;
+  uint8_t* spread_out;
   const int32_t* disp_in;
   int32_t* disp_out;
   int32_t* disp_zero;

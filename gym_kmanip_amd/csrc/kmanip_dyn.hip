@@ -2529,28 +2529,52 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
   __shared__ Ws<NL> ws[EPB];
   __shared__ LModel<NL> lm;
-  stage_model<NL>(lm, dm);
   const KModelDesc* m = &dm->d;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   // wave slot -> env: the identity behind the XCD-aware block mapping, or -- launches of several residency rounds -- the
-  // predicted-cost order of k_sort_envs with workgroup 0 first (longest-processing-time-first dispatch)
+  // predicted-cost order of k_sort_envs with workgroup 0 first (longest-processing-time-first dispatch); or the previous
+  // launch's dispatch list.  Looked up BEFORE the model is staged: the list's two dependent loads wait beside the staging's own.
   int slot = (st.slot_env ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * EPB + grp;
-  if (grp >= EPB) return;                              // whole group exits together
-  int env;
-  if (st.disp_in) {
-    // heavy-first dispatch (KDeviceState): the first workgroups hold the envs predicted heavy, disp_heavy_epb of them per wave
-    // (1: no wave-mates to wait for at the IK, at the solves, in the joint loop); light envs fill the following waves EPB at a time
+  int env = -1;
+  unsigned long long heavy_mask = 0;
+  if (st.spread_in) {
+    // SPREAD (KDeviceState): the 64 flags of this wave's block of 64 consecutive envs, one per lane (every lane votes: before any exit)
+    const int blk = (slot - grp) / 64;
+    heavy_mask = __ballot(st.spread_in[blk * 64 + lane] != 0);
+  }
+  if (grp >= EPB) {
+  } else if (st.spread_in) {
+    const int wv = (slot - grp) / EPB;                        // this wave's index in slot space (xcd_block keeps an XCD's waves together)
+    env = (wv / (64 / EPB)) * 64 + spread_pick(heavy_mask, wv % (64 / EPB), grp, EPB);
+  } else if (st.disp_in) {
+    // dispatch list (KDeviceState; kmanip_api.hip): SPREAD, or the heavy-first experiment -- the first workgroups hold the envs
+    // predicted heavy, disp_heavy_epb of them per wave (1: no wave-mates to wait for at the IK, at the solves, in the joint loop),
+    // light envs fill the following waves EPB at a time
     const int N = st.num_envs, nh = min(st.disp_in[0], st.disp_cap), hepb = st.disp_heavy_epb;
-    const int nhw = (nh + hepb - 1) / hepb, b = blockIdx.x;
-    int idx;
-    if (b < nhw) { idx = b * hepb + grp; if (grp >= hepb || idx >= nh) return; }
-    else { idx = nh + (b - nhw) * EPB + grp; if (idx >= N) return; }
-    env = st.disp_in[KM_DISP_HDR + idx];
+    const int b = blockIdx.x;
+    int idx = -1;
+    // (never seen: the list is filled by the previous launch's waves, one entry each.  A list that does not add up -- a launch
+    // that was aborted half way -- must not lose or duplicate an env: the identity map instead)
+    const bool ident = nh + st.disp_in[1] != N;
+    if (ident) {
+      idx = EPB * b + grp;
+    } else if (hepb == 0) {
+      // SPREAD: the grid stays one wave per EPB envs; wave b < nh takes heavy env b into its lane group 0 and light envs into the
+      // others, so that no wave holds two envs predicted heavy (two coupled envs in one wave run the joint loop for the longer of
+      // their iteration counts, with twice the chance of a straggler: those waves end the launch)
+      idx = b < nh ? (grp == 0 ? b : nh + (EPB - 1) * b + grp - 1) : EPB * b + grp;
+    } else {
+      const int nhw = (nh + hepb - 1) / hepb;
+      if (b < nhw) { if (grp < hepb && b * hepb + grp < nh) idx = b * hepb + grp; }
+      else idx = nh + (b - nhw) * EPB + grp;
+    }
+    if (idx >= 0 && idx < N) env = ident ? idx : st.disp_in[KM_DISP_HDR + idx];
     slot = b * EPB + grp;                               // (diagnostics: wave_clk is sized for the grid)
-  } else {
-    if (slot >= st.num_envs) return;
+  } else if (slot < st.num_envs) {
     env = st.slot_env ? st.slot_env[slot] : slot;
   }
+  stage_model<NL>(lm, dm);
+  if (env < 0) return;                                 // whole group exits together
   Ws<NL>& w = ws[grp];
   CReg<NL> cr;
   real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
@@ -2658,6 +2682,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub == 0) {
     st.step_idx[env] = step_idx; st.episode[env] = episode;
     if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
+    if (!CHUNK && st.spread_out) st.spread_out[env] = (uint8_t)(heavy_next != 0);
     if (!CHUNK && st.disp_out) {
       // register for the next launch: heavy envs from the front of the list (at most disp_cap of them), the others from the back
       int pos = -1;
@@ -2750,7 +2775,7 @@ static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, const 
     if constexpr (EPB == 64 / G) hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB, true>), dim3((st.num_envs + EPB - 1) / EPB), dim3(64), 0, stream, dm, st, act, obs, reward, done, nchunk);
   } else {
     int grid = (st.num_envs + EPB - 1) / EPB;
-    if (st.disp_in)       // room for disp_cap heavy envs at disp_heavy_epb per wave next to the light ones at EPB per wave (surplus workgroups exit at once)
+    if (st.disp_in && st.disp_heavy_epb > 0)       // room for disp_cap heavy envs at disp_heavy_epb per wave next to the light ones at EPB per wave (surplus workgroups exit at once)
       grid = (st.disp_cap + st.disp_heavy_epb - 1) / st.disp_heavy_epb + (st.num_envs - st.disp_cap + EPB - 1) / EPB + 1;
     hipLaunchKernelGGL((k_step<NL, G, SOLVER, EPB, false>), dim3(grid), dim3(64), 0, stream, dm, st, act, obs, reward, done, 1);
   }

@@ -291,23 +291,30 @@ def test_cost_sorted_wave_slots_change_nothing_but_the_order(monkeypatch):
     a.k_close(); b.k_close()
 
 
-@pytest.mark.parametrize("n,hepb", [(4096, "1"), (4096, "2"), (2048, "1")])
+@pytest.mark.parametrize("n,hepb", [(4096, "1"), (4096, "2"), (2048, "1"), (4096, "0"), (4096, "spread"), (2048, "spread")])
 def test_heavy_first_dispatch_changes_nothing_but_the_slots(monkeypatch, n, hepb):
     """Single-arm launches of one residency round dispatch the envs predicted heavy (a collider on or near the cube at the end of
     their last step) FIRST and with a wave to themselves (or two per wave), everybody else four (two) per wave behind them: the
     dispatch table is a partition of the env ids rebuilt by every step, and an env's bits depend neither on its slot nor on its
     wave-mates -- a handle with the dispatch (KMANIP_HEAVY_DISPATCH=1) against one without, bit for bit,
-    across an auto-reset; the table is a permutation every step and heavy envs do occur."""
+    across an auto-reset; the table is a permutation every step and heavy envs do occur.
+    hepb = "0": the list-based spread -- the grid of the plain launch, one predicted-heavy env in lane group 0 of the first waves
+    and light envs beside it.  hepb = "spread": what a handle of >= 2048 single-arm envs does BY DEFAULT:
+    per-env flags, every block of 64 consecutive envs dealt to its own 16 (32) waves so that no wave holds two heavy envs --
+    a permutation inside every block, and heavy envs of a block sit in different waves."""
     import ctypes as C
     import torch
     from gym_kmanip_amd import env_hip
-    monkeypatch.setenv("KMANIP_HEAVY_EPB", hepb)
-    monkeypatch.setenv("KMANIP_HEAVY_DISPATCH", "1")
-    a = env_hip.make("KManipSoloArm", num_envs=n, seed=5)              # heavy-first dispatch (an opt-in experiment: DESIGN.md 3.4c)
+    spread = hepb == "spread"
+    if not spread:
+        monkeypatch.setenv("KMANIP_HEAVY_EPB", hepb)
+        monkeypatch.setenv("KMANIP_HEAVY_DISPATCH", "1")
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=5)              # hepb 0 / 1 / 2: launch-wide lists (opt-in experiments: DESIGN.md 3.2)
+    monkeypatch.setenv("KMANIP_HEAVY_DISPATCH", "0")
+    b = env_hip.make("KManipSoloArm", num_envs=n, seed=5)              # neither: the identity map
     monkeypatch.delenv("KMANIP_HEAVY_DISPATCH")
-    b = env_hip.make("KManipSoloArm", num_envs=n, seed=5)
     S = a.L.kmanip_dbg_wave_slots(a.h)
-    assert S > n and b.L.kmanip_dbg_wave_slots(b.h) == n
+    assert (S > n if hepb in ("1", "2") else S == n) and b.L.kmanip_dbg_wave_slots(b.h) == n
     a.k_reset(); b.k_reset()
     ph = (40 + np.arange(n) % 24).astype(np.int32)
     a.set_state(step=ph); b.set_state(step=ph)
@@ -320,7 +327,14 @@ def test_heavy_first_dispatch_changes_nothing_but_the_slots(monkeypatch, n, hepb
         assert a.L.kmanip_dbg_wave_clocks(a.h, None, slot.ctypes.data_as(C.POINTER(C.c_int32)), None) == 0
         assert np.array_equal(np.sort(slot[slot >= 0]), np.arange(n)), k         # every env exactly once
         per_wave = (slot[:(S // epb) * epb].reshape(-1, epb) >= 0).sum(1)
-        nheavy.append(int(((per_wave > 0) & (per_wave <= int(hepb)) & (per_wave < epb)).sum()))
+        if hepb == "0" or spread:
+            assert (per_wave[:n // epb] == epb).all() and not per_wave[n // epb:].any()      # the plain grid, every wave full
+            nheavy.append(int((slot[:n] != np.arange(n)).sum()))                             # (no heavy env: the identity)
+        if spread:
+            blocks = slot[:n].reshape(-1, 64)
+            assert np.array_equal(np.sort(blocks, axis=1), np.arange(n).reshape(-1, 64)), k   # a permutation inside every 64-env block
+        else:
+            nheavy.append(int(((per_wave > 0) & (per_wave <= int(hepb)) & (per_wave < epb)).sum()))
     assert all(np.array_equal(x, y) for x, y in zip(a.get_state(), b.get_state()))
     assert np.array_equal(a.get_diag()[0], b.get_diag()[0])
     assert max(nheavy) > 0, nheavy                                               # some envs were dispatched as heavy

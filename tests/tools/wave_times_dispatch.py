@@ -14,15 +14,16 @@ for k in range(80):
 S = e.L.kmanip_dbg_wave_slots(e.h)
 epb = 4 if n >= 4096 else 2
 disp = S > n
-allw, heavy_w, light_w, nheavy, late = [], [], [], [], []
+allw, heavy_w, light_w, nheavy, late, pairs = [], [], [], [], [], []
+coupled_prev = None
 for k in range(L):
     e.step_flat(e.sample_action())
     clk = np.zeros(S, dtype=np.uint64); slot = np.full(S, -1, dtype=np.int32)
-    e.L.kmanip_dbg_wave_clocks(e.h, clk.ctypes.data_as(C.POINTER(C.c_ulonglong)), slot.ctypes.data_as(C.POINTER(C.c_int32)) if disp else None, None)
-    if not disp:
-        slot = np.arange(S, dtype=np.int32)
+    e.L.kmanip_dbg_wave_clocks(e.h, clk.ctypes.data_as(C.POINTER(C.c_ulonglong)), slot.ctypes.data_as(C.POINTER(C.c_int32)), None)   # (the launch's own slot -> env map)
     dg = e.get_diag()
     nf = dg[1].max(1); coupled_now = (dg[0] & 0xFFF00) != 0          # (end-of-step state: a sphere on the cube)
+    was = coupled_prev if k else np.zeros(n, dtype=bool)
+    coupled_prev = coupled_now.copy()
     start = ((clk >> np.uint64(40)) & np.uint64(0xFFFFFF)).astype(np.int64)
     ticks = (clk & np.uint64(0xFFFFFFFFFF)).astype(np.float64)
     sl = slot[:(S // epb) * epb].reshape(-1, epb); tk = ticks[:(S // epb) * epb].reshape(-1, epb); st = start[:(S // epb) * epb].reshape(-1, epb)
@@ -40,7 +41,9 @@ for k in range(L):
     mx = np.argmax(w)
     top = np.argsort(w)[::-1][:4]
     envs_of = sl[used]
-    tops = "; ".join("%.0f nfev %s cpl %s" % (w[i], nf[envs_of[i][envs_of[i] >= 0]], coupled_now[envs_of[i][envs_of[i] >= 0]].astype(int)) for i in top)
+    tops = "; ".join("%.0f nfev %s cpl %s was %s" % (w[i], nf[envs_of[i][envs_of[i] >= 0]], coupled_now[envs_of[i][envs_of[i] >= 0]].astype(int), was[envs_of[i][envs_of[i] >= 0]].astype(int)) for i in top)
+    ncw = coupled_now[np.where(envs_of >= 0, envs_of, 0)].sum(1)
+    pairs.append(int((ncw >= 2).sum()))
     print("   top 4 waves: " + tops)
     print("launch %2d: waves %4d  max %.0f (%s, %d env(s), nfev %s, started +%d us)  mean %.0f  p99 %.0f   late-started waves %d%s" % (
         k, len(w), w[mx], "heavy" if disp and c[mx] < epb else "light", c[mx], nf[sl[used][mx][sl[used][mx] >= 0]], s0[mx] // 100, w.mean(), np.percentile(w, 99), late[-1],
@@ -49,6 +52,7 @@ for k in range(L):
 w = np.concatenate(allw)
 print("all launches: wave ticks mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; mean of the launches' max %.0f" % (
     w.mean(), np.median(w), np.percentile(w, 90), np.percentile(w, 99), w.max(), np.mean([a.max() for a in allw])))
+print("waves that ended the step holding two or more envs with a sphere on the cube: mean %.2f per launch" % np.mean(pairs))
 if disp:
     print("heavy envs per launch: mean %.1f (cap %d); heavy-wave ticks mean %.0f p90 %.0f max %.0f; light-wave ticks mean %.0f p99 %.0f max %.0f" % (
         np.mean(nheavy), (S // 4 - n - 4), np.concatenate(heavy_w).mean(), np.percentile(np.concatenate(heavy_w), 90), np.concatenate(heavy_w).max(),
