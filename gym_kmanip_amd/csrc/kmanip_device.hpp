@@ -63,10 +63,13 @@ __host__ __device__ inline int select64(unsigned long long x, int k) {
   }
   return pos;
 }
-// SPREAD: the env (index inside its 64-env block) that lane group `grp` of the block's wave `j` takes, from the block's heavy mask M.
-// Waves j < nh1 = min(popcount(M), waves per block) take the j-th heavy env into group 0 and light envs into the others; "light" =
-// everything but the first nh1 heavy envs.  EPB envs per wave, 64 / EPB waves per block.
-__host__ __device__ inline int spread_pick(unsigned long long M, int j, int grp, int EPB) {
+// SPREAD: the env (index inside its 64-env block) that lane group `grp` of the block's wave `j` takes, from the block's masks:
+// M = heavy (a collider on or near the cube), T = a sphere on the table (a non-trivial arm problem: its iterations outlast a plain
+// one's).  Waves j < nh1 = min(popcount(M), waves per block) take the j-th heavy env into group 0; everything else is dealt in the
+// order [plain envs, then table envs] -- the heavy waves' other groups first -- so that a heavy env's wave-mates are the cheapest
+// envs of the block and the table envs sit together in the block's last waves (like with like: their loops run in lockstep).
+// EPB envs per wave, 64 / EPB waves per block.  A permutation of 0..63 for every (M, T).
+__host__ __device__ inline int spread_pick(unsigned long long M, unsigned long long T, int j, int grp, int EPB) {
   const int WPB = 64 / EPB;
 #if defined(__HIP_DEVICE_COMPILE__)
   const int nhb = __popcll(M);
@@ -76,9 +79,15 @@ __host__ __device__ inline int spread_pick(unsigned long long M, int j, int grp,
   const int nh1 = nhb < WPB ? nhb : WPB;
   unsigned long long H = M;
   if (nhb > WPB) { const int pos = select64(M, WPB - 1); H = M & ((2ull << pos) - 1ull); }
-  const unsigned long long L = ~H;
-  if (j < nh1) return grp == 0 ? select64(H, j) : select64(L, (EPB - 1) * j + grp - 1);
-  return select64(L, (EPB - 1) * nh1 + EPB * (j - nh1) + grp);
+  if (j < nh1 && grp == 0) return select64(H, j);
+  const unsigned long long C = ~H & ~T, B = ~H & T;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int nc = __popcll(C);
+#else
+  const int nc = __builtin_popcountll(C);
+#endif
+  const int k = j < nh1 ? (EPB - 1) * j + grp - 1 : (EPB - 1) * nh1 + EPB * (j - nh1) + grp;
+  return k < nc ? select64(C, k) : select64(B, k - nc);
 }
 
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {
@@ -474,6 +483,7 @@ struct KDeviceState {
   // a permutation inside the block, whatever the flags are -- the block's cache lines are the ones the identity map touches.
   const uint8_t* spread_in;
   uint8_t* spread_out;
+  int spread_table;     // 1: the flags carry the second class too (a sphere on the table); 0 (KMANIP_SPREAD_TABLE=0, A/B): heavy only
   const int32_t* disp_in;
   int32_t* disp_out;
   int32_t* disp_zero;

@@ -2536,16 +2536,18 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   // launch's dispatch list.  Looked up BEFORE the model is staged: the list's two dependent loads wait beside the staging's own.
   int slot = (st.slot_env ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * EPB + grp;
   int env = -1;
-  unsigned long long heavy_mask = 0;
+  unsigned long long heavy_mask = 0, table_mask = 0;
   if (st.spread_in) {
     // SPREAD (KDeviceState): the 64 flags of this wave's block of 64 consecutive envs, one per lane (every lane votes: before any exit)
     const int blk = (slot - grp) / 64;
-    heavy_mask = __ballot(st.spread_in[blk * 64 + lane] != 0);
+    const int fl = st.spread_in[blk * 64 + lane];
+    heavy_mask = __ballot((fl & 1) != 0);
+    table_mask = __ballot((fl & 2) != 0);
   }
   if (grp >= EPB) {
   } else if (st.spread_in) {
     const int wv = (slot - grp) / EPB;                        // this wave's index in slot space (xcd_block keeps an XCD's waves together)
-    env = (wv / (64 / EPB)) * 64 + spread_pick(heavy_mask, wv % (64 / EPB), grp, EPB);
+    env = (wv / (64 / EPB)) * 64 + spread_pick(heavy_mask, table_mask, wv % (64 / EPB), grp, EPB);
   } else if (st.disp_in) {
     // dispatch list (KDeviceState; kmanip_api.hip): SPREAD, or the heavy-first experiment -- the first workgroups hold the envs
     // predicted heavy, disp_heavy_epb of them per wave (1: no wave-mates to wait for at the IK, at the solves, in the joint loop),
@@ -2598,6 +2600,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   // speed instead of the slowest wave's; the state stays in LDS between the steps of a chunk.
   const int nsteps = CHUNK ? nchunk : 1;      // (the single-step kernel keeps its register allocation: no outer loop)
   int heavy_next = 0;                         // this env's class for the next launch's dispatch table (the state it ENDS the step in)
+  int table_next = 0;                         // ... and: a sphere on the table (SPREAD's second class)
   for (int kc = 0; kc < nsteps; kc++) {
   if (fused) {
     if (kc > 0) {
@@ -2620,7 +2623,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     pf.ph(30);
   }
   int bad = 0;
-  heavy_next = 0;
+  heavy_next = 0; table_next = 0;
   const int nsub = m->n_sub_steps;
   for (int s = 0; s < nsub; s++) {
     // the lane's dof index, opaque to the optimiser once per sub-step: everything derived from it (LDS addresses, per-link
@@ -2653,6 +2656,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     fk_parallel<NL, G>(w, lm, sub);
     const int near_cube = collide_parallel<NL, G, true>(w, m, sub);
     heavy_next = near_cube;
+    table_next = st.spread_table && (w.contact_mask & KM_CON_ANY_SPHERE_TABLE) != 0;
     if constexpr (KM_WORK_COUNTERS(NL)) { if (sub == 0 && near_cube) w.work |= 1 << 30; }     // (bit 30: a collider on or close to the cube)
     rew = env_reward<NL, G>(w, m, sub);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
@@ -2666,7 +2670,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (step_idx >= m->max_episode_steps) dn |= KM_DONE_TRUNCATED;
   if (dn && (m->auto_reset || bad)) {
     episode += 1; step_idx = 0;
-    heavy_next = 0;                               // (the respawned cube is nowhere near the home pose)
+    heavy_next = 0; table_next = 0;               // (the respawned cube is nowhere near the home pose)
     GSYNC();
     pf.ph(31);
     reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
@@ -2682,7 +2686,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub == 0) {
     st.step_idx[env] = step_idx; st.episode[env] = episode;
     if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
-    if (!CHUNK && st.spread_out) st.spread_out[env] = (uint8_t)(heavy_next != 0);
+    if (!CHUNK && st.spread_out) st.spread_out[env] = (uint8_t)((heavy_next != 0) | (table_next << 1));
     if (!CHUNK && st.disp_out) {
       // register for the next launch: heavy envs from the front of the list (at most disp_cap of them), the others from the back
       int pos = -1;

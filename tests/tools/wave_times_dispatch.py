@@ -14,7 +14,7 @@ for k in range(80):
 S = e.L.kmanip_dbg_wave_slots(e.h)
 epb = 4 if n >= 4096 else 2
 disp = S > n
-allw, heavy_w, light_w, nheavy, late, pairs = [], [], [], [], [], []
+allw, heavy_w, light_w, nheavy, late, pairs, ntab = [], [], [], [], [], [], []
 coupled_prev = None
 for k in range(L):
     e.step_flat(e.sample_action())
@@ -22,6 +22,7 @@ for k in range(L):
     e.L.kmanip_dbg_wave_clocks(e.h, clk.ctypes.data_as(C.POINTER(C.c_ulonglong)), slot.ctypes.data_as(C.POINTER(C.c_int32)), None)   # (the launch's own slot -> env map)
     dg = e.get_diag()
     nf = dg[1].max(1); coupled_now = (dg[0] & 0xFFF00) != 0          # (end-of-step state: a sphere on the cube)
+    table_now = (dg[0].astype(np.uint32) & np.uint32(0xFFF00000)) != 0                       # (a sphere on the table)
     was = coupled_prev if k else np.zeros(n, dtype=bool)
     coupled_prev = coupled_now.copy()
     start = ((clk >> np.uint64(40)) & np.uint64(0xFFFFFF)).astype(np.int64)
@@ -41,7 +42,8 @@ for k in range(L):
     mx = np.argmax(w)
     top = np.argsort(w)[::-1][:4]
     envs_of = sl[used]
-    tops = "; ".join("%.0f nfev %s cpl %s was %s" % (w[i], nf[envs_of[i][envs_of[i] >= 0]], coupled_now[envs_of[i][envs_of[i] >= 0]].astype(int), was[envs_of[i][envs_of[i] >= 0]].astype(int)) for i in top)
+    tops = "; ".join("%.0f nfev %s cpl %s was %s tab %s" % (w[i], nf[envs_of[i][envs_of[i] >= 0]], coupled_now[envs_of[i][envs_of[i] >= 0]].astype(int), was[envs_of[i][envs_of[i] >= 0]].astype(int), table_now[envs_of[i][envs_of[i] >= 0]].astype(int)) for i in top)
+    ntab.append(float(table_now.mean()))
     ncw = coupled_now[np.where(envs_of >= 0, envs_of, 0)].sum(1)
     pairs.append(int((ncw >= 2).sum()))
     print("   top 4 waves: " + tops)
@@ -52,7 +54,7 @@ for k in range(L):
 w = np.concatenate(allw)
 print("all launches: wave ticks mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; mean of the launches' max %.0f" % (
     w.mean(), np.median(w), np.percentile(w, 90), np.percentile(w, 99), w.max(), np.mean([a.max() for a in allw])))
-print("waves that ended the step holding two or more envs with a sphere on the cube: mean %.2f per launch" % np.mean(pairs))
+print("waves that ended the step holding two or more envs with a sphere on the cube: mean %.2f per launch; envs with a sphere on the TABLE at the end of a step: %.1f %%" % (np.mean(pairs), 100 * np.mean(ntab)))
 if disp:
     print("heavy envs per launch: mean %.1f (cap %d); heavy-wave ticks mean %.0f p90 %.0f max %.0f; light-wave ticks mean %.0f p99 %.0f max %.0f" % (
         np.mean(nheavy), (S // 4 - n - 4), np.concatenate(heavy_w).mean(), np.percentile(np.concatenate(heavy_w), 90), np.concatenate(heavy_w).max(),
