@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.21 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.22 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -418,7 +418,7 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
     h->st.slot_env = h->slot_env;
   }
   h->st.spread_in = nullptr; h->st.spread_out = nullptr;
-  if (h->spread_flags[0] && nchunk == 1) {       // SPREAD: this launch reads the flags the last single-step launch wrote, and writes the other array
+  if (h->spread_flags[0]) {       // SPREAD: this launch (one step or a chunk of them) reads the flags the last launch wrote, and writes the other array
     h->st.spread_in = h->spread_flags[h->spread_k & 1]; h->st.spread_out = h->spread_flags[(h->spread_k + 1) & 1];
     h->spread_k++;
   }

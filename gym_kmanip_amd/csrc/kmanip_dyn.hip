@@ -2686,7 +2686,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (sub == 0) {
     st.step_idx[env] = step_idx; st.episode[env] = episode;
     if (st.sim_time) st.sim_time[env] = step_idx * st.control_dt;
-    if (!CHUNK && st.spread_out) st.spread_out[env] = (uint8_t)((heavy_next != 0) | (table_next << 1));
+    if (st.spread_out) st.spread_out[env] = (uint8_t)((heavy_next != 0) | (table_next << 1));      // (a chunk: the state its LAST step ends in)
     if (!CHUNK && st.disp_out) {
       // register for the next launch: heavy envs from the front of the list (at most disp_cap of them), the others from the back
       int pos = -1;
