@@ -277,7 +277,10 @@ def _make_direct(direct, world, dist, device, force_collective):
         raise RuntimeError("direct=True needs the ranks on distinct GPUs (RCCL refuses two ranks on one device): backend 'nccl'")
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     with torch.cuda.device(device):
-        return RcclDirect(world, rank, dist)
+        comm = RcclDirect(world, rank, dist)
+        if not comm.self_test(rank, device):
+            raise RuntimeError("RcclDirect: the test all-gather of the rank numbers came back wrong on rank %d" % rank)
+        return comm
 
 
 def share_bytes(raw, nbytes: int, dist, torch) -> bytes:
@@ -341,6 +344,16 @@ class RcclDirect:
         assert send.dtype == self.torch.float64 and send.is_contiguous() and recv.is_contiguous() and recv.numel() == self.world * send.numel()
         self._chk(self.L.ncclAllGather(C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel(), self.NCCL_FLOAT64,
                                        self.comm, C.c_void_p(stream.cuda_stream)), "ncclAllGather")
+
+    def self_test(self, rank: int, device) -> bool:
+        """One all-gather of the rank numbers on the current stream: True iff every rank's block arrived in rank order."""
+        torch = self.torch
+        send = torch.full((8,), float(rank), dtype=torch.float64, device=device)
+        recv = torch.full((8 * self.world,), -1.0, dtype=torch.float64, device=device)
+        self.all_gather(send, recv, torch.cuda.current_stream(device))
+        torch.cuda.current_stream(device).synchronize()
+        want = torch.arange(self.world, dtype=torch.float64, device=device).repeat_interleave(8)
+        return bool(torch.equal(recv, want))
 
     def destroy(self):
         """Give the communicator back (after the streams it was used on have drained: the gathers' close() synchronises)."""
