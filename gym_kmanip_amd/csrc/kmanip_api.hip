@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.22 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.23 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -255,14 +255,15 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
     // next step's coupled ones); the next launch uses that to choose its wave-mates.  An env's bits do not depend on its slot or
     // its wave-mates (tests), so this is scheduling only.
     //  * SPREAD (default at >= 2048 envs: two or four envs per wave; KMANIP_SPREAD=0 turns it off): flags, one byte per env
-    //    (KDeviceState::spread_*: bit 0 heavy, bit 1 a sphere on the table).  A wave reads the 64 flags of its block of 64 consecutive
-    //    envs (two ballots) and the block's waves deal its envs out (spread_pick): the j-th heavy env to lane group 0 of wave j, so that
-    //    no wave holds two heavy ones (a wave with two coupled envs runs the joint loop for the longer of their iteration counts: those
-    //    waves ended the launches); the heavy waves' other groups take the block's plainest envs, and the envs with a sphere on the
-    //    table (non-trivial arm problems) sit together in the block's last waves.  k_step 0.5912 -> 0.5741 ms at 4096 envs, 0.5361 ->
-    //    0.5302 ms at 2048 (profiles/r05_spread_dispatch.txt).  A permutation INSIDE each block whatever the flags say: the cache
-    //    lines a block touches are those of the identity map (a first version dealt from launch-wide lists filled by atomics in
-    //    completion order: 0.5853 ms, HBM traffic 5.6 -> 17 MB a launch).
+    //    (KDeviceState::spread_*: bit 0 heavy; bits 1-2 a cost score of the others: a cube that does not rest on four corners, a
+    //    sphere on the table).  A wave reads the 64 flags of its block of 64 consecutive envs (three ballots) and the block's waves
+    //    deal its envs out (spread_pick): the j-th heavy env to lane group 0 of wave j, so that no wave holds two heavy ones (a wave
+    //    with two coupled envs runs the joint loop for the longer of their iteration counts: those waves ended the launches); the
+    //    others in ascending score order, so that the heavy waves' other groups take the block's plainest envs and envs of a kind
+    //    sit together in the later waves.  k_step 0.5896 -> 0.5690 ms at 4096 envs (heavy-only flags 0.5751, + table bit 0.5716),
+    //    0.5361 -> 0.5302 ms at 2048 (profiles/r05_spread_dispatch.txt).  A permutation INSIDE each block whatever the flags
+    //    say: the cache lines a block touches are those of the identity map (a first version dealt from launch-wide lists filled by
+    //    atomics in completion order: 0.5853 ms, HBM traffic 5.6 -> 17 MB a launch).
     //  * HEAVY-FIRST with variable occupancy (experiment, KMANIP_HEAVY_DISPATCH=1 KMANIP_HEAVY_EPB=1|2|4|0, KMANIP_HEAVY_CAP = most
     //    envs dispatched as heavy, default num_envs / 16): launch-wide lists (KDeviceState::disp_*), heavy envs first and
     //    KMANIP_HEAVY_EPB to a wave (0: the list-based spread).  Loses (profiles/r05_heavy_dispatch.txt): a coupled env
@@ -274,8 +275,8 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
     if (const char* e = getenv("KMANIP_SPREAD")) spread = spread && e[0] == '1';
     if (const char* e = getenv("KMANIP_COST_SORT")) if (e[0] == '1') spread = false;      // (the sorted slot order is a map of its own)
     if (spread) for (int t = 0; t < 2; t++) CR(dalloc((void**)&h->spread_flags[t], (size_t)num_envs));
-    h->st.spread_table = 1;
-    if (const char* e = getenv("KMANIP_SPREAD_TABLE")) h->st.spread_table = e[0] != '0';
+    h->st.spread_table = 3;
+    if (const char* e = getenv("KMANIP_SPREAD_TABLE")) h->st.spread_table = atoi(e);
     bool on = false;
     int hepb = 1;
     if (const char* e = getenv("KMANIP_HEAVY_DISPATCH")) on = single_newton && num_envs >= 2048 && e[0] == '1';
@@ -372,10 +373,13 @@ int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env
       int epb = h->num_envs >= 4096 ? 4 : 2;
       if (const char* e = getenv("KMANIP_EPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) epb = v < epb ? v : epb; }
       for (size_t blk = 0; blk < N / 64; blk++) {
-        unsigned long long M = 0, T = 0;
-        for (int i = 0; i < 64; i++) { M |= (unsigned long long)(fl[blk * 64 + i] & 1) << i; T |= (unsigned long long)((fl[blk * 64 + i] >> 1) & 1) << i; }
+        unsigned long long M = 0, S1 = 0, S2 = 0;
+        for (int i = 0; i < 64; i++) {
+          const unsigned long long f = fl[blk * 64 + i];
+          M |= (f & 1) << i; S1 |= ((f >> 1) & 1) << i; S2 |= ((f >> 2) & 1) << i;
+        }
         for (int j = 0; j < 64 / epb; j++)
-          for (int g = 0; g < epb; g++) slot_env[blk * 64 + j * epb + g] = (int32_t)(blk * 64) + spread_pick(M, T, j, g, epb);
+          for (int g = 0; g < epb; g++) slot_env[blk * 64 + j * epb + g] = (int32_t)(blk * 64) + spread_pick(M, S1, S2, j, g, epb);
       }
     } else if (h->cost_sort) HIPCHK(h, hipMemcpy(slot_env, h->slot_env, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
     else for (size_t i = 0; i < N; i++) slot_env[i] = (int32_t)i;                     // the identity map

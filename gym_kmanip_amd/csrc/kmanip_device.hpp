@@ -64,30 +64,35 @@ __host__ __device__ inline int select64(unsigned long long x, int k) {
   return pos;
 }
 // SPREAD: the env (index inside its 64-env block) that lane group `grp` of the block's wave `j` takes, from the block's masks:
-// M = heavy (a collider on or near the cube), T = a sphere on the table (a non-trivial arm problem: its iterations outlast a plain
-// one's).  Waves j < nh1 = min(popcount(M), waves per block) take the j-th heavy env into group 0; everything else is dealt in the
-// order [plain envs, then table envs] -- the heavy waves' other groups first -- so that a heavy env's wave-mates are the cheapest
-// envs of the block and the table envs sit together in the block's last waves (like with like: their loops run in lockstep).
-// EPB envs per wave, 64 / EPB waves per block.  A permutation of 0..63 for every (M, T).
-__host__ __device__ inline int spread_pick(unsigned long long M, unsigned long long T, int j, int grp, int EPB) {
-  const int WPB = 64 / EPB;
+// M = heavy (a collider on or near the cube); S1, S2 = the two bits of a cost score of the others (bit 0: the cube does not rest on
+// four corners -- a longer cube problem; bit 1: a sphere on the table -- a non-trivial arm problem whose iterations outlast a plain
+// one's).  Waves j < nh1 = min(popcount(M), waves per block) take the j-th heavy env into group 0; everything else is dealt in
+// ascending score order -- the heavy waves' other groups first -- so that a heavy env's wave-mates are the cheapest envs of the
+// block and envs of a kind sit together in the block's later waves (like with like: their loops run in lockstep).
+// EPB envs per wave, 64 / EPB waves per block.  A permutation of 0..63 whatever the masks are.
+__host__ __device__ inline int km_popc64(unsigned long long x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int nhb = __popcll(M);
+  return __popcll(x);
 #else
-  const int nhb = __builtin_popcountll(M);
+  return __builtin_popcountll(x);
 #endif
+}
+__host__ __device__ inline int spread_pick(unsigned long long M, unsigned long long S1, unsigned long long S2, int j, int grp, int EPB) {
+  const int WPB = 64 / EPB;
+  const int nhb = km_popc64(M);
   const int nh1 = nhb < WPB ? nhb : WPB;
   unsigned long long H = M;
   if (nhb > WPB) { const int pos = select64(M, WPB - 1); H = M & ((2ull << pos) - 1ull); }
   if (j < nh1 && grp == 0) return select64(H, j);
-  const unsigned long long C = ~H & ~T, B = ~H & T;
-#if defined(__HIP_DEVICE_COMPILE__)
-  const int nc = __popcll(C);
-#else
-  const int nc = __builtin_popcountll(C);
-#endif
-  const int k = j < nh1 ? (EPB - 1) * j + grp - 1 : (EPB - 1) * nh1 + EPB * (j - nh1) + grp;
-  return k < nc ? select64(C, k) : select64(B, k - nc);
+  int k = j < nh1 ? (EPB - 1) * j + grp - 1 : (EPB - 1) * nh1 + EPB * (j - nh1) + grp;
+  const unsigned long long cls[4] = {~H & ~S2 & ~S1, ~H & ~S2 & S1, ~H & S2 & ~S1, ~H & S2 & S1};
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int n = km_popc64(cls[c]);
+    if (k < n) return select64(cls[c], k);
+    k -= n;
+  }
+  return select64(cls[3], k);
 }
 
 __device__ __forceinline__ int xcd_block(int b, int nblocks) {

@@ -2536,18 +2536,19 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   // launch's dispatch list.  Looked up BEFORE the model is staged: the list's two dependent loads wait beside the staging's own.
   int slot = (st.slot_env ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x)) * EPB + grp;
   int env = -1;
-  unsigned long long heavy_mask = 0, table_mask = 0;
+  unsigned long long heavy_mask = 0, s1_mask = 0, s2_mask = 0;
   if (st.spread_in) {
     // SPREAD (KDeviceState): the 64 flags of this wave's block of 64 consecutive envs, one per lane (every lane votes: before any exit)
     const int blk = (slot - grp) / 64;
     const int fl = st.spread_in[blk * 64 + lane];
     heavy_mask = __ballot((fl & 1) != 0);
-    table_mask = __ballot((fl & 2) != 0);
+    s1_mask = __ballot((fl & 2) != 0);
+    s2_mask = __ballot((fl & 4) != 0);
   }
   if (grp >= EPB) {
   } else if (st.spread_in) {
     const int wv = (slot - grp) / EPB;                        // this wave's index in slot space (xcd_block keeps an XCD's waves together)
-    env = (wv / (64 / EPB)) * 64 + spread_pick(heavy_mask, table_mask, wv % (64 / EPB), grp, EPB);
+    env = (wv / (64 / EPB)) * 64 + spread_pick(heavy_mask, s1_mask, s2_mask, wv % (64 / EPB), grp, EPB);
   } else if (st.disp_in) {
     // dispatch list (KDeviceState; kmanip_api.hip): SPREAD, or the heavy-first experiment -- the first workgroups hold the envs
     // predicted heavy, disp_heavy_epb of them per wave (1: no wave-mates to wait for at the IK, at the solves, in the joint loop),
@@ -2656,7 +2657,12 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     fk_parallel<NL, G>(w, lm, sub);
     const int near_cube = collide_parallel<NL, G, true>(w, m, sub);
     heavy_next = near_cube;
-    table_next = st.spread_table && (w.contact_mask & KM_CON_ANY_SPHERE_TABLE) != 0;
+    // the cost score of an env that is not heavy (spread_pick): bit 1 a sphere on the table, bit 0 a cube that does not rest on four corners
+    // (KMANIP_SPREAD_TABLE, A/B: 0 no score; 1 the table bit only; 2 both as ONE class; 3 = default: both bits, four classes)
+    {
+      const int tb = (w.contact_mask & KM_CON_ANY_SPHERE_TABLE) != 0, cb = __popc(w.contact_mask & KM_CON_ANY_CUBE_TABLE) != 4;
+      table_next = st.spread_table == 0 ? 0 : st.spread_table == 1 ? 2 * tb : st.spread_table == 2 ? 2 * (tb | cb) : 2 * tb + cb;
+    }
     if constexpr (KM_WORK_COUNTERS(NL)) { if (sub == 0 && near_cube) w.work |= 1 << 30; }     // (bit 30: a collider on or close to the cube)
     rew = env_reward<NL, G>(w, m, sub);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
