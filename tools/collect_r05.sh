@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: every measurement profiles/r05_* is made from, into gpurun_out/r05/.
-# Usage: bash tools/collect_r05.sh [part ...]   parts: main sq final phase slow configs short soak misc waves multi (default: all)
+# Usage: bash tools/collect_r05.sh [part ...]   parts: main sq final phase slow configs short soak misc waves multi rccl spread behind (default: all but the last two)
 set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/r05
@@ -105,3 +105,24 @@ PY
   echo "rccl done"
 fi
 ls $OUT
+if has spread; then
+  # which envs share a wave: the default against heavy-only flags, table bit only, both bits as one class, and the identity map
+  B="python3 bench.py --steps 2048 --warmup 64 --no-variants --no-cpu-baseline"
+  for rep in 1 2; do
+    for v in "X=1" "KMANIP_SPREAD_TABLE=2" "KMANIP_SPREAD_TABLE=1" "KMANIP_SPREAD_TABLE=0" "KMANIP_SPREAD=0"; do
+      echo "== $v"
+      env $v $B 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg']['k_step'])"
+    done
+  done > $OUT/spread_ab.txt
+  python3 tests/tools/ik_persistence.py KManipSoloArm 4096 200 2>/dev/null | grep -v amdgpu > $OUT/ik_persistence.txt
+  echo "spread done"
+fi
+if has behind; then
+  # cameras rendered behind the steps (pipeline.RenderBehind): bench's render_behind variants, the overlap probe, the kernel trace
+  python3 tests/tools/render_overlap_probe.py 256 2>/dev/null | grep -v amdgpu > $OUT/render_overlap.txt
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/kt_behind -o rb -- python3 tests/tools/render_behind_run.py 64 > /dev/null 2>&1
+  f=$(find $OUT/kt_behind -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/trace_overlap.py $f > $OUT/render_behind_trace.txt
+  rm -rf $OUT/kt_behind
+  python3 tests/tools/depth_parity_soak.py 64 60 2>/dev/null | grep -v amdgpu > $OUT/depth_parity_soak.txt
+  echo "behind done"
+fi
