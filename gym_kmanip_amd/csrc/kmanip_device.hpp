@@ -481,14 +481,15 @@ struct KDeviceState {
   // EPB light envs each; at its end every env registers itself in disp_out for the NEXT launch (heavy = a collider on or within
   // KM_NEAR_MARGIN of the cube: the coupled Newton loop is on or about to start), and workgroup 0 clears the counters of disp_zero
   // (the table after next).  Three tables rotate on the host; any partition of the env ids is a valid table, and an env's bits
-  // depend neither on its slot nor on its wave-mates.
-  // SPREAD (the default of the four-envs-per-wave single-arm launch; kmanip_api.hip): one byte per env, "heavy at the end of its last
-  // step", written by every step into spread_out and read by the next launch from spread_in.  A wave looks at the 64 flags of ITS
-  // block of 64 consecutive envs (one ballot) and deals the block's envs to the block's waves so that no wave holds two heavy ones:
-  // a permutation inside the block, whatever the flags are -- the block's cache lines are the ones the identity map touches.
+  // depend neither on its slot nor on its wave-mates.  (The round-5 EXPERIMENT, KMANIP_HEAVY_DISPATCH=1; the product is SPREAD, below.)
+  // SPREAD (the default of the single-arm launches of two or four envs per wave; kmanip_api.hip): one byte per env -- bit 0 "heavy at
+  // the end of its last step", bits 1-2 a cost score of the others (spread_pick) -- written by every step into spread_out and read by the
+  // next launch from spread_in.  A wave looks at the 64 flags of ITS block of 64 consecutive envs (three ballots) and deals the block's
+  // envs to the block's waves so that no wave holds two heavy ones and a heavy env's wave-mates are the block's plainest envs: a
+  // permutation inside the block, whatever the flags are -- the block's cache lines are the ones the identity map touches.
   const uint8_t* spread_in;
   uint8_t* spread_out;
-  int spread_table;     // 1: the flags carry the second class too (a sphere on the table); 0 (KMANIP_SPREAD_TABLE=0, A/B): heavy only
+  int spread_table;     // which score the flags carry (KMANIP_SPREAD_TABLE, A/B): 3 = both bits (default), 2 = both as one class, 1 = the table bit, 0 = none
   const int32_t* disp_in;
   int32_t* disp_out;
   int32_t* disp_zero;
