@@ -22,9 +22,8 @@ for k in range(6):
     e.step_flat(e.sample_action())
     clk = np.zeros(n, dtype=np.uint64); slot = np.zeros(n, dtype=np.int32); work = np.zeros(n, dtype=np.int32)
     e.L.kmanip_dbg_wave_clocks(e.h, clk.ctypes.data_as(C.POINTER(C.c_ulonglong)), slot.ctypes.data_as(C.POINTER(C.c_int32)), work.ctypes.data_as(C.POINTER(C.c_int32)))
-    if not sorted_on:
-        nb = n // epb; b = np.arange(nb); xb = (b % 8) * (nb // 8) + b // 8      # xcd_block (nb divisible by 8 here)
-        slot = np.arange(n)                                                     # wave_clk is indexed by slot = xcd_block(b) * EPB + g
+    # (slot is the launch's own slot -> env map: the sorted order, the SPREAD deal of a single-arm handle, or the identity;
+    #  wave_clk is indexed by slot = wave index in slot space * EPB + lane group)
     nf = e.get_diag()[1].max(1)
     start = ((clk >> np.uint64(40)) & np.uint64(0xFFFFFF)).reshape(-1, epb)[:, 0].astype(np.int64)   # 100 MHz ticks, 24 bits
     clk = clk & np.uint64(0xFFFFFFFFFF)
