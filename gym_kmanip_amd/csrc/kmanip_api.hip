@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.23 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.24 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -247,6 +247,11 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   h->st.slot_env = nullptr;
   h->st.wave_clk = nullptr;
   h->st.spread_in = nullptr; h->st.spread_out = nullptr;
+  // "near the cube": what flags an env heavy (SPREAD) / sets the sort's proximity bit (k_sort_envs).  Swept on one box
+  // (profiles/r05_near_margin.txt): the single-arm launch is best at 1.5 cm (7.18 M; 1 cm 7.17, 2.5 cm 7.14, 0 = in contact only 7.01);
+  // the two-arm sort at 2.5-3 cm on the DualArm (3.91 -> 3.97 M) and flat on the Torso (4.86 / 4.85 / 4.83 M at 1.5 / 2.5 / 4 cm)
+  h->st.near_margin = nl > 10 ? 0.025 : 0.015;
+  if (const char* e = getenv("KMANIP_NEAR_MARGIN")) { const double v = atof(e); if (v >= 0 && v < 1) h->st.near_margin = v; }
   h->st.disp_in = nullptr; h->st.disp_out = nullptr; h->st.disp_zero = nullptr; h->st.disp_cap = 0; h->st.disp_heavy_epb = 1;
   h->wave_slots = num_envs;
   {

@@ -487,6 +487,7 @@ struct KDeviceState {
   // next launch from spread_in.  A wave looks at the 64 flags of ITS block of 64 consecutive envs (three ballots) and deals the block's
   // envs to the block's waves so that no wave holds two heavy ones and a heavy env's wave-mates are the block's plainest envs: a
   // permutation inside the block, whatever the flags are -- the block's cache lines are the ones the identity map touches.
+  double near_margin;   // "near the cube" for the heavy flag / the sort's proximity bit (KM_NEAR_MARGIN; KMANIP_NEAR_MARGIN, A/B)
   const uint8_t* spread_in;
   uint8_t* spread_out;
   int spread_table;     // which score the flags carry (KMANIP_SPREAD_TABLE, A/B): 3 = both bits (default), 2 = both as one class, 1 = the table bit, 0 = none

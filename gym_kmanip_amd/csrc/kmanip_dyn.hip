@@ -907,9 +907,9 @@ __device__ __forceinline__ bool over_table(const real (&tr)[4], const real* p) {
 
 // NEAR (the trailing mj_step1 of the two-arm kernels only): also report whether some collider is within KM_NEAR_MARGIN of the cube
 // without touching it -- the onset of the coupled Newton loop is what k_sort_envs' last-step counters cannot see coming
-#define KM_NEAR_MARGIN 0.015
+#define KM_NEAR_MARGIN 0.015      // (the default of callers that pass none; the handle's value is KDeviceState::near_margin: kmanip_api.hip)
 template <int NL, int G, bool NEAR = false>
-__device__ __forceinline__ int collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub) {
+__device__ __forceinline__ int collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub, real near_margin = KM_NEAR_MARGIN) {
   constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS, NST = Dim<NL>::NST;
   static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const KModelDesc* m, 
     w.cact = act; w.contact_mask = mask;
     w.touch_ct = (mask & KM_CON_ANY_CUBE_TABLE) != 0;
   }
-  if constexpr (NEAR) return gor<G>((int)(sub >= 8 && sub < 8 + nsph && d1 < KM_NEAR_MARGIN));
+  if constexpr (NEAR) return gor<G>((int)(sub >= 8 && sub < 8 + nsph && d1 < near_margin));
   return 0;
 }
 
@@ -2655,7 +2655,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
-    const int near_cube = collide_parallel<NL, G, true>(w, m, sub);
+    const int near_cube = collide_parallel<NL, G, true>(w, m, sub, st.near_margin);
     heavy_next = near_cube;
     // the cost score of an env that is not heavy (spread_pick): bit 1 a sphere on the table, bit 0 a cube that does not rest on four corners
     // (KMANIP_SPREAD_TABLE, A/B: 0 no score; 1 the table bit only; 2 both as ONE class; 3 = default: both bits, four classes)
