@@ -40,4 +40,4 @@ def test_trace_overlap_counts_what_runs_concurrently(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_overlap.py"), str(p)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.splitlines()
-    assert "100.0 %" in lines[0] and "  0.0 %" in lines[1] and "k_step dispatches: 8" in lines[2], out.stdout
+    assert "100.0 %" in lines[0] and ", 0.0 %" in lines[1] and "k_step dispatches: 8" in lines[2], out.stdout
