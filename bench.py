@@ -54,9 +54,14 @@ def parse_args(argv=None):
                     help="K > 1: the (reward, done) records of K steps per all-gather (dist.BlockRewardDoneGather) instead of one per step")
     ap.add_argument("--gather-direct", choices=["auto", "off", "stream", "side"], default="auto",
                     help="issue the (reward, done) all-gather as ncclAllGather through dist.RcclDirect -- on the step's own stream, or on a "
-                         "side stream tied to it by two events -- instead of through torch.distributed's wrapper (off).  auto: side on "
-                         "RCCL (the wrapper costs the step's stream 36 us per exchange on one MI355X, the side stream 19 us: "
-                         "profiles/r05_rccl_direct.txt), off on gloo")
+                         "side stream tied to it by two events -- instead of through torch.distributed's wrapper (off).  auto = off: "
+                         "torch.distributed's all_gather_into_tensor is the mainstream path and the default until the direct one has "
+                         "met two devices (it has only ever run at world size 1).  Opt in with --gather-direct side|stream or "
+                         "KMANIP_GATHER_DIRECT=side|stream (the wrapper costs the step's stream 36 us per exchange on one MI355X, "
+                         "the side stream 19 us: profiles/r05_rccl_direct.txt)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=float(os.environ.get("KMANIP_RENDEZVOUS_TIMEOUT", "90")),
+                    help="wall-clock bound in seconds on every start-up step that waits for the other ranks (init_process_group, the "
+                         "rank-count all-reduce, the direct communicator and its self-test): past it the rank prints one line and exits 6")
     ap.add_argument("--gather-depth", type=int, default=0,
                     help="ring of (reward, done) record buffers (dist.RewardDoneGather(depth=...)): a rank may run that many steps ahead "
                          "of the slowest one before it waits.  0: 16 on RCCL across ranks (an IK crawl is up to seven steps long; "
@@ -96,6 +101,49 @@ def stdout_to_stderr():
         sys.stdout.flush()
         os.dup2(saved, 1)
         os.close(saved)
+
+
+class Deadline:
+    """Wall-clock bound on a start-up step that waits for other ranks.  A rendezvous that HANGS (a peer that never arrives, an
+    IPC mode RCCL cannot use) raises nothing, so a try/except never sees it and the driver's own timeout would eat the whole
+    run: a watchdog thread prints a one-line diagnosis and ends THIS process with code 6 (os._exit: no re-exec, no retry in
+    the process; the parent -- spawn_ranks or torch.distributed.run -- then stops the peers).  The waits it guards release the
+    GIL (ctypes calls, torch's c10d store / stream synchronisation), so the thread gets to run."""
+    EXIT_CODE = 6
+
+    def __init__(self, what, seconds, rank=0, exit_code=None, _exit=os._exit):
+        self.what, self.seconds, self.rank = what, float(seconds), rank
+        self.code = self.EXIT_CODE if exit_code is None else exit_code
+        self._exit = _exit
+        self._timer = None
+
+    def _expired(self):
+        try:
+            sys.stderr.write("bench.py: rank %d: %s did not finish within %.0f s (a peer rank missing or hung, MASTER_ADDR/PORT, or "
+                             "HSA_ENABLE_IPC_MODE_LEGACY=%s) -- exiting %d\n"
+                             % (self.rank, self.what, self.seconds, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "<unset>"), self.code))
+            sys.stderr.flush()
+        finally:
+            self._exit(self.code)
+
+    def __enter__(self):
+        import threading
+        if self.seconds > 0:
+            self._timer = threading.Timer(self.seconds, self._expired)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
+def kmanip_env_vars():
+    """Every KMANIP_* variable set in this process's environment: several change the timed launch's shape (KMANIP_EPB,
+    KMANIP_SPREAD*, KMANIP_COST_SORT, ...) though never its results -- the bench line records them (`config.kmanip_env`)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("KMANIP_") and k != "KMANIP_BENCH_SPAWNED"}
 
 
 def free_port():
@@ -309,6 +357,16 @@ def cpu_baseline(cm, n_envs, budget_s=15.0):
         except Exception as e:  # noqa: BLE001
             out["mujoco_engine"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+def resolve_gather_direct(flag, env_value=None):
+    """(mode, who asked): --gather-direct auto is torch.distributed's wrapper ("off") -- the path every gloo / world-1 / two-rank
+    test runs -- unless KMANIP_GATHER_DIRECT names a direct mode; an explicit flag wins over the environment."""
+    if flag != "auto":
+        return flag, "flag"
+    if env_value in ("side", "stream"):
+        return env_value, "env"
+    return "off", None
 
 
 def check_ranks_seen(ranks_seen, world, rank):
@@ -578,9 +636,12 @@ def run_rank(args):
             os.environ["NCCL_MIN_NCHANNELS"] = "1"
             os.environ["NCCL_MAX_NCHANNELS"] = "1"
             os.environ["NCCL_NTHREADS"] = "64"
+        import datetime
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        with stdout_to_stderr():      # RCCL prints a five-line version banner to STDOUT when its communicator is created
-            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        # every start-up wait for the peers is bounded (Deadline): a hang becomes a one-line diagnosis and exit code 6
+        with stdout_to_stderr(), Deadline("init_process_group(%r)" % backend, args.rendezvous_timeout, rank):
+            # RCCL prints a five-line version banner to STDOUT when its communicator is created
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(args.rendezvous_timeout, 10.0)), **kw)
 
     if args.envs_total:
         assert args.envs_total % world == 0, "--envs-total must be a multiple of the GPU count (equal shards for the gather)"
@@ -594,19 +655,17 @@ def run_rank(args):
 
     gather = None
     ranks_seen = 1
+    gather_depth = None
     if dist is not None:
-        with stdout_to_stderr():      # (the communicator is created lazily, by the first collective)
+        with stdout_to_stderr(), Deadline("the rank-count all-reduce (first collective: RCCL creates its communicator here)", args.rendezvous_timeout, rank):
             t = torch.ones(1, device="cuda"); dist.all_reduce(t); ranks_seen = int(t.item())      # RCCL really spans all ranks
         rc = check_ranks_seen(ranks_seen, world, rank)
         if rc:
             return rc
         if not args.no_gather:
             from gym_kmanip_amd.dist import BlockRewardDoneGather, RewardDoneGather
-            direct = args.gather_direct
-            if direct == "auto":
-                direct = "side" if backend == "nccl" else "off"
-
-            depth = args.gather_depth if args.gather_depth > 0 else (16 if (backend == "nccl" and world > 1 and not args.gather_serial) else 2)
+            direct, opted_in = resolve_gather_direct(args.gather_direct, os.environ.get("KMANIP_GATHER_DIRECT"))
+            gather_depth = args.gather_depth if args.gather_depth > 0 else (16 if (backend == "nccl" and world > 1 and not args.gather_serial) else 2)
 
             def make_gather(direct):
                 d = direct if direct != "off" else False
@@ -614,19 +673,19 @@ def run_rank(args):
                     return BlockRewardDoneGather(n, world, torch.device("cuda", local_rank), dist, block=args.gather_every,
                                                  force_collective=args.rccl_world1, direct=d)
                 return RewardDoneGather(n, world, torch.device("cuda", local_rank), dist, force_collective=args.rccl_world1,
-                                        overlap=not args.gather_serial, direct=d, depth=depth)
-            ok = 1
+                                        overlap=not args.gather_serial, direct=d, depth=gather_depth)
             try:
-                with stdout_to_stderr():
+                # dist._make_direct moves the ranks in lock-step (agreement before and after the communicator is made), so a failure
+                # raises on every rank together; a HANG in ncclCommInitRank / the self-test ends the rank through the deadline
+                with stdout_to_stderr(), Deadline("the direct RCCL communicator (ncclCommInitRank + self-test)" if direct != "off"
+                                                  else "the (reward, done) gather's set-up", args.rendezvous_timeout, rank):
                     gather = make_gather(direct)
-            except Exception as ex:      # (librccl.so not where torch keeps it, a symbol missing: the same on every rank)
-                sys.stderr.write("bench.py: rank %d: direct RCCL exchange unavailable (%s)\n" % (rank, ex))
-                ok = 0
-            t = torch.tensor([ok], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 0:       # all ranks together: the exchange goes through torch.distributed's wrapper instead
-                if args.gather_direct != "auto":
-                    return 5
-                direct = "off"
+            except Exception as ex:  # noqa: BLE001
+                sys.stderr.write("bench.py: rank %d: %s (%s: %s)\n" % (rank, "direct RCCL exchange unavailable" if direct != "off" else
+                                                                      "the (reward, done) gather could not be set up", type(ex).__name__, ex))
+                if direct == "off" or opted_in == "flag":
+                    return 5                 # asked for on the command line: do not measure something else instead
+                direct = "off"               # asked for by environment only: every rank falls back to torch.distributed's wrapper
                 gather = make_gather(direct)
             args.gather_direct = direct
 
@@ -714,6 +773,9 @@ def run_rank(args):
                        "solver": args.solver, "solver_iterations": args.solver_iterations,
                        "sharding": "contiguous env-index blocks, 1 process per GPU",
                        "collective": (("async all_gather of (reward, done) per step" if args.gather_every <= 1 else "async all_gather of (reward, done), %d steps per exchange" % args.gather_every) + ("" if not args.gather_serial else ", step waits for its own exchange") + ("" if (args.gather_every > 1 or gather is None) else ", ring of %d records" % gather.depth) + ("" if args.gather_direct == "off" else ", ncclAllGather issued directly (%s)" % ("the step's stream" if args.gather_direct == "stream" else "side stream"))) if gather is not None else "none",
+                       "gather_direct": args.gather_direct if gather is not None else None, "gather_depth": getattr(gather, "depth", None) if gather is not None else None,
+                       "gather_every": args.gather_every if gather is not None else None,
+                       "kmanip_env": kmanip_env_vars(),       # diagnostic variables that shape the launch (never the results)
                        "rccl_ranks_seen": ranks_seen, "backend": backend if dist is not None else None, "library": version},
             "roofline": {"bound": "hbm", "bound_note": "the contract's two choices are hbm | mfma; this kernel is bound by FP64 VALU issue and dependent latency (see valu), its HBM fraction is small by construction",
                          "kernel": "k_step (before_step decode+IK fused with the 10 physics sub-steps)" + (" + k_render (in-step depth image)" if args.depth else (" + k_render_rgb (camera observations)" if rgb_bufs else "")), "achieved": achieved,
@@ -793,10 +855,12 @@ def run_rank(args):
     except Exception:  # noqa: BLE001
         pass
     if dist is not None:
-        dist.barrier()
-        if gather is not None:
-            gather.close()
-        dist.destroy_process_group()
+        # the measurement is out: a teardown that hangs must not cost the run its result (exit 0 from the watchdog)
+        with Deadline("the teardown barrier / destroy_process_group", args.rendezvous_timeout, rank, exit_code=0):
+            dist.barrier()
+            if gather is not None:
+                gather.close()
+            dist.destroy_process_group()
     return 0
 
 

@@ -266,8 +266,23 @@ def _direct_gather(g, b):
     return _SideWork(g.torch, sd.after_gather[b])
 
 
+def _all_agree(ok: bool, dist, world: int, torch, device) -> bool:
+    """True iff `ok` on EVERY rank (an all-reduce MIN through the existing process group; world 1: `ok`).  Every rank takes
+    part whatever its own `ok` is, so a rank whose local set-up failed never leaves its peers alone in the next collective."""
+    if world <= 1 or dist is None:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def _make_direct(direct, world, dist, device, force_collective):
-    """The RcclDirect communicator of a gather (None unless asked for and there is something to exchange)."""
+    """The RcclDirect communicator of a gather (None unless asked for and there is something to exchange).
+
+    The ranks move in lock-step: (1) each binds librccl.so and its symbols locally -- nothing that can wait for a peer --, then
+    all agree (all-reduce MIN) that every rank could; (2) only then the id broadcast and ncclCommInitRank, which need every
+    rank; (3) the self-test's verdict is agreed the same way, and a communicator that failed it on ANY rank is destroyed on
+    every rank.  So a failure raises on all ranks together and no rank is left waiting in a collective its peers never issue."""
     if not direct or not (world > 1 or force_collective):
         return None
     import torch
@@ -277,9 +292,20 @@ def _make_direct(direct, world, dist, device, force_collective):
         raise RuntimeError("direct=True needs the ranks on distinct GPUs (RCCL refuses two ranks on one device): backend 'nccl'")
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     with torch.cuda.device(device):
-        comm = RcclDirect(world, rank, dist)
-        if not comm.self_test(rank, device):
-            raise RuntimeError("RcclDirect: the test all-gather of the rank numbers came back wrong on rank %d" % rank)
+        err = None
+        try:
+            comm = RcclDirect.bind_library(world, rank)
+        except Exception as ex:  # noqa: BLE001   (library not where torch keeps it, a symbol missing)
+            comm, err = None, ex
+        if not _all_agree(comm is not None, dist, world, torch, device):
+            raise RuntimeError("RcclDirect: librccl.so could not be bound on %s (%s)" % ("rank %d" % rank if err else "a peer rank", err))
+        comm.init_rank(dist)
+        ok = comm.self_test(rank, device)
+        if not _all_agree(ok, dist, world, torch, device):
+            torch.cuda.synchronize()
+            comm.destroy()
+            raise RuntimeError("RcclDirect: the test all-gather of the rank numbers came back wrong on %s"
+                               % ("rank %d" % rank if not ok else "a peer rank"))
         return comm
 
 
@@ -312,17 +338,34 @@ class RcclDirect:
         _fields_ = [("internal", C.c_ubyte * 128)]
 
     def __init__(self, world: int, rank: int, dist=None, lib_path: Optional[str] = None):
+        """Bind the library and create the communicator (the two halves below, for callers that need no agreement between them)."""
+        self._bind(world, rank, lib_path)
+        self.init_rank(dist)
+
+    @classmethod
+    def bind_library(cls, world: int, rank: int, lib_path: Optional[str] = None) -> "RcclDirect":
+        """Local half only: dlopen + symbol lookups.  Cannot wait for a peer; raises OSError / AttributeError when it cannot be done."""
+        self = cls.__new__(cls)
+        self._bind(world, rank, lib_path)
+        return self
+
+    def _bind(self, world, rank, lib_path=None):
         import os
         import torch
         path = lib_path or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self.torch = torch
         self.comm = None
+        self.world, self.rank = world, rank
         self.L = L = C.CDLL(path)
         L.ncclGetUniqueId.argtypes = [C.POINTER(self._UniqueId)]
         L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self._UniqueId, C.c_int]
         L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.ncclCommDestroy.argtypes = [C.c_void_p]
         L.ncclGetErrorString.restype = C.c_char_p
+
+    def init_rank(self, dist=None):
+        """Collective half: rank 0's ncclUniqueId to every rank through `dist`, then ncclCommInitRank (a rendezvous of all ranks)."""
+        L, world, rank, torch = self.L, self.world, self.rank, self.torch
         uid = self._UniqueId()
         if rank == 0:
             self._chk(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
@@ -331,9 +374,9 @@ class RcclDirect:
             # (string_at: a c_char array FIELD reads back truncated at its first NUL byte)
             raw = share_bytes(C.string_at(C.byref(uid), 128) if rank == 0 else None, 128, dist, torch)
             C.memmove(C.byref(uid), raw, 128)
-        self.comm = C.c_void_p()
-        self._chk(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
-        self.world = world
+        comm = C.c_void_p()
+        self._chk(L.ncclCommInitRank(C.byref(comm), world, uid, rank), "ncclCommInitRank")
+        self.comm = comm
 
     def _chk(self, rc, what):
         if rc != 0:

@@ -78,3 +78,111 @@ def test_rank_path_refuses_a_collective_that_does_not_span_the_job(capsys):
     assert bench.check_ranks_seen(1, 8, 3) == 4
     err = capsys.readouterr().err
     assert "sees 1 rank(s), WORLD_SIZE is 8" in err and "rank 3" in err
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the N > 1 start-up cannot hang: every wait for the peers is under bench.Deadline (VERDICT r5 task 2)
+_HANG = r"""
+import sys, threading, time
+sys.path.insert(0, %r)
+import bench
+
+class FakeHangingBackend:                      # a rendezvous whose peer never arrives: blocks for ever, raises nothing
+    def init_process_group(self, *a, **k):
+        threading.Event().wait()
+
+t0 = time.time()
+try:
+    with bench.Deadline("init_process_group('fakehang')", 1.0, rank=3):
+        FakeHangingBackend().init_process_group("fakehang", rank=3, world_size=8)
+except BaseException as e:                     # the deadline must END the process, not raise into a handler that could retry
+    print("raised", type(e).__name__)
+print("survived", time.time() - t0)
+"""
+
+
+def test_deadline_ends_a_rank_whose_rendezvous_hangs():
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", _HANG % ROOT], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 6, (r.returncode, r.stderr[-500:])
+    assert "rank 3: init_process_group('fakehang') did not finish within 1 s" in r.stderr and "exiting 6" in r.stderr
+    assert r.stderr.count("\n") == 1                           # ONE line of diagnosis
+    assert "survived" not in r.stdout and "raised" not in r.stdout
+    assert time.time() - t0 < 60
+
+
+_GLOO_ALONE = r"""
+import datetime, os, sys
+sys.path.insert(0, %r)
+import bench
+import torch.distributed as dist
+with bench.Deadline("init_process_group('gloo')", 3.0, rank=0):      # rank 0 of a TWO-rank job whose rank 1 was never started
+    dist.init_process_group("gloo", rank=0, world_size=2, timeout=datetime.timedelta(seconds=600))
+print("survived")
+"""
+
+
+def test_deadline_ends_a_real_gloo_rendezvous_whose_peer_never_comes():
+    sys.path.insert(0, ROOT)
+    import bench
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(bench.free_port()), RANK="0", WORLD_SIZE="2")
+    r = subprocess.run([sys.executable, "-c", _GLOO_ALONE % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 6 and "did not finish within 3 s" in r.stderr and "survived" not in r.stdout, (r.returncode, r.stderr[-500:])
+
+
+def test_deadline_is_silent_when_the_step_finishes_and_teardown_exits_zero():
+    sys.path.insert(0, ROOT)
+    import time
+    import bench
+    fired = []
+    with bench.Deadline("quick", 5.0, rank=0, _exit=fired.append):
+        pass
+    time.sleep(0.05)
+    assert fired == []
+    with bench.Deadline("teardown", 0.05, rank=0, exit_code=0, _exit=fired.append):       # (after the JSON line: a hang must not cost the result)
+        time.sleep(0.5)
+    assert fired == [0]
+
+
+def test_parent_stops_the_peers_of_a_rank_that_hit_its_deadline(monkeypatch):
+    """A rank that exits 6 (its rendezvous deadline) must end the whole job: spawn_ranks kills the ranks still waiting."""
+    sys.path.insert(0, ROOT)
+    import bench
+    procs = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            self.rank = int(env["RANK"]); self.killed = False
+            procs.append(self)
+
+        def poll(self):
+            if self.rank == 1:
+                return 6                       # hit its deadline
+            return -9 if self.killed else None   # rank 0 would wait for ever
+
+        def kill(self):
+            self.killed = True
+
+        def wait(self, timeout=None):
+            return -9
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(bench.time, "sleep", lambda s: None)
+    assert bench.spawn_ranks(bench.parse_args(["--gpus", "2"]), ["--gpus", "2"]) == 1
+    assert procs[0].killed and not procs[1].killed
+
+
+def test_default_exchange_is_the_mainstream_path_and_the_line_records_the_knobs(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.parse_args([]).gather_direct == "auto" and bench.parse_args([]).rendezvous_timeout == 90.0
+    assert bench.resolve_gather_direct("auto") == ("off", None)                 # torch.distributed's all_gather_into_tensor
+    assert bench.resolve_gather_direct("auto", "side") == ("side", "env")       # opt-in by environment ...
+    assert bench.resolve_gather_direct("side") == ("side", "flag")              # ... or by flag
+    assert bench.resolve_gather_direct("off", "side") == ("off", "flag")        # an explicit flag wins
+    for k in [k for k in os.environ if k.startswith("KMANIP_")]:
+        monkeypatch.delenv(k)
+    assert bench.kmanip_env_vars() == {}
+    monkeypatch.setenv("KMANIP_EPB", "2"); monkeypatch.setenv("KMANIP_SPREAD", "0"); monkeypatch.setenv("KMANIP_BENCH_SPAWNED", "1")
+    assert bench.kmanip_env_vars() == {"KMANIP_EPB": "2", "KMANIP_SPREAD": "0"}

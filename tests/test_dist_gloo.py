@@ -262,3 +262,33 @@ def test_direct_exchange_is_a_device_path_only():
     for cls in (RewardDoneGather, BlockRewardDoneGather):
         with pytest.raises(RuntimeError, match="device path"):
             cls(4, 2, "cpu", None, direct="stream")
+
+
+def _agree_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from gym_kmanip_amd.dist import RcclDirect, _all_agree
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the local half of the direct communicator: rank 1 cannot bind its library (a path that does not exist)
+    try:
+        RcclDirect.bind_library(world, rank, lib_path=None if rank != 1 else "/nonexistent/librccl.so")
+        mine = True
+    except OSError:
+        mine = False
+    verdicts = [_all_agree(mine, dist, world, torch, "cpu"), _all_agree(True, dist, world, torch, "cpu")]
+    with open(os.path.join(out_dir, "agree%d.txt" % rank), "w") as f:
+        f.write("%s %s %s" % (mine, verdicts[0], verdicts[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_before_the_direct_communicator_is_made(tmp_path):
+    """dist._make_direct's lock-step: a rank that cannot bind librccl.so still takes part in the agreement, every
+    rank learns that ONE of them failed (so all raise together, before ncclCommInitRank could leave the others waiting), and
+    the next agreement is unaffected."""
+    import torch.multiprocessing as mp
+    mp.spawn(_agree_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    got = [open(os.path.join(str(tmp_path), "agree%d.txt" % r)).read().split() for r in range(3)]
+    assert [g[0] for g in got] == ["True", "False", "True"]          # only rank 1 failed locally ...
+    assert all(g[1] == "False" and g[2] == "True" for g in got)      # ... and every rank knows

@@ -35,13 +35,17 @@ def _run_ranks(out, world, extra):
     assert codes == [0] * world, codes
 
 
-@pytest.mark.parametrize("env_id,total,steps", [("KManipSoloArm", 512, 70), ("KManipTorso", 128, 66)])
-def test_two_ranks_match_one_rank_bitwise(tmp_path, env_id, total, steps):
+@pytest.mark.parametrize("env_id,total,steps,direct,depth", [("KManipSoloArm", 512, 70, "off", 2), ("KManipTorso", 128, 66, "off", 2),
+                                                             ("KManipSoloArm", 512, 70, "off", 16),      # bench.py's N > 1 default
+                                                             ("KManipSoloArm", 512, 70, "side", 16)])    # its opt-in direct exchange
+def test_two_ranks_match_one_rank_bitwise(tmp_path, env_id, total, steps, direct, depth):
     import torch
     assert torch.cuda.is_available()
     from gym_kmanip_amd import env_hip
     multi = torch.cuda.device_count() >= 2
-    extra = ["--env", env_id, "--total", str(total), "--steps", str(steps)]
+    if direct != "off" and not multi:
+        pytest.skip("the direct ncclAllGather exchange needs the two ranks on two GPUs (RCCL refuses two ranks on one device)")
+    extra = ["--env", env_id, "--total", str(total), "--steps", str(steps), "--direct", direct, "--depth", str(depth)]
     extra += ["--backend", "nccl"] if multi else ["--backend", "gloo", "--same-device"]
     _run_ranks(str(tmp_path), 2, extra)
     ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2)]
@@ -98,17 +102,26 @@ def test_rccl_device_collective_world1(tmp_path, every, direct, depth):
     ref.k_close()
 
 
-def test_bench_rccl_world1_line():
+@pytest.mark.parametrize("how", ["default", "flag_side", "env_side"])
+def test_bench_rccl_world1_line(how):
     """`python bench.py --rccl-world1`: the N = 1 bench as a one-rank RCCL job with the per-step all-gather forced through the
-    device collective (init_process_group("nccl"), the rank-count all-reduce, bind + before_step / post around every step)."""
+    device collective (init_process_group("nccl"), the rank-count all-reduce, bind + before_step / post around every step).
+    Default = torch.distributed's all_gather_into_tensor (the mainstream path, what an N > 1 run gets); the direct exchange is
+    opt-in by flag or by KMANIP_GATHER_DIRECT; the line records which one ran and every KMANIP_* variable that was set."""
     import json
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "KMANIP_GATHER_DIRECT")}
+    flags = ["--gather-direct", "side"] if how == "flag_side" else []
+    if how == "env_side":
+        env["KMANIP_GATHER_DIRECT"] = "side"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-world1", "--steps", "16", "--warmup", "4",
-                        "--envs-per-gpu", "4096", "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--envs-per-gpu", "4096", "--no-variants", "--no-cpu-baseline"] + flags, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks_seen"] == 1
     assert d["config"]["collective"].startswith("async all_gather") and d["value"] > 0
+    assert d["config"]["gather_direct"] == ("off" if how == "default" else "side") and d["config"]["gather_depth"] == 2
+    assert ("ncclAllGather issued directly" in d["config"]["collective"]) == (how != "default")
+    assert d["config"]["kmanip_env"].get("KMANIP_GATHER_DIRECT") == ("side" if how == "env_side" else None)
 
 
 @pytest.mark.parametrize("shape", ["solo_256", "config4_torso_8192"])
@@ -131,3 +144,6 @@ def test_bench_self_launch_two_ranks(tmp_path, shape):
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["scaling"] == "weak"
     assert d["config"]["envs_per_gpu"] == (256 if shape == "solo_256" else 8192) and d["value"] > 0 and d["steps"] == 8
     assert "collective" in d["config"] and d["config"]["collective"].startswith("async all_gather")
+    # default flags: the exchange goes through torch.distributed's wrapper (never the ctypes-made second communicator)
+    assert d["config"]["gather_direct"] == "off" and d["config"]["gather_depth"] == (16 if d["config"]["backend"] == "nccl" else 2)
+    assert set(d["config"]["kmanip_env"]) >= ({"KMANIP_BENCH_ONE_GPU", "KMANIP_BENCH_BACKEND"} if torch.cuda.device_count() < 2 else set())
