@@ -405,13 +405,16 @@ template <int K0, int N, class F> __device__ __forceinline__ void static_for(F&&
 
 // ---- optional phase profiler (diagnostic build only: make prof -> -DKM_PROFILE).  Stamps go to a buffer of
 // their own and never feed an output; the shipped library compiles every call away.
-#define KM_NPH 44
+#define KM_NPH 48
 #ifdef KM_PROFILE
 static __device__ unsigned long long g_prof[KM_NPH];   // one accumulator per variant object; kmanip_dbg_prof reads the Solo/Newton one
 #define KM_PROF_BLOCKS 4096
 static __device__ unsigned long long g_prof_blk[KM_PROF_BLOCKS][4][KM_NPH];   // last launch, per workgroup and lane group (who is slow?)
 struct Prof {
-  unsigned long long t0, acc[KM_NPH];
+  unsigned long long t0, it0, acc[KM_NPH];
+  // a second, independent stopwatch for spans that overlap the phase stamps (one Newton iteration, lone or beside wave-mates)
+  __device__ __forceinline__ void it_begin() { it0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void it_end(int i) { acc[i] += __builtin_amdgcn_s_memtime() - it0; }
   __device__ __forceinline__ void start() { for (int i = 0; i < KM_NPH; i++) acc[i] = 0; t0 = __builtin_amdgcn_s_memtime(); }
   __device__ __forceinline__ void ph(int i) {
     __builtin_amdgcn_sched_barrier(0);
@@ -429,6 +432,8 @@ struct Prof {
 struct Prof {
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void ph(int) {}
+  __device__ __forceinline__ void it_begin() {}
+  __device__ __forceinline__ void it_end(int) {}
   __device__ __forceinline__ void cnt(int, unsigned) {}
   __device__ __forceinline__ void flush() {}
 };

@@ -1977,6 +1977,10 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
       // The hand-over carries the problem the group is on, its cost so far and its iteration count.
       if (!__any(!two)) { *resume = prob; *rcost = cost; *riter = iter; return; }
     }
+#ifdef KM_PROFILE
+    const bool lone_it = JOINT && __popcll(__ballot(1)) <= 16;       // this group iterates alone: its wave-mates have left the loop
+    if constexpr (JOINT) pf.it_begin();
+#endif
     real p = 0;
     // The arm problem's quadratic rows are usually just single-dof rows (the two slider friction-loss rows; now and then a
     // joint at its limit) -- no sphere on the table.  Its Hessian is then M + diag(delta) with at most two nonzero deltas, and
@@ -2199,6 +2203,9 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
     const real improvement = scale * (cost - cost_new), gradient = scale * km_sqrt(cg[1]);
     cost = cost_new;
     pf.ph(14 + 6 * S);
+#ifdef KM_PROFILE
+    if constexpr (JOINT) { if (prob == KM_SUB_ALL) { pf.cnt(lone_it ? 44 : 45, 1); pf.it_end(lone_it ? 46 : 47); } }
+#endif
     if (improvement < tol || gradient < tol || w.bad || iter + 1 >= maxit) {
       if (!(JOINT && prob == KM_SUB_ARM)) break;
       enter(KM_SUB_CUBE); cost = cost_b;        // an uncoupled env of the joint loop: on to its cube problem

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("KMANIP_LIB", os.path.join(ROOT, "gym_kmanip_amd", "libkmanip_hip_prof.so"))
 import numpy as np, torch
 from gym_kmanip_amd import env_hip
-NPH = 44
+NPH = 48
 names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mass", "build_constraints", "solve (PGS)", "newton: a_s",
          "newton: start evals"] + ["newton %s: %s" % (sb, ph) for sb in ("ALL", "ARM", "CUBE") for ph in ("H build", "chol", "tri-solve", "ls setup", "ls loop", "eval")] + [
          "integrate", "post-solve (sibling wait)", "load state", "before_step (decode + IK)", "tail (reward/obs/store)", "auto-reset",
@@ -14,7 +14,9 @@ names = ["fk", "bias bodies", "collide", "composite+mass+bias_proj", "invert_mas
          "newton: start eval at qacc_smooth (when it beats the warm start)", "invert_mass: row loads (two-arm block path)"]
 names += ["-"] * (40 - len(names))
 names += ["newton: waiting for wave-mates in a loop this env does not run (divergence)", "COUNT coupled-env iterations on the partial refactorisation",
-          "COUNT coupled-env iterations on the full factorisation", "COUNT wave-mates' non-plain iterations in the joint loop: partial + 65536 * full"]
+          "COUNT coupled-env iterations on the full factorisation", "COUNT wave-mates' non-plain iterations in the joint loop: partial + 65536 * full",
+          "COUNT coupled-env iterations run ALONE (wave-mates out of the joint loop)", "COUNT coupled-env iterations beside wave-mates",
+          "CYCLES of the coupled env's iterations run alone", "CYCLES of the coupled env's iterations beside wave-mates"]
 solver = sys.argv[1] if len(sys.argv) > 1 else "newton"
 env_id = sys.argv[2] if len(sys.argv) > 2 else "KManipSoloArm"          # 20-link ids: totals only (no per-workgroup view)
 n = 4096
@@ -43,10 +45,10 @@ prof(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
 nblocks = n // epb
 per = v / nblocks / steps            # cycles (100 MHz memtime ticks?) per block per control step
-tot = per.sum()
+tot = per[:41].sum()       # (slots 41.. are event counters and the iteration stopwatch, not phases)
 print("solver", solver, "total ticks per block per step %.0f" % tot)
 for nm, x in zip(names, per):
-    if nm.startswith("COUNT"):
+    if nm.startswith("COUNT") or nm.startswith("CYCLES"):
         print("  %-26s %10.4f" % (nm, x))
     else:
         print("  %-26s %10.0f  %5.1f%%" % (nm, x, 100 * x / tot))
@@ -59,12 +61,12 @@ if env.cm.nlink == 10 and hasattr(L, "kmanip_dbg_prof_blocks") and L.kmanip_dbg_
     B = np.array(list(blk), dtype=np.float64).reshape(nb, 4, NPH)
     if os.environ.get("KM_PHASE_DUMP"):
         np.save(os.environ["KM_PHASE_DUMP"], B)
-    tot_b = B[:, 0, :].sum(1)                       # wave lifetime as seen by lane group 0
+    tot_b = B[:, 0, :41].sum(1)                       # wave lifetime as seen by lane group 0
     order = np.argsort(tot_b)
     print("last launch: wave totals  mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f" % (
         tot_b.mean(), np.median(tot_b), np.percentile(tot_b, 90), np.percentile(tot_b, 99), tot_b.max()))
     newton = list(range(9, 27))
-    work = B.copy(); work[:, :, 28] = 0; work[:, :, 31] = 0; work[:, :, 40] = 0     # drop the wait / tail slots: a group's OWN work
+    work = B.copy(); work[:, :, 28] = 0; work[:, :, 31] = 0; work[:, :, 40:] = 0     # drop the wait / tail slots: a group's OWN work
     own = work.sum(2)                                            # [nb, 4]
     slow_g = own.argmax(1)
     slow = order[-10:]
