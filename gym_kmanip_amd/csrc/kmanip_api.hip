@@ -48,6 +48,7 @@ struct KHandle_ {
   int32_t* disp_tab[3] = {nullptr, nullptr, nullptr};
   unsigned disp_k = 0;
   int wave_slots = 0;           // entries of st.wave_clk (one per lane group of the step launch's grid)
+  int last_epb = 0;             // envs per wave of the LAST step launch (a chunk launch always takes the full shape): what the slot -> env maps of kmanip_dbg_wave_clocks are rebuilt with
   std::vector<void*> allocs;
 };
 
@@ -348,7 +349,7 @@ int kmanip_reset(KHandle h, const uint8_t* mask_dev, double* obs_dev, void* stre
 }
 
 // Diagnostics (include/kmanip_debug.h, not part of the boundary; KMANIP_WAVE_CLOCKS=1 at create): per wave slot, the ticks its wave spent in the last
-// k_step, the env it held, that env's work counter and IK evaluation counts -- HOST arrays of num_envs entries.  Synchronous.
+// k_step and the env it held -- HOST arrays of kmanip_dbg_wave_slots(h) entries --, and every env's work counter (num_envs entries).  Synchronous.
 int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env, int32_t* work) {
   if (!h) return -1;
   if (clk && !h->st.wave_clk) { h->err = "kmanip_dbg_wave_clocks: clk needs KMANIP_WAVE_CLOCKS=1 at create"; return -1; }
@@ -361,7 +362,7 @@ int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env
       // heavy-first dispatch: rebuild the LAST launch's slot -> env map (4 slots per workgroup, -1 = empty lane group) from its table
       std::vector<int32_t> tab(KM_DISP_HDR + N);
       HIPCHK(h, hipMemcpy(tab.data(), h->disp_tab[(h->disp_k + 2) % 3], sizeof(int32_t) * (KM_DISP_HDR + N), hipMemcpyDeviceToHost));
-      const int epb = h->num_envs >= 4096 ? 4 : 2, hepb = h->st.disp_heavy_epb;
+      const int epb = h->last_epb ? h->last_epb : km_step_epb(h->num_envs, 4, 1), hepb = h->st.disp_heavy_epb;
       const int nh = tab[0] < h->st.disp_cap ? tab[0] : h->st.disp_cap, nhw = hepb ? (nh + hepb - 1) / hepb : 0;
       for (int sl = 0; sl < h->wave_slots; sl++) {
         const int b = sl / epb, grp = sl % epb;
@@ -375,8 +376,7 @@ int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env
       // SPREAD: the LAST launch's map from the flags it read (slot = wave index in slot space x envs per wave + lane group)
       std::vector<uint8_t> fl(N);
       HIPCHK(h, hipMemcpy(fl.data(), h->spread_flags[(h->spread_k + 1) & 1], N, hipMemcpyDeviceToHost));
-      int epb = h->num_envs >= 4096 ? 4 : 2;
-      if (const char* e = getenv("KMANIP_EPB")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) epb = v < epb ? v : epb; }
+      const int epb = h->last_epb ? h->last_epb : km_step_epb(h->num_envs, 4, 1);      // (a chunk launch at 2048 envs runs four envs per wave, a step two)
       for (size_t blk = 0; blk < N / 64; blk++) {
         unsigned long long M = 0, S1 = 0, S2 = 0;
         for (int i = 0; i < 64; i++) {
@@ -436,6 +436,7 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
     h->st.disp_in = h->disp_tab[h->disp_k % 3]; h->st.disp_out = h->disp_tab[(h->disp_k + 1) % 3]; h->st.disp_zero = h->disp_tab[(h->disp_k + 2) % 3];
     h->disp_k++;
   }
+  h->last_epb = km_step_epb(h->num_envs, h->desc.nlink <= 10 ? 4 : 2, nchunk);
   if (tm) HIPCHK(h, hipEventRecord(ev[1], s));        // (fused path: two events per step, each costs the stream a barrier packet)
   kmanip_launch_step(h->dmodel, h->desc, h->st, split ? nullptr : act_dev, obs_dev, reward_dev, done_dev, nchunk, s);
   if (tm) HIPCHK(h, hipEventRecord(ev[2], s));

@@ -2,6 +2,7 @@
 // Arithmetic type is double: the reference computes in float64 (MuJoCo mjtNum, OBS_DTYPE
 // gym_kmanip/__init__.py:50) and MI355X runs FP64 FMA at half the FP32 vector rate.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -527,6 +528,19 @@ void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, 
 // up to KM_MAX_CAMS camera images of every env in ONE launch (grid = envs x jobs): the *Vision observation
 struct KRenderJobs { int n; int cam[KM_MAX_CAMS], height[KM_MAX_CAMS], width[KM_MAX_CAMS]; uint8_t* rgb[KM_MAX_CAMS]; };
 void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, const KRenderJobs& jobs, hipStream_t stream);
+// envs per workgroup (= per wave) of a step / reset launch: as many waves as the chip has SIMD slots for, but no more lanes idle than
+// needed; the chunked kernel exists for the full shape only.  Shared by the launchers (kmanip_dyn.hip) and by the host code that
+// has to know the LAST launch's shape (kmanip_api.hip: the slot -> env maps of kmanip_dbg_wave_clocks).
+#define KM_TARGET_WAVES 1024   // 256 CUs x 4 SIMDs: below this many workgroups, fewer envs per wave fills more SIMDs
+static inline int km_pick_epb(int num_envs, int max_epb) {
+  const char* e = getenv("KMANIP_EPB");              // diagnostic override (tests exercise every launch shape)
+  const int forced = e ? atoi(e) : 0;
+  if (forced > 0) return forced < max_epb ? forced : max_epb;
+  int epb = max_epb;
+  while (epb > 1 && (num_envs + epb - 1) / epb < KM_TARGET_WAVES) epb >>= 1;
+  return epb;
+}
+static inline int km_step_epb(int num_envs, int max_epb, int nchunk) { return nchunk > 1 ? max_epb : km_pick_epb(num_envs, max_epb); }
 // slot_env[s] = the env wave slot s handles, envs ordered by the cost their LAST step predicts, heaviest first (LPT dispatch)
 struct KCostWeights { int ik, work, coupled, armtab, cubetab, binw; };
 void kmanip_launch_sort_envs(const KDeviceState& st, int32_t* slot_env, const KCostWeights& w, hipStream_t stream);

@@ -34,7 +34,6 @@
 // tree loops over link candidates (static addresses + a mask bit each): fully unrolled for the 10-link model, where all the
 // loads can be in flight together; the 20-link models sit at the 512-register limit and keep them rolled
 #define KM_TREE_UNROLL(NL) NL <= 10 ? NL : 1
-#define KM_TARGET_WAVES 1024   // 256 CUs x 4 SIMDs: below this many workgroups, fewer envs per wave fills more SIMDs
 
 // Work units one Newton iteration of each kind adds to Ws::work (roughly kilo-clocks on the two-arm kernels; only their ORDER
 // matters: k_sort_envs ranks the envs by them).  Two-arm kernels only: the single-arm headline launch is one residency round.
@@ -2777,15 +2776,6 @@ __global__ __launch_bounds__(64) void k_observe(const KDeviceModel* __restrict__
   if (sub == 0) { st.contact_mask[env] = w.contact_mask; if (reward) reward[env] = rew; }
 }
 
-// envs per workgroup: as many waves as the chip has SIMD slots for, but no more lanes idle than needed.
-static int pick_epb(int num_envs, int max_epb) {
-  const char* e = getenv("KMANIP_EPB");              // diagnostic override (tests exercise every launch shape)
-  const int forced = e ? atoi(e) : 0;
-  if (forced > 0) return forced < max_epb ? forced : max_epb;
-  int epb = max_epb;
-  while (epb > 1 && (num_envs + epb - 1) / epb < KM_TARGET_WAVES) epb >>= 1;
-  return epb;
-}
 template <int NL, int G, int SOLVER, int EPB>
 static void launch_step_e(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, int nchunk, hipStream_t stream) {
   if (nchunk > 1) {
@@ -2803,14 +2793,14 @@ static void launch_reset_e(const KDeviceModel* dm, const KDeviceState& st, const
 }
 template <int NL, int G, int SOLVER>
 static void launch_step_t(const KDeviceModel* dm, const KDeviceState& st, const float* act, double* obs, double* reward, uint8_t* done, int nchunk, hipStream_t stream) {
-  const int epb = nchunk > 1 ? 64 / G : pick_epb(st.num_envs, 64 / G);      // (the chunked kernel exists for the full shape only)
+  const int epb = km_step_epb(st.num_envs, 64 / G, nchunk);
   if constexpr (64 / G >= 4) if (epb == 4) return launch_step_e<NL, G, SOLVER, 4>(dm, st, act, obs, reward, done, nchunk, stream);
   if (epb == 2) return launch_step_e<NL, G, SOLVER, 2>(dm, st, act, obs, reward, done, nchunk, stream);
   launch_step_e<NL, G, SOLVER, 1>(dm, st, act, obs, reward, done, nchunk, stream);
 }
 template <int NL, int G, int SOLVER>
 static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const uint8_t* mask, double* obs, hipStream_t stream) {
-  const int epb = pick_epb(st.num_envs, 64 / G);
+  const int epb = km_pick_epb(st.num_envs, 64 / G);
   if constexpr (64 / G >= 4) if (epb == 4) return launch_reset_e<NL, G, SOLVER, 4>(dm, st, mask, obs, stream);
   if (epb == 2) return launch_reset_e<NL, G, SOLVER, 2>(dm, st, mask, obs, stream);
   launch_reset_e<NL, G, SOLVER, 1>(dm, st, mask, obs, stream);

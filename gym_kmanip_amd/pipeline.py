@@ -137,6 +137,12 @@ class RenderBehind:
             env.step_flat(policy_from_state(env.obs))
             rb.after_step()                          # snapshot + render of step t, behind
             if t: log(rb.images(t - 1))              # dict name -> uint8 [n, h, w, 3]; current stream ordered after that render
+
+    CONTRACT of images(): it returns the LIVE ring buffers of that step, not copies -- two image sets exist, and the render of step
+    k + 2 rewrites set k & 1.  The reads a consumer enqueues on the stream it called images() from, before the second following
+    after_step(), are safe: that after_step() makes the render stream wait for every stream images(k) was called from before it
+    rewrites the set (for the step's own stream the snapshot copy already orders it).  A dict kept ACROSS two after_step() calls, or
+    read from a stream images() never saw, shows torn or newer images: clone what has to live longer.
     """
 
     def __init__(self, env, cams=None, depth=None):
@@ -150,6 +156,7 @@ class RenderBehind:
         self.copied = [torch.cuda.Event() for _ in range(2)]
         self.rendered = [torch.cuda.Event() for _ in range(2)]
         self._used = [False, False]
+        self._readers = [set(), set()]            # streams images() handed set s to since its last render
 
     def _render(self, out):
         bufs = dict(self.env.render_cameras(self.cams, out=out)) if (self.cams is None or len(self.cams)) else {}
@@ -168,6 +175,10 @@ class RenderBehind:
         env.snapshot_render_state(s)
         self.copied[s].record(cur)
         self.stream.wait_event(self.copied[s])
+        for st in self._readers[s]:                   # consumers of set s on other streams: their reads come before the rewrite
+            if st != cur:
+                self.stream.wait_stream(st)
+        self._readers[s].clear()
         env.set_render_source(s)
         try:
             with torch.cuda.stream(self.stream):
@@ -180,11 +191,14 @@ class RenderBehind:
         return self.k - 1
 
     def images(self, step: int):
-        """Image set of `step` (one of the last two after_step calls); the current stream waits for its render."""
+        """Image set of `step` (one of the last two after_step calls): the live ring buffers (see the class docstring's CONTRACT);
+        the current stream waits for the step's render, and the render that will rewrite the set waits for the current stream."""
         if not (self.k - 2 <= step < self.k) or step < 0:
             raise ValueError("RenderBehind keeps the images of the last two steps (asked for %d, at %d)" % (step, self.k))
         s = step & 1
-        self.torch.cuda.current_stream(self.env.device).wait_event(self.rendered[s])
+        cur = self.torch.cuda.current_stream(self.env.device)
+        cur.wait_event(self.rendered[s])
+        self._readers[s].add(cur)
         return self.bufs[s]
 
     def synchronize(self):

@@ -14,10 +14,12 @@ extern "C" {
 #endif
 
 /* Product build.  With KMANIP_WAVE_CLOCKS=1 in the environment at kmanip_create: per wave slot, the s_memtime ticks its wave
- * spent in the last k_step (clk, HOST unsigned long long[num_envs]); always: the env each dispatch slot held (slot_env, HOST
- * int32[num_envs]: the order k_sort_envs chose, the identity when the handle does not sort) and every env's work counter of
- * its last step (work, HOST int32[num_envs]; zero on the single-arm kernel, which ships without the counters).  Any pointer
- * may be NULL; clk needs the environment variable (an error otherwise).  Synchronous. */
+ * spent in the last k_step (clk, HOST unsigned long long[S]); always: the env each dispatch slot held in the LAST step launch
+ * (slot_env, HOST int32[S]: the order k_sort_envs chose, the SPREAD map of that launch's shape, the identity otherwise) and every
+ * env's work counter of its last step (work, HOST int32[num_envs]; zero on the single-arm kernel, which ships without the
+ * counters).  S = kmanip_dbg_wave_slots(h) -- size clk and slot_env from THAT call, not from num_envs: a handle with the
+ * heavy-first dispatch has more lane groups than envs.  Any pointer may be NULL; clk needs the environment variable (an error
+ * otherwise).  Synchronous. */
 KMANIP_API int kmanip_dbg_wave_clocks(KHandle h, unsigned long long* clk, int32_t* slot_env, int32_t* work);
 /* Entries of the clk / slot_env arrays above: num_envs, or -- on a handle with the heavy-first dispatch (kmanip.h, launch shape),
  * whose grid has more lane groups than envs -- 4 per workgroup of the largest grid; slot_env is -1 for a lane group that held no env. */

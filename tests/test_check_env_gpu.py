@@ -322,6 +322,24 @@ def test_render_behind_gives_the_images_of_its_step():
             assert torch.equal(got[k][c], want[k][c]), (k, c)
     with pytest.raises(ValueError):
         rb.images(steps - 3)
+    # a consumer on a stream of its own: the render that rewrites set k & 1 waits for the reads enqueued there
+    side = torch.cuda.Stream()
+    got2 = []
+    for k in range(steps):
+        a.step_flat(acts[k]); b.step_flat(acts[k])
+        j = rb.after_step()
+        with torch.cuda.stream(side):
+            imgs = rb.images(j)
+            for _ in range(4):                          # (a slow consumer: the clone sits behind other work on its stream)
+                torch.mm(torch.ones(512, 512, device="cuda"), torch.ones(512, 512, device="cuda"))
+            got2.append({c: img.clone() for c, img in imgs.items()})
+        want2 = {c: img.clone() for c, img in b.render_cameras().items()}
+        want2["depth"] = b.render_depth("grip_r", 64, 64).clone()
+        want.append(want2)
+    torch.cuda.synchronize()
+    for k in range(steps):
+        for c in want[steps + k]:
+            assert torch.equal(got2[k][c], want[steps + k][c]), (k, c)
     # depth through a snapshot, and back to the live state
     d_live = a.render_depth("grip_r", 64, 64).clone()
     a.snapshot_render_state(0)

@@ -11,7 +11,8 @@ b = env_hip.make("KManipSoloArm", num_envs=n, seed=7)
 del os.environ["KMANIP_SPREAD"]
 a.k_reset(); b.k_reset()
 ph = (np.arange(n) % 64).astype(np.int32); a.set_state(step=ph); b.set_state(step=ph)
-slot = np.zeros(n, dtype=np.int32); moved = 0
+slot = np.zeros(a.L.kmanip_dbg_wave_slots(a.h), dtype=np.int32); moved = 0
+assert len(slot) == n
 for k in range(steps):
     act = a.sample_action().clone()
     a.step_flat(act); b.step_flat(act)

@@ -16,7 +16,9 @@ w.lay_out(steps)
 T = np.zeros((steps, n // epb))
 for k in range(steps):
     w.step()
-    clk = np.zeros(n, dtype=np.uint64); slot = np.zeros(n, dtype=np.int32); work = np.zeros(n, dtype=np.int32)
+    S = env.L.kmanip_dbg_wave_slots(env.h)       # entries of clk / slot_env (include/kmanip_debug.h): more than n with the heavy-first dispatch
+    assert S == n, "this tool reads the plain grid (unset KMANIP_HEAVY_DISPATCH / KMANIP_HEAVY_EPB)"
+    clk = np.zeros(S, dtype=np.uint64); slot = np.zeros(S, dtype=np.int32); work = np.zeros(n, dtype=np.int32)
     env.L.kmanip_dbg_wave_clocks(env.h, clk.ctypes.data_as(C.POINTER(C.c_ulonglong)), slot.ctypes.data_as(C.POINTER(C.c_int32)), work.ctypes.data_as(C.POINTER(C.c_int32)))
     T[k] = (clk & np.uint64(0xFFFFFFFFFF)).reshape(-1, epb)[:, 0].astype(np.float64)      # (wave slots are fixed at 4096 envs: no cost sort)
 per_step = T.max(1).sum()

@@ -20,7 +20,9 @@ for k in range(6):
     e.L.kmanip_dbg_wave_clocks(e.h, None, None, pre_work.ctypes.data_as(C.POINTER(C.c_int32)))
     pre_nf = e.get_diag()[1].max(1)
     e.step_flat(e.sample_action())
-    clk = np.zeros(n, dtype=np.uint64); slot = np.zeros(n, dtype=np.int32); work = np.zeros(n, dtype=np.int32)
+    S = e.L.kmanip_dbg_wave_slots(e.h)           # entries of clk / slot_env (include/kmanip_debug.h): more than n with the heavy-first dispatch
+    assert S == n, "this tool reads the plain grid (unset KMANIP_HEAVY_DISPATCH / KMANIP_HEAVY_EPB; tests/tools/wave_times_dispatch.py handles those)"
+    clk = np.zeros(S, dtype=np.uint64); slot = np.zeros(S, dtype=np.int32); work = np.zeros(n, dtype=np.int32)
     e.L.kmanip_dbg_wave_clocks(e.h, clk.ctypes.data_as(C.POINTER(C.c_ulonglong)), slot.ctypes.data_as(C.POINTER(C.c_int32)), work.ctypes.data_as(C.POINTER(C.c_int32)))
     # (slot is the launch's own slot -> env map: the sorted order, the SPREAD deal of a single-arm handle, or the identity;
     #  wave_clk is indexed by slot = wave index in slot space * EPB + lane group)
