@@ -83,6 +83,10 @@ struct LModel {
   // solimp of the two parameter sets, clamped like mj_makeImpedance clamps it, with the reciprocals the spline divides by
   // (mode 0: constant (d0 + dw) / 2; 1: linear; 2: MuJoCo's default quadratic spline)
   struct Imp { real d0, dw, iw, mid, imid, i1mid; int mode; } imp[2];
+  // collision candidates (round 6): link, centre, radius and capsule segment of sphere s were per-lane GLOBAL loads in every
+  // sub-step's narrow phase (and the link again, behind an LDS load, for every active sphere slot of the constraint assembly)
+  int sph_link[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1], nsph;
+  real sph_pos[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1][3], sph_rad[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1], sph_seg[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1][3];
 };
 
 // friction coefficient k (0, 1: tangential, 2: torsional) of contact slot kind `kind`: pairs with the cube use the mixed cube
@@ -518,20 +522,33 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
       N[0] += t[0]; N[1] += t[1]; N[2] += t[2];
     }
     const uint32_t am = lm.anc[j];
+    // Round 6: one basic block.  With the stores inside `if (i <= j)` the compiler sank each row's six LDS loads into that row's
+    // conditional block: ten load -> wait -> compute -> store round trips in a row (one wave per SIMD: nothing hides them).  Now every
+    // row's entry is stored unconditionally -- rows this lane does not own go to a scratch slot of its own (w.tmp[j], not live before
+    // the solve) -- so nothing is conditional, and the scheduler issues the rows' loads together.  Same operations, same bits.
+    real mcol[W];
 #pragma unroll
     for (int c = 0; c < W; c++) {
-      const int i = base + c;                  // rows of the block only: M has no entries between blocks
-      if (W != NL && i >= NL) continue;
+      const int i = base + c < NL ? base + c : NL - 1;      // rows of the block only: M has no entries between blocks (clamped: never stored)
       const real ai[3] = {w.k.axis[i][0], w.k.axis[i][1], w.k.axis[i][2]};
       const real oi[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
       cross3(t, oi, F);
       const real mo[3] = {N[0] - t[0], N[1] - t[1], N[2] - t[2]};
       const real val = lm.jtype[i] == KM_JNT_SLIDE ? dot3(ai, F) : dot3(ai, mo);
-      const real mij = ((am >> i) & 1u) ? val : 0.0;
-      if (i <= j) {                            // both triangles: the inversion then reads plain rows; entry (a, b) is written
-        w.Minv[i][j] = mij;                    // by the lane of link max(a, b) only
-        w.Minv[j][i] = mij;
-      }
+      mcol[c] = ((am >> i) & 1u) ? val : 0.0;
+    }
+    // (scheduling hint for the block above: all the rows' LDS reads first, then the arithmetic)
+    __builtin_amdgcn_sched_group_barrier(0x100, 8 * W, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 64 * W, 0);
+#pragma unroll
+    for (int c = 0; c < W; c++) {
+      const int i = base + c;
+      if (W != NL && i >= NL) continue;
+      // both triangles: the inversion then reads plain rows; entry (a, b) is written by the lane of link max(a, b) only
+      real* const up = i <= j ? &w.Minv[i][j] : &w.tmp[j];
+      real* const lo = i <= j ? &w.Minv[j][i] : &w.tmp[j];
+      *up = mcol[c];
+      *lo = mcol[c];
     }
     // bias_j = axis_j . (subtree wrench about the joint)
     const real Fb[3] = {acc[10], acc[11], acc[12]};
@@ -908,7 +925,7 @@ __device__ __forceinline__ bool over_table(const real (&tr)[4], const real* p) {
 // without touching it -- the onset of the coupled Newton loop is what k_sort_envs' last-step counters cannot see coming
 #define KM_NEAR_MARGIN 0.015      // (the default of callers that pass none; the handle's value is KDeviceState::near_margin: kmanip_api.hip)
 template <int NL, int G, bool NEAR = false>
-__device__ __forceinline__ int collide_parallel(Ws<NL>& w, const KModelDesc* m, int sub, real near_margin = KM_NEAR_MARGIN) {
+__device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub, real near_margin = KM_NEAR_MARGIN) {
   constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS, NST = Dim<NL>::NST;
   static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
@@ -936,17 +953,17 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const KModelDesc* m, 
       mask |= KM_CON_CUBE_TABLE(sub); act |= 1u << n;
     }
   }
-  const int nsph = m->nsphere < NSPH ? m->nsphere : NSPH;
+  const int nsph = lm.nsph;
   const int s = sub - 8;
   bool hitc = false, hitt = false;
   real ctr[3] = {0, 0, 0}, ctrt[3] = {0, 0, 0}, nloc[3] = {0, 0, 0}, d1 = 0, d2 = 0, rad = 0;
   if (sub >= 8 && sub < 8 + nsph) {
-    const int l = m->sphere_link[s];
-    real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, rel[3], loc[3], cl[3];
+    const int l = lm.sph_link[s];
+    real sl[3] = {lm.sph_pos[s][0], lm.sph_pos[s][1], lm.sph_pos[s][2]}, rel[3], loc[3], cl[3];
     mat_vec3(ctr, w.k.xmat[l], sl);
 #pragma unroll
     for (int a = 0; a < 3; a++) ctr[a] += w.k.xpos[l][a];
-    rad = m->sphere_radius[s];
+    rad = lm.sph_rad[s];
     // table plane (geom1) - sphere (geom2): the end sphere itself (a capsule meets a plane in its end spheres)
     d2 = ctr[2] - m->table_z - rad;
     hitt = (d2 < 0) & over_table(tr, ctr);
@@ -954,7 +971,7 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const KModelDesc* m, 
     // capsule section (kmanip.h sphere_seg): against the cube the collider is the point of the link's segment closest to the
     // cube centre -- a sphere sliding along the link
     {
-      const real sg[3] = {m->sphere_seg[s][0], m->sphere_seg[s][1], m->sphere_seg[s][2]};
+      const real sg[3] = {lm.sph_seg[s][0], lm.sph_seg[s][1], lm.sph_seg[s][2]};
       real sw[3];
       mat_vec3(sw, w.k.xmat[l], sg);
       const real ss = dot3(sw, sw);
@@ -1128,7 +1145,7 @@ __device__ __forceinline__ void build_constraints(Ws<NL>& w, const LModel<NL>& l
     cr.jb[c][0] = 0; cr.jb[c][1] = 0; cr.jb[c][2] = 0; cr.jb[c][3] = 0;
     if (((act >> c) & 1u) && sub < NV) {
       const int kind = slot_kind<NL>(c);
-      const int link = kind == 0 ? -1 : m->sphere_link[w.slot_sph[c]];
+      const int link = kind == 0 ? -1 : lm.sph_link[w.slot_sph[c]];
       const int b1 = kind == 1 ? link : -1, b2 = kind == 2 ? link : NL;   // geom1 / geom2 bodies
       real pt[3] = {w.c_pos[c][0], w.c_pos[c][1], w.c_pos[c][2]};
       real p1[3], r1[3], p2[3], r2[3];
@@ -1639,7 +1656,7 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       real sgn = 0;
       if (kind == 0) sgn = cubelane ? 1.0 : 0.0;
       else {
-        const uint32_t am = lm.anc[m->sphere_link[w.slot_sph[c]]];
+        const uint32_t am = lm.anc[lm.sph_link[w.slot_sph[c]]];
         const bool mine = armlane && ((am >> jl) & 1u);
         sgn = kind == 1 ? (mine ? -1.0 : (cubelane ? 1.0 : 0.0)) : (mine ? 1.0 : 0.0);
       }
@@ -2317,7 +2334,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   }
   else bias_bodies_parallel<NL, G>(w, lm, m, sub);
   pf.ph(1);
-  collide_parallel<NL, G>(w, m, sub);
+  collide_parallel<NL, G>(w, lm, m, sub);
   if constexpr (SOLVER != KM_SOLVER_NEWTON) { if (sub == 0) scalar_rows_serial<NL>(w, lm); }
   GSYNC();
   pf.ph(2);
@@ -2493,6 +2510,12 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
         lm.sphA[1][sp] = lw + mud * mud * lw;
       }
     }
+    if (i < Dim<NL>::NSPH) {           // (NSPH <= NL)
+      const int sp = i < m->nsphere ? i : 0;          // (unused candidates: finite copies, never tested)
+      lm.sph_link[i] = m->sphere_link[sp]; lm.sph_rad[i] = m->sphere_radius[sp];
+      for (int c = 0; c < 3; c++) { lm.sph_pos[i][c] = m->sphere_pos[sp][c]; lm.sph_seg[i][c] = m->sphere_seg[sp][c]; }
+      if (i == 0) lm.nsph = m->nsphere < Dim<NL>::NSPH ? m->nsphere : Dim<NL>::NSPH;
+    }
     lm.dofw[i] = m->dof_invweight0[i];
     lm.floss[i] = m->frictionloss[i]; lm.kp[i] = m->kp[i]; lm.mass[i] = m->mass[i]; lm.q_home[i] = m->q_home[i];
     for (int c = 0; c < 3; c++) { lm.pos[i][c] = m->link_pos[i][c]; lm.jaxis[i][c] = m->jnt_axis[i][c]; lm.com[i][c] = m->com[i][c]; lm.inertia[i][c] = m->inertia[i][c]; }
@@ -2661,7 +2684,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   if (!bad) {
     // trailing mj_step1: kinematics + collision feed reward and the contact mask
     fk_parallel<NL, G>(w, lm, sub);
-    const int near_cube = collide_parallel<NL, G, true>(w, m, sub, st.near_margin);
+    const int near_cube = collide_parallel<NL, G, true>(w, lm, m, sub, st.near_margin);
     heavy_next = near_cube;
     // the cost score of an env that is not heavy (spread_pick): bit 1 a sphere on the table, bit 0 a cube that does not rest on four corners
     // (KMANIP_SPREAD_TABLE, A/B: 0 no score; 1 the table bit only; 2 both as ONE class; 3 = default: both bits, four classes)
@@ -2770,7 +2793,7 @@ __global__ __launch_bounds__(64) void k_observe(const KDeviceModel* __restrict__
     return;
   }
   fk_parallel<NL, G>(w, lm, sub);
-  collide_parallel<NL, G>(w, m, sub);
+  collide_parallel<NL, G>(w, lm, m, sub);
   const real rew = env_reward<NL, G>(w, m, sub);
   if (obs) write_obs<NL, G>(w, lm, m, sub, obs + (size_t)env * m->obs_dim);
   if (sub == 0) { st.contact_mask[env] = w.contact_mask; if (reward) reward[env] = rew; }

@@ -184,9 +184,10 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
     real axs[3] = {rq[0], rq[1], rq[2]};
     real half = 0.5 * normalize3_fast(axs);
     real coef = 1.0 - (half < 6e-8 ? 1.0 : half * ac_h / sn_h);      // half / tan(half), tan(half) = sn_h / ac_h
-    const int l = P.ax->chain_link[arm][P.on ? P.c : 0];
+    // (P.cslide: the joint type of THIS lane's chain link, read once per problem by coop_chain_setup -- lanes with an unknown
+    // have c < clen, so it is their link's; round 5 re-read chain_link -> jnt_type, two dependent global loads, in every evaluation)
     if (!P.on) { Jc[0] = 0; Jc[1] = 0; Jc[2] = 0; Jc[3] = 0; Jc[4] = 0; Jc[5] = 0; }
-    else if (m->jnt_type[l] == KM_JNT_SLIDE) { Jc[0] = axw[0]; Jc[1] = axw[1]; Jc[2] = axw[2]; Jc[3] = 0; Jc[4] = 0; Jc[5] = 0; }
+    else if (P.cslide) { Jc[0] = axw[0]; Jc[1] = axw[1]; Jc[2] = axw[2]; Jc[3] = 0; Jc[4] = 0; Jc[5] = 0; }
     else {
       real r[3] = {sp[0] - anc[0], sp[1] - anc[1], sp[2] - anc[2]}, jp[3];
       cross3(jp, axw, r);
