@@ -102,6 +102,32 @@ __device__ __forceinline__ int xcd_block(int b, int nblocks) {
 }
 
 
+// LDS LATENCY (round 6).  With one wave per SIMD nothing hides an LDS round trip (~64-130 cycles), and the compiler both SINKS
+// loads into the conditional blocks that use them and waits for each before it issues the next: a phase that reads its inputs
+// where it needs them pays one round trip per input (the constraint assembly: ~30 in a row).  km_pin names values that must be
+// in registers at this point -- ONE empty asm with all of them as operands -- so that their (independent) loads are issued
+// back to back in front of it and waited for once.  No instruction is emitted; the arithmetic is untouched.
+__device__ __forceinline__ void km_pin(real& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void km_pin(real& a, real& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void km_pin(real& a, real& b, real& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ void km_pin(real& a, real& b, real& c, real& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void km_pin(real& a, real& b, real& c, real& d, real& e) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)); }
+__device__ __forceinline__ void km_pin(real& a, real& b, real& c, real& d, real& e, real& f) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+__device__ __forceinline__ void km_pin(real (&v)[3]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
+__device__ __forceinline__ void km_pin(real (&v)[9]) {
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+}
+__device__ __forceinline__ void km_pin(real (&a)[3], real (&b)[3]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+}
+__device__ __forceinline__ void km_pin(real (&a)[3], real (&b)[9]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]));
+}
+__device__ __forceinline__ void km_pin_i(int& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void km_pin_i(int& a, int& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
 __device__ __forceinline__ real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(real* r, const real* a, const real* b) {
   real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];

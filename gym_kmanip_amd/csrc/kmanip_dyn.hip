@@ -85,6 +85,7 @@ struct LModel {
   struct Imp { real d0, dw, iw, mid, imid, i1mid; int mode; } imp[2];
   // collision candidates (round 6): link, centre, radius and capsule segment of sphere s were per-lane GLOBAL loads in every
   // sub-step's narrow phase (and the link again, behind an LDS load, for every active sphere slot of the constraint assembly)
+  real fric[2][2];      // (tangential, torsional) friction of pairs without / with the cube (con_def_friction, con_cube_friction)
   int sph_link[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1], nsph;
   real sph_pos[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1][3], sph_rad[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1], sph_seg[Dim<NL>::NSPH > 0 ? Dim<NL>::NSPH : 1][3];
 };
@@ -107,7 +108,7 @@ struct ConRec {
   real f[6];       // edge forces
 };
 
-#define KM_WS_PAD(NL) ((NL) <= 10 ? 13 : 1)      // doubles of padding at the end of Ws (see the note on row strides in it)
+#define KM_WS_PAD(NL) ((NL) <= 10 ? 9 : 1)      // doubles of padding at the end of Ws (see the note on row strides in it)
 template <int NL>
 struct Ws {
   static constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ, NS = Dim<NL>::NS, NC = Dim<NL>::NC;
@@ -154,6 +155,7 @@ struct Ws {
   // contact geometry per slot
   real c_pos[NC][3], c_frame[NC][9], c_dist[NC];
   int slot_sph[NC];        // sphere index held by each active sphere slot (4..NC-1)
+  uint32_t slot_anc[NC];   // ... and the ancestor mask of that sphere's link (round 6: the constraint assembly read it through two more dependent loads)
   real pad_[KM_WS_PAD(NL)];
 };
 static_assert(KM_VAR_NL != 10 || KM_VAR_SOLVER != 1 || sizeof(Ws<KM_VAR_NL>) % 256 == 128, "Ws<10>: consecutive envs 128 bytes apart modulo the 256-byte bank row");
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
     w.c_dist[n] = d1;
 #pragma unroll
     for (int a = 0; a < 3; a++) w.c_pos[n][a] = ctr[a] + fr[a] * (rad + 0.5 * d1);
-    w.slot_sph[n] = s;
+    w.slot_sph[n] = s; w.slot_anc[n] = lm.anc[lm.sph_link[s]];
     mask |= KM_CON_SPHERE_CUBE(s); act |= 1u << n;
   }
   if (hitt && __popc(mt) < NST) {
@@ -1027,7 +1029,7 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
     for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
     w.c_dist[n] = d2;
     w.c_pos[n][0] = ctrt[0]; w.c_pos[n][1] = ctrt[1]; w.c_pos[n][2] = ctrt[2] - (rad + 0.5 * d2);
-    w.slot_sph[n] = s;
+    w.slot_sph[n] = s; w.slot_anc[n] = lm.anc[lm.sph_link[s]];
     mask |= KM_CON_SPHERE_TABLE(s); act |= 1u << n;
   }
   mask = (uint32_t)gor<G>((int)mask);
@@ -1043,12 +1045,26 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
 // MuJoCo impedance d(r) from the staged, pre-clamped solimp constants: no divide, no pow (power is 1 or 2: kmanip_create
 // refuses any other value; every reference model uses the default 2)
 template <class IMP> __device__ __forceinline__ real impedance_c(const IMP& p, real pos) {
-  if (p.mode == 0) return 0.5 * (p.d0 + p.dw);
-  const real x = fabs(pos) * p.iw;
-  if (x >= 1) return p.dw;
-  if (x <= 0) return p.d0;
-  const real y = p.mode == 1 ? x : ((x <= p.mid) ? x * x * p.imid : 1 - (1 - x) * (1 - x) * p.i1mid);
-  return p.d0 + y * (p.dw - p.d0);
+  // (round 6: the seven staged constants fetched together and the cases as selects -- as early returns each case read its own
+  // constants from LDS behind its own branch, eight round trips in a row; same expressions, same value)
+  real d0 = p.d0, dw = p.dw, iw = p.iw, mid = p.mid, imid = p.imid, i1mid = p.i1mid;
+  int mode = p.mode;
+  km_pin(d0, dw, iw, mid, imid, i1mid); km_pin_i(mode);
+  const real x = fabs(pos) * iw;
+  const real y = mode == 1 ? x : ((x <= mid) ? x * x * imid : 1 - (1 - x) * (1 - x) * i1mid);
+  real r = d0 + y * (dw - d0);
+  r = x <= 0 ? d0 : r;
+  r = x >= 1 ? dw : r;
+  return mode == 0 ? 0.5 * (d0 + dw) : r;
+}
+// the same from constants the caller fetched (together with its other inputs)
+__device__ __forceinline__ real impedance_v(real d0, real dw, real iw, real mid, real imid, real i1mid, int mode, real pos) {
+  const real x = fabs(pos) * iw;
+  const real y = mode == 1 ? x : ((x <= mid) ? x * x * imid : 1 - (1 - x) * (1 - x) * i1mid);
+  real r = d0 + y * (dw - d0);
+  r = x <= 0 ? d0 : r;
+  r = x >= 1 ? dw : r;
+  return mode == 0 ? 0.5 * (d0 + dw) : r;
 }
 template <class IMP> __device__ __forceinline__ void stage_imp(IMP& p, const real* si) {
   p.d0 = fmin(fmax(si[0], MJ_MINIMP), MJ_MAXIMP); p.dw = fmin(fmax(si[1], MJ_MINIMP), MJ_MAXIMP);
@@ -1604,19 +1620,40 @@ template <int NL, int G>
 __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
                                                          CReg<NL>& cr, real invm) {
   SlotC& sc = cr.sc;
-  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC;
+  constexpr int NV = Dim<NL>::NV, NC = Dim<NL>::NC, NSPH = Dim<NL>::NSPH;
   cr.fl = 0; cr.Rf = 1; cr.Df = 1; cr.areff = 0; cr.sg = 0; cr.Rl = 1; cr.Dl = 1; cr.arefl = 0;
+  const bool armlane = sub < NL, cubelane = sub >= NL && sub < NV;
+  const int jl = armlane ? sub : 0, ce = cubelane ? sub - NL : 0;
+  // ---- Round 6: EVERYTHING the assembly reads unconditionally is fetched here, at clamped addresses, in one go (km_pin: one wait
+  // instead of one per input -- the phase was ~30 LDS round trips in a row with one wave per SIMD); the conditions select afterwards.
+  const int si = sub < NL ? sub : NL - 1, sv = sub < NV ? sub : NV - 1, ck = ce >= 3 ? ce - 3 : 0;
+  const int cs = sub < NC ? sub : NC - 1;                       // the contact slot this lane owns (slot lanes)
+  real dofw = lm.dofw[si], cubew0 = lm.cubew[0], cubew1 = lm.cubew[1], qvs = w.qvel[sv], kk0 = lm.kb[0][0], bb0 = lm.kb[0][1];
+  real floss = lm.floss[si], imp00 = lm.imp0[0], qps = w.qpos[si], rlo = lm.range[si][0], rhi = lm.range[si][1], distc = w.c_dist[cs];
+  real ax[3] = {w.k.axis[jl][0], w.k.axis[jl][1], w.k.axis[jl][2]}, xo[3] = {w.k.xpos[jl][0], w.k.xpos[jl][1], w.k.xpos[jl][2]};
+  real col0 = w.k.cube_mat[ck], col1 = w.k.cube_mat[3 + ck], col2 = w.k.cube_mat[6 + ck], cpos[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
+  real cm[9], cpc[4][3], cpl[3];                                // cube rotation; the four corner slots' contact points; this lane's corner
+#pragma unroll
+  for (int k = 0; k < 9; k++) cm[k] = w.k.cube_mat[k];
+#pragma unroll
+  for (int c = 0; c < 4; c++) { cpc[c][0] = w.c_pos[c][0]; cpc[c][1] = w.c_pos[c][1]; cpc[c][2] = w.c_pos[c][2]; }
+  { const int cl = sub < 4 ? sub : 0; cpl[0] = w.c_pos[cl][0]; cpl[1] = w.c_pos[cl][1]; cpl[2] = w.c_pos[cl][2]; }
+  int jt = lm.jtype[jl], sps = w.slot_sph[cs];
+  uint32_t act = w.cact;
+  km_pin(dofw, cubew0, cubew1, qvs, kk0, bb0); km_pin(floss, imp00, qps, rlo, rhi, distc);
+  km_pin(ax, xo); km_pin(col0, col1, col2); km_pin(cpos); km_pin(cm); km_pin(cpc[0], cpc[1]); km_pin(cpc[2], cpc[3]); km_pin(cpl);
+  km_pin_i(jt, sps); asm volatile("" : "+v"(act));
   if (sub < NV) {
-    const real Ad = sub < NL ? lm.dofw[sub] : lm.cubew[sub < NL + 3 ? 0 : 1];     // efc_diagApprox (qpos0 constants)
-    const real qv = w.qvel[sub];
-    const real kk = lm.kb[0][0], bb = lm.kb[0][1];
-    const real fl = sub < NL ? lm.floss[sub] : m->cube_frictionloss;
+    const real Ad = sub < NL ? dofw : (sub < NL + 3 ? cubew0 : cubew1);           // efc_diagApprox (qpos0 constants)
+    const real qv = qvs;
+    const real kk = kk0, bb = bb0;
+    const real fl = sub < NL ? floss : m->cube_frictionloss;
     if (fl > 0) {
-      const real imp = lm.imp0[0];
+      const real imp = imp00;
       cr.fl = fl; cr.Rf = fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad); cr.Df = frcp(cr.Rf); cr.areff = -bb * qv;
     }
     if (sub < NL) {
-      const real dl = w.qpos[sub] - lm.range[sub][0], du = lm.range[sub][1] - w.qpos[sub];
+      const real dl = qps - rlo, du = rhi - qps;
       const real pos = dl < 0 ? dl : du;
       if (pos < 0) {                                       // (lower and upper cannot both be violated: range lo < hi)
         const real imp = impedance_c(lm.imp[0], pos);
@@ -1627,24 +1664,18 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       }
     }
   }
-  const uint32_t act = w.cact;
   // ---- this lane's column of every active contact's Jacobian basis.  What a dof does to a point depends on the dof only
   // through a direction A and, for rotations, a point O on the axis (an arm hinge: joint axis and origin; an arm slider: its
-  // axis; the cube: a world axis, or a body axis through the cube centre) -- fetched ONCE, unconditionally, before the slot
-  // loop; per slot the column is then a cross product and selects, no branches and no loads under conditions.
-  const bool armlane = sub < NL, cubelane = sub >= NL && sub < NV;
-  const int jl = armlane ? sub : 0, ce = cubelane ? sub - NL : 0;
-  const bool rot = armlane ? lm.jtype[jl] != KM_JNT_SLIDE : ce >= 3;
+  // axis; the cube: a world axis, or a body axis through the cube centre) -- fetched ONCE, unconditionally, above;
+  // per slot the column is then a cross product and selects, no branches and no loads under conditions (sphere slots, which are
+  // rarely active, fetch their contact point, frame and ancestor mask together inside their branch).
+  const bool rot = armlane ? jt != KM_JNT_SLIDE : ce >= 3;
   real A[3], O[3];
-  {
-    const real ax[3] = {w.k.axis[jl][0], w.k.axis[jl][1], w.k.axis[jl][2]}, xo[3] = {w.k.xpos[jl][0], w.k.xpos[jl][1], w.k.xpos[jl][2]};
-    const int k = ce >= 3 ? ce - 3 : 0;
-    const real col[3] = {w.k.cube_mat[k], w.k.cube_mat[3 + k], w.k.cube_mat[6 + k]};
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-      A[d] = armlane ? ax[d] : (ce >= 3 ? col[d] : (ce == d ? 1.0 : 0.0));
-      O[d] = armlane ? xo[d] : w.qpos[NL + d];
-    }
+  for (int d = 0; d < 3; d++) {
+    const real cold = d == 0 ? col0 : (d == 1 ? col1 : col2);
+    A[d] = armlane ? ax[d] : (ce >= 3 ? cold : (ce == d ? 1.0 : 0.0));
+    O[d] = armlane ? xo[d] : cpos[d];
   }
 #pragma unroll
   for (int c = 0; c < NC; c++) {
@@ -1653,14 +1684,20 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       const int kind = slot_kind<NL>(c);
       // geom1 / geom2: kind 0 table (world) / cube, kind 1 sphere's link / cube, kind 2 table (world) / sphere's link.  A lane
       // belongs to at most one of the two bodies; its column is +J for geom2's body, -J for geom1's.
-      real sgn = 0;
-      if (kind == 0) sgn = cubelane ? 1.0 : 0.0;
-      else {
-        const uint32_t am = lm.anc[lm.sph_link[w.slot_sph[c]]];
+      real sgn = 0, cp[3], fr[9];
+      if (kind == 0) {
+        sgn = cubelane ? 1.0 : 0.0;
+        cp[0] = cpc[c < 4 ? c : 0][0]; cp[1] = cpc[c < 4 ? c : 0][1]; cp[2] = cpc[c < 4 ? c : 0][2];
+      } else {
+        cp[0] = w.c_pos[c][0]; cp[1] = w.c_pos[c][1]; cp[2] = w.c_pos[c][2];
+#pragma unroll
+        for (int k = 0; k < 9; k++) fr[k] = w.c_frame[c][k];
+        uint32_t am = w.slot_anc[c];
+        km_pin(cp, fr); asm volatile("" : "+v"(am));
         const bool mine = armlane && ((am >> jl) & 1u);
         sgn = kind == 1 ? (mine ? -1.0 : (cubelane ? 1.0 : 0.0)) : (mine ? 1.0 : 0.0);
       }
-      const real r[3] = {w.c_pos[c][0] - O[0], w.c_pos[c][1] - O[1], w.c_pos[c][2] - O[2]};
+      const real r[3] = {cp[0] - O[0], cp[1] - O[1], cp[2] - O[2]};
       real jp[3];
       cross3(jp, A, r);
 #pragma unroll
@@ -1669,20 +1706,37 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
       if (kind == 0) {                                     // constant plane frame: rows n = +z, t1 = +y, t2 = -x
         cr.jb[c][0] = jp[2]; cr.jb[c][1] = jp[1]; cr.jb[c][2] = -jp[0]; cr.jb[c][3] = jr[2];
       } else {
-        cr.jb[c][0] = dot3(w.c_frame[c], jp);
-        cr.jb[c][1] = dot3(w.c_frame[c] + 3, jp);
-        cr.jb[c][2] = dot3(w.c_frame[c] + 6, jp);
-        cr.jb[c][3] = dot3(w.c_frame[c], jr);
+        cr.jb[c][0] = dot3(fr, jp);
+        cr.jb[c][1] = dot3(fr + 3, jp);
+        cr.jb[c][2] = dot3(fr + 6, jp);
+        cr.jb[c][3] = dot3(fr, jr);
       }
     }
   }
-  GSYNC();
-  const real qv = sub < NV ? w.qvel[sub] : 0.0;
+  // the slot lanes' solver constants: fetched now, while the projections below run (slot `sub` of a slot lane; clamped elsewhere)
+  const int kindl = cs < 4 ? 0 : (cs < 4 + Dim<NL>::NSS ? 1 : 2), pset = kindl != 2 ? 1 : 0;
+  const int spc = sps < 0 ? 0 : (sps >= NSPH ? NSPH - 1 : sps);            // (an inactive slot's sphere index is stale: clamped, never used)
+  real sA = kindl == 0 ? lm.cornerA : lm.sphA[kindl == 2][spc];            // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
+  real mu_t = lm.fric[pset][0], mu_r = lm.fric[pset][1], kks = lm.kb[pset][0], bbs = lm.kb[pset][1];
+  real i_d0 = lm.imp[pset].d0, i_dw = lm.imp[pset].dw, i_iw = lm.imp[pset].iw, i_mid = lm.imp[pset].mid, i_imid = lm.imp[pset].imid, i_i1 = lm.imp[pset].i1mid;
+  int i_mode = lm.imp[pset].mode;
+  const real qv = sub < NV ? qvs : 0.0;
+  // the six cube components of qvel on every lane, the angular part in the world frame (cube_part with the rotation fetched above)
   real qlin[3], qangw[3];
-  cube_part<NL, G>(w, qv, qlin, qangw);
+  {
+    qlin[0] = gbcast<G, NL>(qv); qlin[1] = gbcast<G, NL + 1>(qv); qlin[2] = gbcast<G, NL + 2>(qv);
+    const real ab[3] = {gbcast<G, NL + 3>(qv), gbcast<G, NL + 4>(qv), gbcast<G, NL + 5>(qv)};
+    mat_vec3(qangw, cm, ab);
+  }
   // velocity projections of every active slot; lane c keeps slot c's
   real vb[4] = {0, 0, 0, 0};
-  plane_proj_lane<NL>(w, sub, qlin, qangw, vb);                 // table-cube slots: lane c < 4 evaluates ITS corner
+  {                                                             // table-cube slots: lane c < 4 evaluates ITS corner (plane_proj)
+    const real r[3] = {cpl[0] - cpos[0], cpl[1] - cpos[1], cpl[2] - cpos[2]};
+    real v[3];
+    cross3(v, qangw, r);
+    v[0] += qlin[0]; v[1] += qlin[1]; v[2] += qlin[2];
+    vb[0] = v[2]; vb[1] = v[1]; vb[2] = -v[0]; vb[3] = qangw[2];     // KM_PLANE_FRAME rows
+  }
   static_for<4, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if ((act >> c) & 1u) {
@@ -1698,17 +1752,15 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   });
   // the solver constants of slot `sub`, one slot per lane (all slots through ONE pass of the impedance / regulariser / reference
   // acceleration arithmetic instead of one unrolled copy per slot)
+  km_pin(sA, mu_t, mu_r, kks, bbs, i_d0); km_pin(i_dw, i_iw, i_mid, i_imid, i_i1); km_pin_i(i_mode);
   sc.D = 0; sc.D3 = 0; sc.mu = 0; sc.mu3 = 0; sc.A[0] = 0; sc.A[1] = 0; sc.A[2] = 0; sc.A[3] = 0;
   if (sub < NC && ((act >> sub) & 1u)) {
-    const int c = sub, kind = c < 4 ? 0 : (c < 4 + Dim<NL>::NSS ? 1 : 2);
-    const bool cube = kind != 2;
-    const real* fr = cube ? m->con_cube_friction : m->con_def_friction;
-    const int sp = kind == 0 ? 0 : w.slot_sph[c];
-    const real Ad = kind == 0 ? lm.cornerA : lm.sphA[kind == 2][sp];   // efc_diagApprox of the first pyramid edge (qpos0 constant; no M^-1 product)
-    const real dist = w.c_dist[c];
-    const real imp = impedance_c(lm.imp[cube ? 1 : 0], dist), kk = lm.kb[cube ? 1 : 0][0], bb = lm.kb[cube ? 1 : 0][1];
-    const real R = 2 * fr[0] * fr[0] * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad), Dn = frcp(R);
-    sc.D = Dn; sc.D3 = kind == 2 ? 0.0 : Dn; sc.mu = fr[0]; sc.mu3 = fr[1];
+    const int kind = kindl;
+    const real Ad = sA;
+    const real dist = distc;
+    const real imp = impedance_v(i_d0, i_dw, i_iw, i_mid, i_imid, i_i1, i_mode, dist), kk = kks, bb = bbs;
+    const real R = 2 * mu_t * mu_t * fmax(MJ_MINVAL, (1 - imp) * frcp(imp) * Ad), Dn = frcp(R);
+    sc.D = Dn; sc.D3 = kind == 2 ? 0.0 : Dn; sc.mu = mu_t; sc.mu3 = mu_r;
     sc.A[0] = -bb * vb[0] - kk * imp * dist; sc.A[1] = -bb * vb[1]; sc.A[2] = -bb * vb[2]; sc.A[3] = -bb * vb[3];
   }
   GSYNC();
@@ -2501,6 +2553,8 @@ __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* 
       lm.imp0[1] = impedance(m->con_cube_solimp, 0.0);
       stage_imp(lm.imp[0], m->con_def_solimp); stage_imp(lm.imp[1], m->con_cube_solimp);
       lm.cubew[0] = m->cube_invweight0[0]; lm.cubew[1] = m->cube_invweight0[1];
+      lm.fric[0][0] = m->con_def_friction[0]; lm.fric[0][1] = m->con_def_friction[1];
+      lm.fric[1][0] = m->con_cube_friction[0]; lm.fric[1][1] = m->con_cube_friction[1];
       lm.scale = 1.0 / (m->meaninertia * (NL + 6));
       const real muc = m->con_cube_friction[0], mud = m->con_def_friction[0], cw = m->cube_invweight0[0];
       lm.cornerA = cw + muc * muc * cw;
