@@ -183,6 +183,10 @@ template <int NL> struct CReg {
   real fl, Rf, Df, areff;    // friction-loss row x = a - areff          (fl = 0: no row); Df = 1 / Rf
   real sg, Rl, Dl, arefl;    // limit row         x = sg * a - arefl     (sg = 0: no row); Dl = 1 / Rl
   SlotC sc;                  // one-row groups: the contact slot this lane owns
+  // Newton path (round 6): the cube's rotation and this lane's corner contact point relative to the cube centre, fetched once per
+  // sub-step by the constraint assembly -- every projection J_c v of the table-cube slots (two per start evaluation, one per Newton
+  // iteration) re-read all twelve from LDS
+  real cm[9], pr[3];
 };
 
 #ifdef KM_PROFILE
@@ -1730,8 +1734,11 @@ __device__ __forceinline__ void build_constraints_newton(Ws<NL>& w, const LModel
   }
   // velocity projections of every active slot; lane c keeps slot c's
   real vb[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 9; k++) cr.cm[k] = cm[k];
+  cr.pr[0] = cpl[0] - cpos[0]; cr.pr[1] = cpl[1] - cpos[1]; cr.pr[2] = cpl[2] - cpos[2];
   {                                                             // table-cube slots: lane c < 4 evaluates ITS corner (plane_proj)
-    const real r[3] = {cpl[0] - cpos[0], cpl[1] - cpos[1], cpl[2] - cpos[2]};
+    const real r[3] = {cr.pr[0], cr.pr[1], cr.pr[2]};
     real v[3];
     cross3(v, qangw, r);
     v[0] += qlin[0]; v[1] += qlin[1]; v[2] += qlin[2];
@@ -1836,9 +1843,14 @@ __device__ __forceinline__ void slot_project(const Ws<NL>& w, const CReg<NL>& cr
   using SS = SubSet<NL, S>;
   u[0] = 0; u[1] = 0; u[2] = 0; u[3] = 0;
   if constexpr (S != KM_SUB_ARM) {
-    real lin[3], angw[3];
-    cube_part<NL, G>(w, v, lin, angw);
-    plane_proj_lane<NL>(w, sub, lin, angw, u);
+    // cube_part + plane_proj_lane on the registers the constraint assembly left in cr (same operations, same values)
+    const real lin[3] = {gbcast<G, NL>(v), gbcast<G, NL + 1>(v), gbcast<G, NL + 2>(v)};
+    const real ab[3] = {gbcast<G, NL + 3>(v), gbcast<G, NL + 4>(v), gbcast<G, NL + 5>(v)};
+    real angw[3], vv[3];
+    mat_vec3(angw, cr.cm, ab);
+    cross3(vv, angw, cr.pr);
+    vv[0] += lin[0]; vv[1] += lin[1]; vv[2] += lin[2];
+    u[0] = vv[2]; u[1] = vv[1]; u[2] = -vv[0]; u[3] = angw[2];     // KM_PLANE_FRAME rows
   }
   static_for<4, NC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
