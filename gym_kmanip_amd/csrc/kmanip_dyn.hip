@@ -276,9 +276,11 @@ template <int G> __device__ __forceinline__ int gor(int v) {
 // mj_kinematics, all links at once: lane i builds link i's transform in its parent (constant rotation times the
 // planar joint rotation; one sincos per lane instead of NL in a row), then ceil(log2(depth)) rounds of pointer
 // jumping compose it with the transform of the 2^k-th ancestor (staged in the link's own xmat/xpos slots).
+// kin (optional, 15 doubles): the world frame of THIS lane's link as it was written to LDS -- rotation R[9], origin p[3], centre of
+// mass c[3] (zeros on lanes without a link) -- so that the passes that follow need not read their own link back (round 6)
 template <int NL, int G>
-__device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int sub) {
-  real R[9], p[3];
+__device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int sub, real* kin = nullptr) {
+  real R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, p[3] = {0, 0, 0};
   const bool on = sub < NL;
   if (on) {
     const real q = w.qpos[sub];
@@ -334,11 +336,19 @@ __device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int
     }
     GSYNC();
   }
+  real cpo[3] = {0, 0, 0};
   if (on) {
     real cl[3] = {lm.com[sub][0], lm.com[sub][1], lm.com[sub][2]}, cw[3];
     mat_vec3(cw, R, cl);
-    w.k.cpos[sub][0] = p[0] + cw[0]; w.k.cpos[sub][1] = p[1] + cw[1]; w.k.cpos[sub][2] = p[2] + cw[2];
+    cpo[0] = p[0] + cw[0]; cpo[1] = p[1] + cw[1]; cpo[2] = p[2] + cw[2];
+    w.k.cpos[sub][0] = cpo[0]; w.k.cpos[sub][1] = cpo[1]; w.k.cpos[sub][2] = cpo[2];
     w.k.axis[sub][0] = R[2]; w.k.axis[sub][1] = R[5]; w.k.axis[sub][2] = R[8];
+  }
+  if (kin) {
+#pragma unroll
+    for (int c = 0; c < 9; c++) kin[c] = on ? R[c] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { kin[9 + c] = on ? p[c] : 0.0; kin[12 + c] = cpo[c]; }
   }
   GSYNC();
 }
@@ -466,16 +476,32 @@ __device__ __forceinline__ void mass_matrix(Ws<NL>& w, const LModel<NL>& lm, int
 // acceleration wrench onto its ancestors' joints (column `sub` of M, rows through LDS for the row-per-lane inversion) and its
 // subtree wrench onto its own joint (bias).
 template <int NL, int W>
-__device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel<NL>& lm, int li, int base, const real (&FN)[6]) {
+__device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel<NL>& lm, int li, int base, const real (&FN)[6], const real* kin = nullptr) {
   static_assert(W <= 16, "one DPP row per block");
   const bool on = li >= 0;
   const int b = on ? li : 0;
+  // (round 6) the link's frame from fk_parallel's registers (kin; else one batch from LDS), its constants in one batch
+  real Rk[9], oj[3], c[3];
+  real massb = lm.mass[b], I0 = lm.inertia[b][0], I1 = lm.inertia[b][1], I2 = lm.inertia[b][2];
+  int jtb = lm.jtype[b];
+  uint32_t descb = lm.desc[b], ancb = lm.anc[b];
+  if (kin) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rk[k] = kin[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { oj[k] = kin[9 + k]; c[k] = kin[12 + k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rk[k] = w.k.xmat[b][k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { oj[k] = w.k.xpos[b][k]; c[k] = w.k.cpos[b][k]; }
+    km_pin(Rk); km_pin(oj, c);
+  }
+  km_pin(massb, I0, I1, I2); km_pin_i(jtb); asm volatile("" : "+v"(descb), "+v"(ancb));
   real own[16];
   {
-    const real mb = on ? lm.mass[b] : 0.0;
-    const real c[3] = {w.k.cpos[b][0], w.k.cpos[b][1], w.k.cpos[b][2]};
-    const real* R = w.k.xmat[b];
-    const real I0 = lm.inertia[b][0], I1 = lm.inertia[b][1], I2 = lm.inertia[b][2];
+    const real mb = on ? massb : 0.0;
+    const real* R = Rk;
     const real cc = dot3(c, c);
     own[0] = mb; own[1] = mb * c[0]; own[2] = mb * c[1]; own[3] = mb * c[2];
     // R diag(I) R^T + m (|c|^2 1 - c c^T), packed xx xy xz yy yz zz
@@ -495,7 +521,7 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
   real acc[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) acc[k] = 0;
-  const uint32_t dm = on ? lm.desc[li] >> base : 0u;   // row-local bits (the link's own bit is set: its own contribution)
+  const uint32_t dm = on ? descb >> base : 0u;   // row-local bits (the link's own bit is set: its own contribution)
   static_for<0, W>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
     const real take = ((dm >> j) & 1u) ? 1.0 : 0.0;
@@ -508,11 +534,10 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
   if (on) {
     const int j = li;
     const real* o = acc;
-    const real ax[3] = {w.k.axis[j][0], w.k.axis[j][1], w.k.axis[j][2]};
-    const real oj[3] = {w.k.xpos[j][0], w.k.xpos[j][1], w.k.xpos[j][2]};
+    const real ax[3] = {Rk[2], Rk[5], Rk[8]};
     const real h[3] = {o[1], o[2], o[3]};
     real F[3], N[3], t[3];
-    const bool slide = lm.jtype[j] == KM_JNT_SLIDE;
+    const bool slide = jtb == KM_JNT_SLIDE;
     if (slide) {
       F[0] = o[0] * ax[0]; F[1] = o[0] * ax[1]; F[2] = o[0] * ax[2];
       cross3(N, h, ax);
@@ -527,7 +552,7 @@ __device__ __forceinline__ void composite_mass_bias_rows(Ws<NL>& w, const LModel
       cross3(t, h, aO);
       N[0] += t[0]; N[1] += t[1]; N[2] += t[2];
     }
-    const uint32_t am = lm.anc[j];
+    const uint32_t am = ancb;
     // Round 6: one basic block.  With the stores inside `if (i <= j)` the compiler sank each row's six LDS loads into that row's
     // conditional block: ten load -> wait -> compute -> store round trips in a row (one wave per SIMD: nothing hides them).  Now every
     // row's entry is stored unconditionally -- rows this lane does not own go to a scratch slot of its own (w.tmp[j], not live before
@@ -690,26 +715,45 @@ __device__ __forceinline__ void cube_bias(Ws<NL>& w, const KModelDesc* m) {
 // W = links per DPP row.  One-row groups: the row holds the whole robot (li = sub, base = 0, W = NL).  Two-row groups with a
 // block split (two-arm models): each row holds one block of the robot -- lane c of a row works on link li = base + c of ITS
 // block, masks are taken relative to the block's first link, and both blocks go through the same instructions at once.
+// kin != nullptr (one-row groups, lane = link): the link's own frame from fk_parallel's registers instead of LDS.
 template <int NL, int W>
-__device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int li, int base, bool cube_lane, real (&FN)[6]) {
+__device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int li, int base, bool cube_lane, real (&FN)[6],
+                                                 const real* kin = nullptr) {
   static_assert(W <= 16, "one DPP row per block");
   constexpr int G = 16;
   const bool on = li >= 0;
   const int i = on ? li : 0;
-  const bool slide = on && lm.jtype[i] == KM_JNT_SLIDE;
-  const uint32_t am = on ? lm.anc[i] >> base : 0u, up = am & ~(1u << (i - base));       // ancestors incl. self / proper ancestors (row-local bits)
-  const real qv = on ? w.qvel[i] : 0.0;
-  const real ax[3] = {w.k.axis[i][0] * qv, w.k.axis[i][1] * qv, w.k.axis[i][2] * qv};
+  // (round 6) the link's constants and state in one batch; the parent's origin -- the one dependent read -- right behind it
+  int jti = lm.jtype[i], pari = lm.parent[i];
+  uint32_t anci = lm.anc[i];
+  real qvi = w.qvel[i], in0 = lm.inertia[i][0], in1 = lm.inertia[i][1], in2 = lm.inertia[i][2], massi = lm.mass[i];
+  real Rk[9], xo[3], cpi[3];
+  if (kin) {
+#pragma unroll
+    for (int c = 0; c < 9; c++) Rk[c] = kin[c];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { xo[c] = kin[9 + c]; cpi[c] = kin[12 + c]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 9; c++) Rk[c] = w.k.xmat[i][c];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { xo[c] = w.k.xpos[i][c]; cpi[c] = w.k.cpos[i][c]; }
+    km_pin(Rk); km_pin(xo, cpi);
+  }
+  km_pin_i(jti, pari); asm volatile("" : "+v"(anci)); km_pin(qvi, in0, in1, in2, massi);
+  real op[3] = {0, 0, 0};
+  { const int pc = pari >= 0 ? pari : 0; op[0] = w.k.xpos[pc][0]; op[1] = w.k.xpos[pc][1]; op[2] = w.k.xpos[pc][2]; }
+  if (!(on && pari >= 0)) { op[0] = 0; op[1] = 0; op[2] = 0; }
+  const bool slide = on && jti == KM_JNT_SLIDE;
+  const uint32_t am = on ? anci >> base : 0u, up = am & ~(1u << (i - base));       // ancestors incl. self / proper ancestors (row-local bits)
+  const real qv = on ? qvi : 0.0;
+  const real ax[3] = {Rk[2] * qv, Rk[5] * qv, Rk[8] * qv};                           // (the joint axis = third column of the link's rotation)
   const real wv[3] = {(slide || !on) ? 0.0 : ax[0], (slide || !on) ? 0.0 : ax[1], (slide || !on) ? 0.0 : ax[2]};
   real wp[3] = {0, 0, 0}, cz[3], alp[3] = {0, 0, 0};
   anc_sum3<W, G>(up, wv, wp);
   cross3(cz, wp, ax);
   const real czv[3] = {(slide || !on) ? 0.0 : cz[0], (slide || !on) ? 0.0 : cz[1], (slide || !on) ? 0.0 : cz[2]};
   anc_sum3<W, G>(up, czv, alp);
-  const int p = lm.parent[i];
-  real op[3] = {0, 0, 0};
-  if (on && p >= 0) { op[0] = w.k.xpos[p][0]; op[1] = w.k.xpos[p][1]; op[2] = w.k.xpos[p][2]; }
-  const real xo[3] = {w.k.xpos[i][0], w.k.xpos[i][1], w.k.xpos[i][2]};
   real r[3] = {xo[0] - op[0], xo[1] - op[1], xo[2] - op[2]}, t1[3], t2[3], db[3];
   cross3(t1, alp, r);
   cross3(t2, wp, r); cross3(t2, wp, t2);
@@ -723,20 +767,20 @@ __device__ __forceinline__ void bias_bodies_rows(Ws<NL>& w, const LModel<NL>& lm
 #pragma unroll
       for (int c = 0; c < 3; c++) { wi[c] += ax[c]; ali[c] += cz[c]; }
     }
-    const real cpi[3] = {w.k.cpos[i][0], w.k.cpos[i][1], w.k.cpos[i][2]};
     real cr[3] = {cpi[0] - xo[0], cpi[1] - xo[1], cpi[2] - xo[2]};
     cross3(t1, ali, cr);
     cross3(t2, wi, cr); cross3(t2, wi, t2);
     real wl[3], all[3], Iw[3], nl3[3], nw[3];
-    matT_vec3(wl, w.k.xmat[i], wi);
-    matT_vec3(all, w.k.xmat[i], ali);
+    const real inr[3] = {in0, in1, in2};
+    matT_vec3(wl, Rk, wi);
+    matT_vec3(all, Rk, ali);
 #pragma unroll
-    for (int c = 0; c < 3; c++) Iw[c] = lm.inertia[i][c] * wl[c];
+    for (int c = 0; c < 3; c++) Iw[c] = inr[c] * wl[c];
     cross3(nl3, wl, Iw);
 #pragma unroll
-    for (int c = 0; c < 3; c++) nl3[c] += lm.inertia[i][c] * all[c];
-    mat_vec3(nw, w.k.xmat[i], nl3);
-    real Fi[3] = {lm.mass[i] * (ai[0] + t1[0] + t2[0]), lm.mass[i] * (ai[1] + t1[1] + t2[1]), lm.mass[i] * (ai[2] + t1[2] + t2[2])}, sh[3];
+    for (int c = 0; c < 3; c++) nl3[c] += inr[c] * all[c];
+    mat_vec3(nw, Rk, nl3);
+    real Fi[3] = {massi * (ai[0] + t1[0] + t2[0]), massi * (ai[1] + t1[1] + t2[1]), massi * (ai[2] + t1[2] + t2[2])}, sh[3];
     cross3(sh, cpi, Fi);                       // shift the moment from the com to the world origin
 #pragma unroll
     for (int c = 0; c < 3; c++) { FN[c] = Fi[c]; FN[3 + c] = nw[c] + sh[c]; }
@@ -2376,7 +2420,8 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
 template <int NL, int G, int SOLVER>
 __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, const KModelDesc* m, int sub,
                                                CReg<NL>& cr, real invm, Prof& pf) {
-  fk_parallel<NL, G>(w, lm, sub);
+  real kin[15];
+  fk_parallel<NL, G>(w, lm, sub, G == 16 ? kin : nullptr);
   pf.ph(0);
   real FN[6];
   // two-row groups with a block split: row r of the group = block r of the robot (lane c <-> link base + c) for the two tree
@@ -2391,7 +2436,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
       for (int e = sub; e < (int)(sizeof(w.Minv) / sizeof(real)); e += G) (&w.Minv[0][0])[e] = 0.0;      // (the padded rows whole)
     }
   }
-  if constexpr (G == 16) bias_bodies_rows<NL, NL>(w, lm, m, sub < NL ? sub : -1, 0, sub == NL, FN);
+  if constexpr (G == 16) bias_bodies_rows<NL, NL>(w, lm, m, sub < NL ? sub : -1, 0, sub == NL, FN, kin);
   else if (split) {
     bias_bodies_rows<NL, KM_BLOCK_MAX>(w, lm, m, bli, bbase, false, FN);
     if (sub == NL) cube_bias<NL>(w, m);          // (lane NL also works on a link of the second block above)
@@ -2403,7 +2448,7 @@ __device__ __forceinline__ void step1_products(Ws<NL>& w, const LModel<NL>& lm, 
   GSYNC();
   pf.ph(2);
   if constexpr (G == 16) {
-    composite_mass_bias_rows<NL, NL>(w, lm, sub < NL ? sub : -1, 0, FN);
+    composite_mass_bias_rows<NL, NL>(w, lm, sub < NL ? sub : -1, 0, FN, kin);
   } else if (split) {
     composite_mass_bias_rows<NL, KM_BLOCK_MAX>(w, lm, bli, bbase, FN);
   } else {
