@@ -282,22 +282,29 @@ template <int NL, int G>
 __device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int sub, real* kin = nullptr) {
   real R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, p[3] = {0, 0, 0};
   const bool on = sub < NL;
-  if (on) {
-    const real q = w.qpos[sub];
-    p[0] = lm.pos[sub][0]; p[1] = lm.pos[sub][1]; p[2] = lm.pos[sub][2];
-    if (lm.jtype[sub] == KM_JNT_SLIDE) {
+  // (round 6) everything the pass reads about this lane's link -- its coordinate, its constant frame in the parent, its joint
+  // type, its jump table, its centre of mass -- in one batch: as written, each sat behind the branch that used it
+  const int li = on ? sub : 0;
+  real q = w.qpos[li], lp[3] = {lm.pos[li][0], lm.pos[li][1], lm.pos[li][2]}, lR[9], cl[3] = {lm.com[li][0], lm.com[li][1], lm.com[li][2]};
 #pragma unroll
-      for (int c = 0; c < 9; c++) R[c] = lm.R[sub][c];
+  for (int c = 0; c < 9; c++) lR[c] = lm.R[li][c];
+  int jt = lm.jtype[li], jmp0 = lm.jump[0][li], jmp1 = lm.jump[1][li], jmp2 = lm.jump[2][li], jmp3 = lm.jump[3][li], rounds = lm.fk_rounds;
+  km_pin(q); km_pin(lp, cl); km_pin(lR); km_pin_i(jt, rounds); km_pin_i(jmp0, jmp1); km_pin_i(jmp2, jmp3);
+  if (on) {
+    p[0] = lp[0]; p[1] = lp[1]; p[2] = lp[2];
+    if (jt == KM_JNT_SLIDE) {
+#pragma unroll
+      for (int c = 0; c < 9; c++) R[c] = lR[c];
       p[0] += R[2] * q; p[1] += R[5] * q; p[2] += R[8] * q;
     } else {
       real sn, cs;
       km_sincos(q, &sn, &cs);
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const real c0 = lm.R[sub][3 * a], c1 = lm.R[sub][3 * a + 1];
+        const real c0 = lR[3 * a], c1 = lR[3 * a + 1];
         R[3 * a] = cs * c0 + sn * c1;
         R[3 * a + 1] = cs * c1 - sn * c0;
-        R[3 * a + 2] = lm.R[sub][3 * a + 2];
+        R[3 * a + 2] = lR[3 * a + 2];
       }
     }
 #pragma unroll
@@ -311,9 +318,9 @@ __device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int
     for (int c = 0; c < 9; c++) w.k.cube_mat[c] = cm[c];
   }
   GSYNC();
-  const int rounds = lm.fk_rounds;
   for (int k = 0; k < rounds; k++) {
-    const int a = on ? lm.jump[k][sub] : -1;
+    const int jk = k == 0 ? jmp0 : (k == 1 ? jmp1 : (k == 2 ? jmp2 : jmp3));
+    const int a = on ? jk : -1;
     if (a >= 0) {
       real A[9], pa[3], Rn[9], t[3];
 #pragma unroll
@@ -338,7 +345,7 @@ __device__ __forceinline__ void fk_parallel(Ws<NL>& w, const LModel<NL>& lm, int
   }
   real cpo[3] = {0, 0, 0};
   if (on) {
-    real cl[3] = {lm.com[sub][0], lm.com[sub][1], lm.com[sub][2]}, cw[3];
+    real cw[3];
     mat_vec3(cw, R, cl);
     cpo[0] = p[0] + cw[0]; cpo[1] = p[1] + cw[1]; cpo[2] = p[2] + cw[2];
     w.k.cpos[sub][0] = cpo[0]; w.k.cpos[sub][1] = cpo[1]; w.k.cpos[sub][2] = cpo[2];
