@@ -986,13 +986,26 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
   constexpr int NSPH = Dim<NL>::NSPH, NSS = Dim<NL>::NSS, NST = Dim<NL>::NST;
   static_assert(8 + NSPH <= G, "one lane per collision candidate");
   uint32_t mask = 0, act = 0;
-  const real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]};
+  // (round 6) the cube's pose and this lane's candidate (sphere s = sub - 8: link, centre, radius, capsule segment) in one batch;
+  // the candidate's link frame -- the one dependent read -- in a second
+  const int sidx = sub >= 8 && sub - 8 < NSPH ? sub - 8 : 0;
+  real cp[3] = {w.qpos[NL], w.qpos[NL + 1], w.qpos[NL + 2]}, cmat[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) cmat[k] = w.k.cube_mat[k];
+  int lnk = lm.sph_link[sidx], nsph_ = lm.nsph;
+  real slp[3] = {lm.sph_pos[sidx][0], lm.sph_pos[sidx][1], lm.sph_pos[sidx][2]}, sgp[3] = {lm.sph_seg[sidx][0], lm.sph_seg[sidx][1], lm.sph_seg[sidx][2]}, radp = lm.sph_rad[sidx];
+  km_pin(cp); km_pin(cmat); km_pin(slp, sgp); km_pin(radp); km_pin_i(lnk, nsph_);
+  real lmat[9], lpos[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) lmat[k] = w.k.xmat[lnk][k];
+  lpos[0] = w.k.xpos[lnk][0]; lpos[1] = w.k.xpos[lnk][1]; lpos[2] = w.k.xpos[lnk][2];
+  uint32_t lanc = lm.anc[lnk];
   const real tr[4] = {m->table_rect[0], m->table_rect[1], m->table_rect[2], m->table_rect[3]};
   bool below = false;
   real c[3] = {0, 0, 0}, dist = 0;
   if (sub < 8) {
     const real loc[3] = {(sub & 1 ? 1 : -1) * m->cube_half[0], (sub & 2 ? 1 : -1) * m->cube_half[1], (sub & 4 ? 1 : -1) * m->cube_half[2]};
-    mat_vec3(c, w.k.cube_mat, loc);
+    mat_vec3(c, cmat, loc);
     c[0] += cp[0]; c[1] += cp[1]; c[2] += cp[2];
     dist = c[2] - m->table_z;
     below = (dist < 0) & over_table(tr, c);
@@ -1010,17 +1023,17 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
       mask |= KM_CON_CUBE_TABLE(sub); act |= 1u << n;
     }
   }
-  const int nsph = lm.nsph;
+  const int nsph = nsph_;
   const int s = sub - 8;
   bool hitc = false, hitt = false;
   real ctr[3] = {0, 0, 0}, ctrt[3] = {0, 0, 0}, nloc[3] = {0, 0, 0}, d1 = 0, d2 = 0, rad = 0;
+  km_pin(lmat); km_pin(lpos); asm volatile("" : "+v"(lanc));
   if (sub >= 8 && sub < 8 + nsph) {
-    const int l = lm.sph_link[s];
-    real sl[3] = {lm.sph_pos[s][0], lm.sph_pos[s][1], lm.sph_pos[s][2]}, rel[3], loc[3], cl[3];
-    mat_vec3(ctr, w.k.xmat[l], sl);
+    real sl[3] = {slp[0], slp[1], slp[2]}, rel[3], loc[3], cl[3];
+    mat_vec3(ctr, lmat, sl);
 #pragma unroll
-    for (int a = 0; a < 3; a++) ctr[a] += w.k.xpos[l][a];
-    rad = lm.sph_rad[s];
+    for (int a = 0; a < 3; a++) ctr[a] += lpos[a];
+    rad = radp;
     // table plane (geom1) - sphere (geom2): the end sphere itself (a capsule meets a plane in its end spheres)
     d2 = ctr[2] - m->table_z - rad;
     hitt = (d2 < 0) & over_table(tr, ctr);
@@ -1028,9 +1041,9 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
     // capsule section (kmanip.h sphere_seg): against the cube the collider is the point of the link's segment closest to the
     // cube centre -- a sphere sliding along the link
     {
-      const real sg[3] = {lm.sph_seg[s][0], lm.sph_seg[s][1], lm.sph_seg[s][2]};
+      const real sg[3] = {sgp[0], sgp[1], sgp[2]};
       real sw[3];
-      mat_vec3(sw, w.k.xmat[l], sg);
+      mat_vec3(sw, lmat, sg);
       const real ss = dot3(sw, sw);
       if (ss > 0) {
         real t = ((cp[0] - ctr[0]) * sw[0] + (cp[1] - ctr[1]) * sw[1] + (cp[2] - ctr[2]) * sw[2]) / ss;
@@ -1042,7 +1055,7 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
 #pragma unroll
     for (int a = 0; a < 3; a++) rel[a] = ctr[a] - cp[a];
     // sphere (geom1) - cube box (geom2)
-    matT_vec3(loc, w.k.cube_mat, rel);
+    matT_vec3(loc, cmat, rel);
     bool inside = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) { cl[a] = fmin(fmax(loc[a], -m->cube_half[a]), m->cube_half[a]); if (cl[a] != loc[a]) inside = false; }
@@ -1067,14 +1080,14 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
   if (hitc && __popc(mc) < NSS) {
     const int n = 4 + __popc(mc);
     real fr[9];
-    mat_vec3(fr, w.k.cube_mat, nloc);
+    mat_vec3(fr, cmat, nloc);
     make_frame(fr);
 #pragma unroll
     for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
     w.c_dist[n] = d1;
 #pragma unroll
     for (int a = 0; a < 3; a++) w.c_pos[n][a] = ctr[a] + fr[a] * (rad + 0.5 * d1);
-    w.slot_sph[n] = s; w.slot_anc[n] = lm.anc[lm.sph_link[s]];
+    w.slot_sph[n] = s; w.slot_anc[n] = lanc;
     mask |= KM_CON_SPHERE_CUBE(s); act |= 1u << n;
   }
   if (hitt && __popc(mt) < NST) {
@@ -1084,7 +1097,7 @@ __device__ __forceinline__ int collide_parallel(Ws<NL>& w, const LModel<NL>& lm,
     for (int k = 0; k < 9; k++) w.c_frame[n][k] = fr[k];
     w.c_dist[n] = d2;
     w.c_pos[n][0] = ctrt[0]; w.c_pos[n][1] = ctrt[1]; w.c_pos[n][2] = ctrt[2] - (rad + 0.5 * d2);
-    w.slot_sph[n] = s; w.slot_anc[n] = lm.anc[lm.sph_link[s]];
+    w.slot_sph[n] = s; w.slot_anc[n] = lanc;
     mask |= KM_CON_SPHERE_TABLE(s); act |= 1u << n;
   }
   mask = (uint32_t)gor<G>((int)mask);
@@ -2405,20 +2418,34 @@ __device__ __forceinline__ real solve_newton(Ws<NL>& w, const LModel<NL>& lm, co
                                              CReg<NL>& cr, real invm, Prof& pf) {
   constexpr int NV = Dim<NL>::NV;
   // ---- actuation and smooth acceleration (as in the PGS path)
+  // (round 6) the lane's inputs and its row of M^-1 in one batch in front of the exchange, the right-hand sides in one behind it
+  const int si = sub < NL ? sub : NL - 1, sv = sub < NV ? sub : NV - 1;
+  real bia = w.bias[sv], ctl = w.ctrl[si], cr0 = lm.ctrlrange[si][0], cr1 = lm.ctrlrange[si][1], kpv = lm.kp[si], qps = w.qpos[si];
+  real fr0 = lm.forcerange[si][0], fr1 = lm.forcerange[si][1];
+  int flim = lm.forcelimited[si];
+  real mrow[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) mrow[j] = w.Minv[si][j];
+  km_pin(bia, ctl, cr0, cr1, kpv, qps); km_pin(fr0, fr1); km_pin_i(flim);
+  real rhs = -bia;
   if (sub < NV) {
-    real rhs = -w.bias[sub];
     if (actuation && sub < NL) {
-      real c = fmin(fmax(w.ctrl[sub], lm.ctrlrange[sub][0]), lm.ctrlrange[sub][1]);
-      real force = lm.kp[sub] * c - lm.kp[sub] * w.qpos[sub];
-      if (lm.forcelimited[sub]) force = fmin(fmax(force, lm.forcerange[sub][0]), lm.forcerange[sub][1]);
+      real c = fmin(fmax(ctl, cr0), cr1);
+      real force = kpv * c - kpv * qps;
+      if (flim) force = fmin(fmax(force, fr0), fr1);
       rhs += force;
     }
     w.tmp[sub] = rhs;
   }
   GSYNC();
+  real tv[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) tv[j] = w.tmp[j];
   real a_s = 0;
-  if (sub < NL) { for (int j = 0; j < NL; j++) a_s += w.Minv[sub][j] * w.tmp[j]; }
-  else if (sub < NV) a_s = w.tmp[sub] * invm;
+  if (sub < NL) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) a_s += mrow[j] * tv[j];
+  } else if (sub < NV) a_s = rhs * invm;
   pf.ph(7);
   return solve_newton_sl<NL, G>(w, lm, m, sub, cr, a_s, invm, pf);
 }
