@@ -2753,7 +2753,6 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
   stage_model<NL>(lm, dm);
   if (env < 0) return;                                 // whole group exits together
   Ws<NL>& w = ws[grp];
-  CReg<NL> cr;
   real invm = 0;                       // diagonal of M^-1 for the cube dof owned by this lane
   if (sub >= NL && sub < NV) invm = sub < NL + 3 ? 1.0 / m->cube_mass : 1.0 / m->cube_inertia[sub - NL - 3];
   Prof pf;
@@ -2787,12 +2786,17 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     // ---- KManipTask.before_step: 8 lanes per arm, one arm per 16-lane DPP row of the group (lanes 0-7 of row 0: right arm;
     // of row 1, in the two-row groups: left arm), the rest idle.
     // Fused here so that an env whose IK needs many evaluations delays only its own wave, not the whole batch.
-    const int arm = sub / GS;
-    if (sub % GS < GI && arm < KM_MAX_ARMS && (NL > 10 || arm == 0) && m->arm_present[arm]) {
+    // (chunk kernels: the lane index is made opaque once per control step, like the dof index per sub-step below -- otherwise the
+    // IK's per-lane chain constants, invariant across the steps of a chunk, are hoisted out of the chunk loop and kept alive
+    // through the physics: the two-arm chunk kernels sat at the 512-register cap with 268 / 116 bytes of scratch)
+    int subk = sub;
+    if constexpr (CHUNK) asm volatile("" : "+v"(subk));
+    const int arm = subk / GS;
+    if (subk % GS < GI && arm < KM_MAX_ARMS && (NL > 10 || arm == 0) && m->arm_present[arm]) {
       LdsIO<NL> io{w, st, env};
       const float* arow = act + ((size_t)kc * NE + env) * m->act_dim;
-      if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, arm, sub % GS, arow, io, &pf);
-      else coop_before_step<6>(dm, arm, sub % GS, arow, io, &pf);
+      if (m->arm_nq[arm] == 7) coop_before_step<7>(dm, arm, subk % GS, arow, io, &pf);
+      else coop_before_step<6>(dm, arm, subk % GS, arow, io, &pf);
     }
     GSYNC();
     pf.ph(30);
@@ -2805,6 +2809,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     // constants, masks) is recomputed inside the sub-step instead of being hoisted out of this loop and kept alive -- or
     // shuttled through AGPRs -- across all ten (380 -> 318 registers, measured)
     int subv = sub; asm volatile("" : "+v"(subv));
+    CReg<NL> cr;                       // (one per sub-step: nothing of it can be carried round the loops)
     step1_products<NL, G, SOLVER>(w, lm, m, subv, cr, invm, pf);      // s == 0: products of the pre-IK state (stale mj_step2)
     real a = solve<NL, G, SOLVER>(w, lm, m, subv, 1, cr, invm, pf);
     pf.ph(28);
@@ -2853,6 +2858,7 @@ __global__ __launch_bounds__(64) void k_step(const KDeviceModel* __restrict__ dm
     heavy_next = 0; table_next = 0;               // (the respawned cube is nowhere near the home pose)
     GSYNC();
     pf.ph(31);
+    CReg<NL> cr;
     reset_env<NL, G, SOLVER>(w, lm, m, sub, st.seed, st.env_id_offset + env, episode, cr, invm, pf);
     write_obs<NL, G>(w, lm, m, sub, obs_row);
     pf.ph(32);
