@@ -2518,17 +2518,21 @@ template <int NL, int G>
 __device__ __forceinline__ void integrate(Ws<NL>& w, const KModelDesc* m, int sub, real a) {
   constexpr int NV = Dim<NL>::NV;
   const real dt = m->timestep;
+  // (round 6) the lane's velocity / position and the cube's quaternion in one batch; the new angular velocity reaches lane 0 by row
+  // broadcast instead of through LDS (one synchronisation and one round trip less in front of the quaternion's serial chain)
+  const int sv = sub < NV ? sub : NV - 1, sq = sub < NL + 3 ? sub : NL + 2;
+  real v0 = w.qvel[sv], qp = w.qpos[sq], q[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]};
+  km_pin(v0, qp, q[0], q[1], q[2], q[3]);
+  real v = 0;
   if (sub < NV) {
-    real v = w.qvel[sub] + dt * a;
+    v = v0 + dt * a;
     w.qvel[sub] = v;
     w.warm[sub] = a;
-    if (sub < NL + 3) w.qpos[sub] += dt * v;
+    if (sub < NL + 3) w.qpos[sub] = qp + dt * v;
   }
-  GSYNC();
+  real ax[3] = {gbcast<G, NL + 3>(v), gbcast<G, NL + 4>(v), gbcast<G, NL + 5>(v)};
   if (sub == 0) {
-    real ax[3] = {w.qvel[NL + 3], w.qvel[NL + 4], w.qvel[NL + 5]};
     real ang = dt * normalize3_fast(ax), qr[4], qn[4];
-    real q[4] = {w.qpos[NL + 3], w.qpos[NL + 4], w.qpos[NL + 5], w.qpos[NL + 6]};
     axis_angle2quat(qr, ax, ang);
     normalize4_fast(q);
     qmul(qn, q, qr);
@@ -2538,6 +2542,7 @@ __device__ __forceinline__ void integrate(Ws<NL>& w, const KModelDesc* m, int su
   GSYNC();
 }
 
+// [-1, 1] clip of an observation component
 __device__ __forceinline__ real clip1(real x) { return fmin(fmax(x, -1.0), 1.0); }
 
 // get_observation, env_sim.py:110-146 (state keys; cameras are out of this kernel)
