@@ -2220,12 +2220,16 @@ __device__ __forceinline__ void newton_loop_sl(Ws<NL>& w, const LModel<NL>& lm, 
             const real lo = h[k], hi = split == 10 ? h[(10 + k) < NL ? 10 + k : NL - 1] : h[(11 + k) < NL ? 11 + k : NL - 1];
             mine[k] = sub < split ? lo : hi;
           }
+          // (round 6) all twelve shuffles in flight together: taken one at a time, each pair of ds_bpermute was waited for before the
+          // next was issued (twelve round trips per iteration of a two-arm env's arm problem)
+          real sv[NB];
 #pragma unroll
-          for (int k = 0; k < NB; k++) {
-            const real v = __shfl(mine[k], src, 64);
-            loc[k] = (on && k < nb) ? v : ((!on && k == c) ? 1.0 : 0.0);
-          }
-          const real gsrc = __shfl(in ? -grad : 0.0, src, 64);
+          for (int k = 0; k < NB; k++) sv[k] = __shfl(mine[k], src, 64);
+          real gsrc = __shfl(in ? -grad : 0.0, src, 64);
+          static_assert(NB == 11, "the pins below name eleven block columns");
+          km_pin(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5]); km_pin(sv[6], sv[7], sv[8], sv[9], sv[10], gsrc);
+#pragma unroll
+          for (int k = 0; k < NB; k++) loc[k] = (on && k < nb) ? sv[k] : ((!on && k == c) ? 1.0 : 0.0);
           real invl = 0, utl[NB];
           chol_rows1<NB, 0, NB, 0, true>(loc, utl, invl, c, true, hbad);
           if (__any(hbad)) { const int gb = gor<G>(hbad); if (gb && sub == 0) w.bad = 1; }
