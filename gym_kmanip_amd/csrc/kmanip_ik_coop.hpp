@@ -85,10 +85,6 @@ struct CoopCtx {
   // this lane's chain link (position c of the root -> site chain): constant rotation / offset in its parent
   real cR[9], cp[3];
   int clen, cslide;           // chain length; 1 if this lane's link is a slide joint
-  // (round 6) the model constants every evaluation / cost / gradient reads -- the site's frame in its link, the residual and
-  // Jacobian weights -- fetched ONCE per problem into registers: as m-> / ax-> reads they were scalar loads re-issued, and each
-  // waited for on its own, inside every one of the ~15 evaluations (the SGPR file cannot hold them across the solve)
-  real site_pos[3], site_R[9], res_rad, jac_rad, reg_prev, reg_home, jac_reg;
   Prof* pf;                   // phase stamps of the diagnostic build (no-ops in the product)
 };
 // per-problem constants of lane c (call once per problem, after arm / c / m / ax are set)
@@ -101,14 +97,6 @@ __device__ __forceinline__ void coop_chain_setup(CoopCtx<N>& P) {
   for (int i = 0; i < 9; i++) P.cR[i] = P.ax->chain_R[P.arm][k][i];
   P.cp[0] = P.m->link_pos[l][0]; P.cp[1] = P.m->link_pos[l][1]; P.cp[2] = P.m->link_pos[l][2];
   P.cslide = P.m->jnt_type[l] == KM_JNT_SLIDE;
-#pragma unroll
-  for (int i = 0; i < 3; i++) P.site_pos[i] = P.m->arm_site_pos[P.arm][i];
-#pragma unroll
-  for (int i = 0; i < 9; i++) P.site_R[i] = P.ax->site_R[P.arm][i];
-  P.res_rad = P.m->ik_res_rad; P.jac_rad = P.m->ik_jac_rad;
-  P.reg_prev = P.m->ik_res_reg_prev; P.reg_home = P.m->ik_res_reg_home; P.jac_reg = P.m->ik_jac_reg;
-  // (opaque: the values stay in vector registers for the whole solve instead of being rematerialised by a reload)
-  km_pin(P.site_pos); km_pin(P.site_R); km_pin(P.res_rad, P.jac_rad, P.reg_prev, P.reg_home, P.jac_reg);
 }
 // value of lane (c - S) of the same 8-lane problem (garbage for c < S: callers mask); DPP row_shr
 template <int S> __device__ __forceinline__ real shr8(real v) { return dpp_f64<0x110 + S>(v); }
@@ -171,8 +159,8 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
   pos[0] = bcast8<GI - 1>(p[0]); pos[1] = bcast8<GI - 1>(p[1]); pos[2] = bcast8<GI - 1>(p[2]);
   const real anc[3] = {p[0], p[1], p[2]}, axw[3] = {R[2], R[5], R[8]};
   real sp[3], smat[9], cur[4], rq[3];
-  real so[3] = {P.site_pos[0], P.site_pos[1], P.site_pos[2]};
-  const double* Rs = P.site_R;
+  real so[3] = {m->arm_site_pos[arm][0], m->arm_site_pos[arm][1], m->arm_site_pos[arm][2]};
+  const double* Rs = P.ax->site_R[arm];
   mat_vec3(sp, mat, so);
   sp[0] += pos[0]; sp[1] += pos[1]; sp[2] += pos[2];
 #pragma unroll
@@ -188,7 +176,7 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
     for (int i = 0; i < 9; i++) smat_out[i] = smat[i];
   }
   ft[0] = sp[0] - P.goal_pos[0]; ft[1] = sp[1] - P.goal_pos[1]; ft[2] = sp[2] - P.goal_pos[2];
-  ft[3] = rq[0] * P.res_rad; ft[4] = rq[1] * P.res_rad; ft[5] = rq[2] * P.res_rad;
+  ft[3] = rq[0] * m->ik_res_rad; ft[4] = rq[1] * m->ik_res_rad; ft[5] = rq[2] * m->ik_res_rad;
   if (JAC) {
     // mjd_subQuat: Da = I + h K + (1 - h / tan h) K^2 (K = [axs]x, |axs| = 1, so K^2 v = axs (axs . v) - v), D_ee = -Da^T;
     // J_orn column = rad * D_ee^T * site_xmat^T * axis = -rad * Da * (site_xmat^T axis): applied to the one vector this lane
@@ -209,7 +197,7 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
       cross3(cx, axs, uu);
       const real du = dot3(axs, uu);
 #pragma unroll
-      for (int i = 0; i < 3; i++) Jc[3 + i] = -P.jac_rad * ((uu[i] + half * cx[i]) + coef * (axs[i] * du - uu[i]));
+      for (int i = 0; i < 3; i++) Jc[3 + i] = -m->ik_jac_rad * ((uu[i] + half * cx[i]) + coef * (axs[i] * du - uu[i]));
     }
   }
 }
@@ -217,7 +205,7 @@ __device__ __forceinline__ void coop_eval(const CoopCtx<N>& P, real x, real* ft,
 // cost = 0.5 |f|^2 (task + both regulariser blocks, ik_mujoco.py:48-53)
 template <int N>
 __device__ __forceinline__ real coop_cost(const CoopCtx<N>& P, real x, const real* ft) {
-  real a = P.reg_prev * (x - P.q_prev), b = P.reg_home * (x - P.q_home);
+  real a = P.m->ik_res_reg_prev * (x - P.q_prev), b = P.m->ik_res_reg_home * (x - P.q_home);
   real loc = P.on ? a * a + b * b : 0.0;
   real s = gsum8(loc);
 #pragma unroll
@@ -230,7 +218,7 @@ __device__ __forceinline__ real coop_grad(const CoopCtx<N>& P, real x, const rea
   real s = 0;
 #pragma unroll
   for (int r = 0; r < 6; r++) s += Jc[r] * ft[r];
-  return s + P.jac_reg * (P.reg_prev * (x - P.q_prev) + P.reg_home * (x - P.q_home));
+  return s + P.m->ik_jac_reg * (P.m->ik_res_reg_prev * (x - P.q_prev) + P.m->ik_res_reg_home * (x - P.q_home));
 }
 
 // ---- trust-region subproblem, cooperative over the problem's 8 lanes (round 3; round 2 factorised the 7 x 7 redundantly in
@@ -535,7 +523,7 @@ template <int N>
 __device__ int coop_trf(const CoopCtx<N>& P, real& x, real& x_last, int* nfev_out) {
   const real ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
   const int max_nfev = P.m->ik_max_nfev > 0 ? P.m->ik_max_nfev : 100 * N;      // (KModelDesc::ik_max_nfev: opt-in cap, 0 = SciPy's default)
-  const real jreg2 = 2 * P.jac_reg * P.jac_reg;
+  const real jreg2 = 2 * P.m->ik_jac_reg * P.m->ik_jac_reg;
   real ft[6], Jc[6], ft_new[6], Jn[6], e[N];
 #pragma unroll
   for (int j = 0; j < N; j++) e[j] = P.c == j ? 1.0 : 0.0;

@@ -27,6 +27,7 @@ for env in ["KManipSoloArm", "KManipDualArm", "KManipTorso"]:
     rng = None
     worst = dict(q=0.0, v=0.0, r=0.0)
     n_mask = n_done = n_ctrl = n_nfev = 0
+    n_q10 = n_q9 = 0                              # one-step samples (float32 ctrl agreeing) with |dq| above 1e-10 / 1e-9: how FAT is the tail behind `worst`?
     seen = 0
     t0 = time.time()
     for k in range(steps):
@@ -45,12 +46,14 @@ for env in ["KManipSoloArm", "KManipDualArm", "KManipTorso"]:
                      **{"dev%d" % i: sg[i][e] for i in range(5)}, **{"orc%d" % i: so[i][e] for i in range(5)})
         worst["q"] = max(worst["q"], float(np.abs(sg[0] - so[0])[ok].max())); worst["v"] = max(worst["v"], float(np.abs(sg[1] - so[1])[ok].max()))
         worst["r"] = max(worst["r"], float(np.abs(dev.reward.cpu().numpy() - ro)[ok].max()))
+        dqk = np.where(ok, np.abs(sg[0] - so[0]).max(axis=1), 0.0)
+        n_q10 += int((dqk > 1e-10).sum()); n_q9 += int((dqk > 1e-9).sum())
         mg, nfg, stg = dev.get_diag(); mo, nfo, sto = orc.get_diag()
         n_mask += int((mg != mo).sum()); n_done += int((dev.done.cpu().numpy() != do).sum()); n_ctrl += int((sg[2] != so[2]).any(axis=1).sum())
         n_nfev += int((np.abs(nfg - nfo) > 1).sum())
         seen |= int(np.bitwise_or.reduce(mg))
         orc.set_state(*sg)                       # one-step samples
         orc.set_episode(dev.get_episode()) if hasattr(orc, "set_episode") else None
-    print("%-14s %d envs x %d steps (%.0f s): worst one-step |dq| %.2e |dv| %.2e |dr| %.2e (envs whose float32 ctrl agrees); mismatches: mask %d done %d ctrl(f32) %d nfev(>1) %d; bits seen %#x" % (
-        env, n, steps, time.time() - t0, worst["q"], worst["v"], worst["r"], n_mask, n_done, n_ctrl, n_nfev, seen), flush=True)
+    print("%-14s %d envs x %d steps (%.0f s): worst one-step |dq| %.2e |dv| %.2e |dr| %.2e (envs whose float32 ctrl agrees); mismatches: mask %d done %d ctrl(f32) %d nfev(>1) %d; samples with |dq| > 1e-10: %d, > 1e-9: %d of %d; bits seen %#x" % (
+        env, n, steps, time.time() - t0, worst["q"], worst["v"], worst["r"], n_mask, n_done, n_ctrl, n_nfev, n_q10, n_q9, n * steps, seen), flush=True)
     dev.k_close()

@@ -68,7 +68,16 @@ def phase_of(chain, src, stamps, fn_of):
         text = src[l - 1] if 0 < l <= len(src) else ""
         fn = fn_of(l)
         if fn == "k_step":
-            if "coop_before_step" in text: return "IK"
+            if "coop_before_step" in text:
+                # refined by where in coop_trf (kmanip_ik_coop.hpp) the instruction sits: set-up | once per outer iteration
+                # (normal matrix, scaling) | once per trial point (trust-region solve, step, evaluation, ratio) | acceptance tests
+                for f2, l2 in reversed(chain):
+                    if f2 == "kmanip_ik_coop.hpp" and IK["lo"] <= l2 <= IK["hi"]:
+                        if l2 < IK["outer"]: return "IK: trf set-up"
+                        if l2 < IK["trial"]: return "IK: per outer iteration"
+                        if l2 <= IK["trial_end"]: return "IK: per trial point"
+                        return "IK: acceptance / tests"
+                return "IK: decode, first evaluation, write-back"
             if "step1_products" in text: top = "step1"; continue
             if "solve<" in text: top = "solve"; continue
             if "integrate<" in text: return "integrate"
@@ -110,6 +119,20 @@ def phase_of(chain, src, stamps, fn_of):
     return top or "?"
 
 
+IK = {}
+
+
+def ik_lines(path):
+    """line landmarks of coop_trf in kmanip_ik_coop.hpp: its extent, the outer `for (;;)`, the inner `while (actual <= 0 ...)`, stamp 37"""
+    src = open(path).read().split("\n")
+    lo = next(i for i, l in enumerate(src, 1) if "int coop_trf(" in l)
+    hi = next(i for i, l in enumerate(src, 1) if i > lo and l.startswith("}"))
+    IK.update(lo=lo, hi=hi,
+              outer=next(i for i, l in enumerate(src, 1) if i > lo and "for (;;)" in l),
+              trial=next(i for i, l in enumerate(src, 1) if i > lo and "while (actual <= 0" in l),
+              trial_end=next(i for i, l in enumerate(src, 1) if i > lo and "pf->ph(37)" in l))
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     path, sym = args[0], args[1]
@@ -118,6 +141,7 @@ def main():
     src_path = opt.get("src", os.path.join(here, "..", "gym_kmanip_amd", "csrc", "kmanip_dyn.hip"))
     src = open(src_path).read().split("\n")
     stamps = newton_stamps(src)
+    ik_lines(os.path.join(os.path.dirname(src_path), "kmanip_ik_coop.hpp"))
     # function of a source line: the nearest preceding "__device__ ... name(" / "__global__ ... name(" definition
     starts = []
     for i, ln in enumerate(src, 1):
