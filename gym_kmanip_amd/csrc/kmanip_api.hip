@@ -226,6 +226,8 @@ int kmanip_create(const KModelDesc* desc, int num_envs, int device, uint64_t see
   };
   CR(dalloc((void**)&h->dmodel, sizeof(KDeviceModel)));
   CR(hipMemcpy(h->dmodel, &hm, sizeof(KDeviceModel), hipMemcpyHostToDevice));
+  kmanip_launch_prepare_model(h->dmodel, *desc, nullptr);       // the kernels' LDS image of the model constants, built once (KDeviceModel::staged)
+  CR(hipGetLastError());
   CR(dalloc((void**)&h->st.qpos, sizeof(double) * nq * N));
   CR(dalloc((void**)&h->st.qvel, sizeof(double) * nv * N));
   CR(dalloc((void**)&h->st.ctrl, sizeof(double) * nl * N));

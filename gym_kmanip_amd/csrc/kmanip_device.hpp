@@ -37,9 +37,15 @@ struct KModelAux {
 };
 #define KM_RENDER_MAXVIS 4
 
+// `staged` (round 6): the per-workgroup LDS image of the model constants (kmanip_dyn.hip: LModel<NL>), built ONCE at kmanip_create by
+// k_prepare_model.  Every workgroup of every step used to derive it itself -- ~40 per-lane global loads and, on lane 0, eighteen
+// dependent scalar-load round trips (solref / solimp staging, the collider pairs' diagApprox constants): 6-8 k cycles at the start
+// of every wave of every launch.  Now a launch's workgroups copy 4-8 KB with one batch of 16-byte loads.
+#define KM_LMODEL_MAX 8192
 struct KDeviceModel {
   KModelDesc d;
   KModelAux x;
+  alignas(16) unsigned char staged[KM_LMODEL_MAX];
 };
 
 typedef double real;
@@ -534,6 +540,8 @@ struct KDeviceState {
   uint64_t seed;
 };
 
+// fills dm->staged (device memory) for the model's link-count class; kmanip_create, once
+void kmanip_launch_prepare_model(KDeviceModel* dm, const KModelDesc& hd, hipStream_t stream);
 void kmanip_launch_ik_coop(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act,
                            hipStream_t stream);
 void kmanip_launch_ik_coop_standalone(const KDeviceModel* dm, const KModelDesc& hd, int arm, int n, double* qpos_env_major,

@@ -7,6 +7,8 @@
 KM_DECL(10, 16, 0) KM_DECL(10, 16, 1) KM_DECL(20, 32, 0) KM_DECL(20, 32, 1)
 #undef KM_DECL
 void kmanip_launch_observe_10_16_1(const KDeviceModel*, const KDeviceState&, double*, double*, hipStream_t);
+void kmanip_launch_prepare_10_16_1(KDeviceModel*, hipStream_t);
+void kmanip_launch_prepare_20_32_1(KDeviceModel*, hipStream_t);
 void kmanip_launch_observe_20_32_1(const KDeviceModel*, const KDeviceState&, double*, double*, hipStream_t);
 
 void kmanip_launch_step(const KDeviceModel* dm, const KModelDesc& hd, const KDeviceState& st, const float* act, double* obs, double* reward,
@@ -26,4 +28,8 @@ void kmanip_launch_observe(const KDeviceModel* dm, const KModelDesc& hd, const K
                            hipStream_t stream) {
   if (hd.nlink <= 10) kmanip_launch_observe_10_16_1(dm, st, obs, reward, stream);
   else kmanip_launch_observe_20_32_1(dm, st, obs, reward, stream);
+}
+void kmanip_launch_prepare_model(KDeviceModel* dm, const KModelDesc& hd, hipStream_t stream) {
+  if (hd.nlink <= 10) kmanip_launch_prepare_10_16_1(dm, stream);
+  else kmanip_launch_prepare_20_32_1(dm, stream);
 }

@@ -65,7 +65,7 @@ template <int NL> __device__ __forceinline__ constexpr int slot_kind(int c) { re
 // Per-link model constants staged in LDS once per workgroup (lane-indexed reads stay on-chip); scalars
 // and small fixed arrays are read straight from the global KModelDesc with wave-uniform (scalar) loads.
 template <int NL>
-struct LModel {
+struct alignas(16) LModel {
   int parent[NL], jtype[NL], forcelimited[NL];
   uint32_t anc[NL], desc[NL];
   int jump[4][NL], fk_rounds, split;
@@ -2637,9 +2637,24 @@ __device__ __forceinline__ void store_state(const Ws<NL>& w, const KDeviceState&
   for (int i = sub; i < NL; i += G) st.ctrl[(size_t)i * NE + env] = w.ctrl[i];
 }
 
-// per-link constants -> LDS with all 64 lanes, then a workgroup barrier (one wave: cheap)
+// per-link constants -> LDS: a flat copy of the image k_prepare_model built at kmanip_create (KDeviceModel::staged), one batch of
+// 16-byte loads per lane, then a workgroup barrier (one wave: cheap)
 template <int NL>
 __device__ __forceinline__ void stage_model(LModel<NL>& lm, const KDeviceModel* dm) {
+  static_assert(sizeof(LModel<NL>) % 16 == 0 && sizeof(LModel<NL>) <= KM_LMODEL_MAX, "the staged image is copied in 16-byte pieces");
+  constexpr int N16 = (int)(sizeof(LModel<NL>) / 16);
+  const uint4* src = reinterpret_cast<const uint4*>(dm->staged);
+  uint4* dst = reinterpret_cast<uint4*>(&lm);
+  uint4 v[(N16 + 63) / 64];
+#pragma unroll
+  for (int k = 0; k < (N16 + 63) / 64; k++) { const int i = threadIdx.x + 64 * k; v[k] = src[i < N16 ? i : N16 - 1]; }
+#pragma unroll
+  for (int k = 0; k < (N16 + 63) / 64; k++) { const int i = threadIdx.x + 64 * k; if (i < N16) dst[i] = v[k]; }
+  __syncthreads();
+}
+// the image itself: per-link constants with all 64 lanes, the derived scalars on lane 0 (k_prepare_model only)
+template <int NL>
+__device__ __forceinline__ void build_lmodel(LModel<NL>& lm, const KDeviceModel* dm) {
   const KModelDesc* m = &dm->d;
   for (int i = threadIdx.x; i < NL; i += 64) {
     lm.parent[i] = m->link_parent[i]; lm.jtype[i] = m->jnt_type[i]; lm.forcelimited[i] = m->forcelimited[i];
@@ -2988,6 +3003,17 @@ static void launch_reset_t(const KDeviceModel* dm, const KDeviceState& st, const
   if (epb == 2) return launch_reset_e<NL, G, SOLVER, 2>(dm, st, mask, obs, stream);
   launch_reset_e<NL, G, SOLVER, 1>(dm, st, mask, obs, stream);
 }
+// kmanip_create, once: the LDS image of the model constants into KDeviceModel::staged (one workgroup)
+template <int NL>
+__global__ __launch_bounds__(64) void k_prepare_model(KDeviceModel* dm) {
+  __shared__ LModel<NL> lm;
+  { unsigned char* z = reinterpret_cast<unsigned char*>(&lm); for (int i = threadIdx.x; i < (int)sizeof(LModel<NL>); i += 64) z[i] = 0; }      // (padding bytes: defined)
+  __syncthreads();
+  build_lmodel<NL>(lm, dm);
+  const uint4* src = reinterpret_cast<const uint4*>(&lm);
+  uint4* dst = reinterpret_cast<uint4*>(dm->staged);
+  for (int i = threadIdx.x; i < (int)(sizeof(LModel<NL>) / 16); i += 64) dst[i] = src[i];
+}
 template <int NL, int G>
 static void launch_observe_t(const KDeviceModel* dm, const KDeviceState& st, double* obs, double* reward, hipStream_t stream) {
   constexpr int EPB = 64 / G;
@@ -3008,6 +3034,9 @@ void KM_CAT4(kmanip_launch_reset_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDe
   launch_reset_t<KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER>(dm, st, mask, obs, stream);
 }
 #if KM_VAR_SOLVER == 1      // (solver-independent: one copy per link-count class)
+void KM_CAT4(kmanip_launch_prepare_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(KDeviceModel* dm, hipStream_t stream) {
+  hipLaunchKernelGGL((k_prepare_model<KM_VAR_NL>), dim3(1), dim3(64), 0, stream, dm);
+}
 void KM_CAT4(kmanip_launch_observe_, KM_VAR_NL, KM_VAR_G, KM_VAR_SOLVER)(const KDeviceModel* dm, const KDeviceState& st, double* obs,
                                                                        double* reward, hipStream_t stream) {
   launch_observe_t<KM_VAR_NL, KM_VAR_G>(dm, st, obs, reward, stream);
