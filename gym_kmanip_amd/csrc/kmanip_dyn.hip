@@ -2609,16 +2609,34 @@ template <int NL, int G>
 __device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, int env, int sub, bool fused) {
   constexpr int NV = Dim<NL>::NV, NQ = Dim<NL>::NQ;
   const int NE = st.num_envs;
-  for (int i = sub; i < NQ; i += G) { const real q = st.qpos[(size_t)i * NE + env]; w.qpos[i] = q; if (fused && i < NL) w.qpos_ik[i] = q; }
-  for (int i = sub; i < NV; i += G) { w.qvel[i] = st.qvel[(size_t)i * NE + env]; w.warm[i] = st.warm[(size_t)i * NE + env]; }
-  for (int i = sub; i < NL; i += G) {
-    const real c = st.ctrl[(size_t)i * NE + env];
-    w.ctrl[i] = fused ? (real)(float)c : c;
-    if (!fused) w.qpos_ik[i] = st.qpos_ik[(size_t)i * NE + env];
+  // (round 6) every column read of the env's state issued before the first is waited for: as loops, each HBM read was waited for
+  // on its own (five to six round trips at the start of every wave)
+  constexpr int KQ = (NQ + G - 1) / G, KV = (NV + G - 1) / G, KL = (NL + G - 1) / G;
+  real q[KQ], v[KV], wm[KV], c[KL], qi[KL];
+#pragma unroll
+  for (int k = 0; k < KQ; k++) { const int i = sub + G * k; q[k] = st.qpos[(size_t)(i < NQ ? i : NQ - 1) * NE + env]; }
+#pragma unroll
+  for (int k = 0; k < KV; k++) { const int i = sub + G * k, ic = i < NV ? i : NV - 1; v[k] = st.qvel[(size_t)ic * NE + env]; wm[k] = st.warm[(size_t)ic * NE + env]; }
+#pragma unroll
+  for (int k = 0; k < KL; k++) {
+    const int i = sub + G * k, ic = i < NL ? i : NL - 1;
+    c[k] = st.ctrl[(size_t)ic * NE + env];
+    qi[k] = fused ? 0.0 : st.qpos_ik[(size_t)ic * NE + env];
+  }
+#pragma unroll
+  for (int k = 0; k < KQ; k++) { const int i = sub + G * k; if (i < NQ) { w.qpos[i] = q[k]; if (fused && i < NL) w.qpos_ik[i] = q[k]; } }
+#pragma unroll
+  for (int k = 0; k < KV; k++) { const int i = sub + G * k; if (i < NV) { w.qvel[i] = v[k]; w.warm[i] = wm[k]; } }
+#pragma unroll
+  for (int k = 0; k < KL; k++) {
+    const int i = sub + G * k;
+    if (i < NL) {
+      w.ctrl[i] = fused ? (real)(float)c[k] : c[k];
+      if (!fused) w.qpos_ik[i] = qi[k];
+    }
   }
   if (sub == 0) { w.bad = 0; w.work = 0; }
 }
-// state accessor of the fused before_step: the env's LDS workspace (diagnostics go straight to HBM)
 template <int NL> struct LdsIO {
   Ws<NL>& w; const KDeviceState& st; int env;
   __device__ __forceinline__ real qpos(int i) const { return w.qpos[i]; }
