@@ -2621,7 +2621,8 @@ __device__ __forceinline__ void load_state(Ws<NL>& w, const KDeviceState& st, in
   for (int k = 0; k < KL; k++) {
     const int i = sub + G * k, ic = i < NL ? i : NL - 1;
     c[k] = st.ctrl[(size_t)ic * NE + env];
-    qi[k] = fused ? 0.0 : st.qpos_ik[(size_t)ic * NE + env];
+    qi[k] = 0.0;
+    if (!fused) qi[k] = st.qpos_ik[(size_t)ic * NE + env];      // (wave-uniform: the split-launch path only)
   }
 #pragma unroll
   for (int k = 0; k < KQ; k++) { const int i = sub + G * k; if (i < NQ) { w.qpos[i] = q[k]; if (fused && i < NL) w.qpos_ik[i] = q[k]; } }
