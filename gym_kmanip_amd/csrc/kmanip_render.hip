@@ -35,19 +35,47 @@ struct RenderScene {
   real cube_p[3], cube_R[9];
   real sph[KM_MAX_SPHERES][3];
   real focal;
+  real cube_q[8];              // the cube's pose (qpos[nl .. nl + 6]) as read by lanes 0-6 at the top of the set-up
 };
+// what the camera / sphere lanes need from global memory, read at the top of render_fk together with the kinematics' inputs
+struct RenderPre { int sl, cl, tl; real sp[3], cp[3], tp[3], tanhalf; };
 
-// mj_kinematics, one link per lane + pointer jumping (block-wide barriers: the workgroup is 4 waves)
-__device__ __forceinline__ void render_fk(const KDeviceModel* dm, const KDeviceState& st, int env, RenderScene* sc) {
+// mj_kinematics, one link per lane + pointer jumping (block-wide barriers: the workgroup is 4 waves).
+// Round 6: every global read of the set-up is issued at the top and waited for once -- the joint angle (HBM), the link's constants
+// and its jump table for all four rounds (L2): read where they were used, each round's `jump[k][i]` cost another L2 round trip
+// behind a barrier, and a launch whose 2048 workgroups all start together hides none of it (the 64 x 64 depth render: 8 of 39 us).
+__device__ __forceinline__ void render_fk(const KDeviceModel* dm, const KDeviceState& st, int env, int cam, RenderScene* sc, RenderPre& pre) {
   const KModelDesc* m = &dm->d;
   const int nl = m->nlink, NE = st.num_envs, i = threadIdx.x;
   const bool on = i < nl;
-  real R[9], p[3];
+  const int ii = on ? i : 0;
+  real R[9], p[3], Rl[9];
+  int ja[4];
+  // lanes 0-6: one component of the cube's pose each; lanes 64..: one collision sphere each; the camera's constants (wave-uniform)
+  real cube_c = st.qpos[(size_t)(nl + (i < 7 ? i : 0)) * NE + env];
+  {
+    const int s = (i >= 64 && i < 64 + m->nsphere) ? i - 64 : 0;
+    pre.sl = m->sphere_link[s];
+    pre.sp[0] = m->sphere_pos[s][0]; pre.sp[1] = m->sphere_pos[s][1]; pre.sp[2] = m->sphere_pos[s][2];
+    pre.cl = m->cam_link[cam]; pre.tl = m->cam_target_link[cam];
+    for (int c = 0; c < 3; c++) { pre.cp[c] = m->cam_pos[cam][c]; pre.tp[c] = m->cam_target_pos[cam][c]; }
+    pre.tanhalf = dm->x.cam_tanhalf[cam];
+  }
+  {
+    const double* Rg = dm->x.link_R[ii];                // (normalised link_quat as a matrix: built once per model on the host)
+#pragma unroll
+    for (int c = 0; c < 9; c++) Rl[c] = Rg[c];
+  }
+  p[0] = m->link_pos[ii][0]; p[1] = m->link_pos[ii][1]; p[2] = m->link_pos[ii][2];
+  real q = st.qpos[(size_t)ii * NE + env];
+  int jt = m->jnt_type[ii];
+#pragma unroll
+  for (int k = 0; k < 4; k++) ja[k] = dm->x.jump[k][ii];
+  const int rounds = dm->x.fk_rounds;
+  km_pin(Rl); km_pin(p); km_pin(q, cube_c); km_pin_i(jt); km_pin_i(ja[0], ja[1]); km_pin_i(ja[2], ja[3]); km_pin(pre.sp); km_pin_i(pre.sl);
+  if (i < 7) sc->cube_q[i] = cube_c;
   if (on) {
-    const double* Rl = dm->x.link_R[i];                 // (normalised link_quat as a matrix: built once per model on the host)
-    p[0] = m->link_pos[i][0]; p[1] = m->link_pos[i][1]; p[2] = m->link_pos[i][2];
-    const real q = st.qpos[(size_t)i * NE + env];
-    if (m->jnt_type[i] == KM_JNT_SLIDE) {
+    if (jt == KM_JNT_SLIDE) {
 #pragma unroll
       for (int c = 0; c < 9; c++) R[c] = Rl[c];
       p[0] += Rl[2] * q; p[1] += Rl[5] * q; p[2] += Rl[8] * q;
@@ -66,9 +94,8 @@ __device__ __forceinline__ void render_fk(const KDeviceModel* dm, const KDeviceS
     sc->xpos[i][0] = p[0]; sc->xpos[i][1] = p[1]; sc->xpos[i][2] = p[2];
   }
   __syncthreads();
-  const int rounds = dm->x.fk_rounds;
   for (int k = 0; k < rounds; k++) {
-    const int a = on ? dm->x.jump[k][i] : -1;
+    const int a = on ? (k == 0 ? ja[0] : (k == 1 ? ja[1] : (k == 2 ? ja[2] : ja[3]))) : -1;
     if (a >= 0) {
       real A[9], pa[3], Rn[9], t[3];
 #pragma unroll
@@ -95,15 +122,15 @@ __device__ __forceinline__ void render_fk(const KDeviceModel* dm, const KDeviceS
 
 // Per-env scene after the FK: lane 0 builds the camera frame (mj_camlight, targetbody) and the cube pose, lanes 64.. one sphere
 // centre each (another wave: in parallel with lane 0).  Caller synchronises afterwards.
-__device__ __forceinline__ void render_camera(const KDeviceModel* dm, const KDeviceState& st, int env, int cam, int height, RenderScene* sc) {
+__device__ __forceinline__ void render_camera(const KDeviceModel* dm, const KDeviceState& st, int env, int cam, int height, RenderScene* sc, const RenderPre& pre) {
   const KModelDesc* m = &dm->d;
-  const int nl = m->nlink, NE = st.num_envs, t = threadIdx.x;
+  const int t = threadIdx.x;
   if (t == 0) {
     // camera frame: z = (cam - target)/|.|, x = (0,0,1) x z, y = z x x; a link of -1 = world frame
-    const int cl = m->cam_link[cam], tl = m->cam_target_link[cam];
+    const int cl = pre.cl, tl = pre.tl;
     real co[3], to[3], v[3];
-    real cp[3] = {m->cam_pos[cam][0], m->cam_pos[cam][1], m->cam_pos[cam][2]};
-    real tp[3] = {m->cam_target_pos[cam][0], m->cam_target_pos[cam][1], m->cam_target_pos[cam][2]};
+    real cp[3] = {pre.cp[0], pre.cp[1], pre.cp[2]};
+    real tp[3] = {pre.tp[0], pre.tp[1], pre.tp[2]};
     if (cl < 0) { co[0] = cp[0]; co[1] = cp[1]; co[2] = cp[2]; }
     else { mat_vec3(v, sc->xmat[cl], cp); co[0] = sc->xpos[cl][0] + v[0]; co[1] = sc->xpos[cl][1] + v[1]; co[2] = sc->xpos[cl][2] + v[2]; }
     if (tl < 0) { to[0] = tp[0]; to[1] = tp[1]; to[2] = tp[2]; }
@@ -113,15 +140,15 @@ __device__ __forceinline__ void render_camera(const KDeviceModel* dm, const KDev
     cross3(x, up, z); normalize3_fast(x);
     cross3(y, z, x); normalize3_fast(y);
     for (int c = 0; c < 3; c++) { sc->cam_o[c] = co[c]; sc->cam_x[c] = x[c]; sc->cam_y[c] = y[c]; sc->cam_z[c] = z[c]; }
-    sc->focal = (0.5 * height) / dm->x.cam_tanhalf[cam];
+    sc->focal = (0.5 * height) / pre.tanhalf;
     real cq[4];
-    for (int c = 0; c < 3; c++) sc->cube_p[c] = st.qpos[(size_t)(nl + c) * NE + env];
-    for (int c = 0; c < 4; c++) cq[c] = st.qpos[(size_t)(nl + 3 + c) * NE + env];
+    for (int c = 0; c < 3; c++) sc->cube_p[c] = sc->cube_q[c];
+    for (int c = 0; c < 4; c++) cq[c] = sc->cube_q[3 + c];
     normalize4_fast(cq);
     quat2mat(sc->cube_R, cq);
   } else if (t >= 64 && t < 64 + m->nsphere) {
-    const int s = t - 64, l = m->sphere_link[s];
-    real sl[3] = {m->sphere_pos[s][0], m->sphere_pos[s][1], m->sphere_pos[s][2]}, v[3];
+    const int s = t - 64, l = pre.sl;
+    real sl[3] = {pre.sp[0], pre.sp[1], pre.sp[2]}, v[3];
     mat_vec3(v, sc->xmat[l], sl);
     sc->sph[s][0] = sc->xpos[l][0] + v[0]; sc->sph[s][1] = sc->xpos[l][1] + v[1]; sc->sph[s][2] = sc->xpos[l][2] + v[2];
   }
@@ -252,8 +279,13 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
   __shared__ DepthScene ds;
   const KModelDesc* m = &dm->d;
   const int env = blockIdx.x;
-  render_fk(dm, st, env, &sc);
-  render_camera(dm, st, env, cam, height, &sc);
+  // model scalars of the pixel loop: wave-uniform reads, issued in front of the set-up (they used to start after its last barrier)
+  const real zfar = m->cam_zfar, znear = m->cam_znear, tabz = m->table_z;
+  const real rx0 = m->table_rect[0], rx1 = m->table_rect[1], ry0 = m->table_rect[2], ry1 = m->table_rect[3];
+  const real hf0 = m->cube_half[0], hf1 = m->cube_half[1], hf2 = m->cube_half[2];
+  RenderPre pre;
+  render_fk(dm, st, env, cam, &sc, pre);
+  render_camera(dm, st, env, cam, height, &sc, pre);
   __syncthreads();
   if (threadIdx.x < 4) {
     // ray origin and basis in the cube frame, one vector per lane
@@ -275,14 +307,13 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
   }
   __syncthreads();
   // ---- everything the pixel loop reads, in registers
-  const real zfar = m->cam_zfar, znear = m->cam_znear;
-  const real k0 = m->table_z - sc.cam_o[2], ox = sc.cam_o[0], oy = sc.cam_o[1];
-  const real rx0 = m->table_rect[0], rx1 = m->table_rect[1], ry0 = m->table_rect[2], ry1 = m->table_rect[3];
-  real X[3], Y[3], Z[3], ol[3], DX[3], DY[3], DZ[3], hf[3];
+  const real k0 = tabz - sc.cam_o[2], ox = sc.cam_o[0], oy = sc.cam_o[1];
+  real X[3], Y[3], Z[3], ol[3], DX[3], DY[3], DZ[3];
+  const real hf[3] = {hf0, hf1, hf2};
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     X[c] = sc.cam_x[c]; Y[c] = sc.cam_y[c]; Z[c] = sc.cam_z[c];
-    ol[c] = ds.ol[c]; DX[c] = ds.DX[c]; DY[c] = ds.DY[c]; DZ[c] = ds.DZ[c]; hf[c] = m->cube_half[c];
+    ol[c] = ds.ol[c]; DX[c] = ds.DX[c]; DY[c] = ds.DY[c]; DZ[c] = ds.DZ[c];
   }
   // |camera - cube centre|^2 - (bounding radius)^2, the radius padded by a relative 1e-9 so that roundoff never rejects a grazing ray
   const real cube_cc = (ol[0] * ol[0] + ol[1] * ol[1] + ol[2] * ol[2]) - (hf[0] * hf[0] + hf[1] * hf[1] + hf[2] * hf[2]) * (1.0 + 1e-9);
@@ -299,51 +330,78 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
   int r = threadIdx.x / width, c = threadIdx.x - r * width;         // row / column advance incrementally (no division in the loop)
   const int dr = blockDim.x / width, dc = blockDim.x - dr * width;
   // Round 5: when the workgroup's stride is a whole number of image rows (64-wide images: 128 lanes = two rows) a lane keeps its
-  // COLUMN for the whole loop, so everything that is linear in the pixel coordinates has a per-lane constant part -- the ray
-  // direction in the world and in the cube frame cost one FMA per component and pixel instead of two or three.
-  // The loop is bound by the NUMBER of float64 instructions a pixel issues (a wave is one image row; 85 VALU instructions for a
-  // pixel that sees the table only, ISA count): what a ray rarely needs is computed where it is needed -- the direction in the
-  // cube frame and the slab reciprocals behind the bounding-sphere test (itself in the world frame: a rotation changes neither
-  // dot product), 1 / |d|^2 behind a sphere hit -- the table's rectangle test is one min-chain instead of four compare-and-
-  // combine pairs, reciprocals take one Newton step (v_rcp_f64 is good to 2^-23: one step gives 2^-46, the depth bar is 1e-6 m),
-  // and the final clamp is one v_med3_f32 after the conversion (rounding is monotonic: the same float as clamping first).
+  // COLUMN for the whole loop, so everything that is linear in the pixel coordinates has a per-lane constant part.
+  // The loop is bound by the NUMBER of float64 instructions a pixel issues (a wave is one image row): what a ray rarely needs is
+  // computed where it is needed -- the direction in the cube frame and the slab reciprocals behind the bounding-sphere test (itself
+  // in the world frame: a rotation changes neither dot product), reciprocals take one Newton step (v_rcp_f64 is good to 2^-23: one
+  // step gives 2^-46, the depth bar is 1e-6 m), and the final clamp is one v_med3_f32 after the conversion (rounding is monotonic).
+  // Round 6 (column kept): the ray direction is d = e + Y dy with e fixed per lane, so every dot product with d is ONE FMA in dy
+  // against two per-lane constants (|d|^2: two) instead of three; dy itself advances by a constant; the table's rectangle is
+  // tested as half-width minus |offset from its centre| (three instructions for the four edges' seven).
   constexpr bool colfixed = COLFIXED;
   const real dxl = (c + 0.5 - hw) * inv_f;
   real ex[3], bx[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) { ex[a] = X[a] * dxl - Z[a]; bx[a] = DX[a] * dxl - DZ[a]; }
   const real rel[3] = {sc.cam_o[0] - sc.cube_p[0], sc.cam_o[1] - sc.cube_p[1], sc.cam_o[2] - sc.cube_p[2]};   // (|rel| = |ol|)
+  real A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, S0[KM_RENDER_MAXVIS], S1[KM_RENDER_MAXVIS];
+#pragma unroll
+  for (int s = 0; s < KM_RENDER_MAXVIS; s++) { S0[s] = 0; S1[s] = 0; }
+  if constexpr (colfixed) {
+    A0 = dot3(ex, ex); A1 = 2.0 * dot3(ex, Y); A2 = dot3(Y, Y);
+    B0 = dot3(ex, rel); B1 = dot3(Y, rel);
+#pragma unroll
+    for (int s = 0; s < KM_RENDER_MAXVIS; s++) { S0[s] = dot3(ex, soc[s]); S1[s] = dot3(Y, soc[s]); }
+  }
+  // table rectangle by centre and half-widths (an unbounded side: the four-edge form below)
+  const bool centred = isfinite(rx0) && isfinite(rx1) && isfinite(ry0) && isfinite(ry1);
+  const real tcx = centred ? 0.5 * (rx0 + rx1) : 0.0, tcy = centred ? 0.5 * (ry0 + ry1) : 0.0;
+  const real thx = 0.5 * (rx1 - rx0), thy = 0.5 * (ry1 - ry0);
+  const real oxc = ox - tcx, oyc = oy - tcy;
   const float znf = (float)znear, zff = (float)zfar;
-  const real row0 = hh - 0.5;                            // dy = (row0 - r) / f, r counted in float64 (exact)
+  const real row0 = hh - 0.5;                            // dy = (row0 - r) / f
   real rd = (real)r;
   const real drd = (real)dr;
+  real dyc = (row0 - rd) * inv_f;
+  const real ddy = drd * inv_f;
+  real zfv = zfar;
+  asm volatile("" : "+v"(zfv));                          // (kept in a register pair: the selects below cannot take it from SGPRs next to VCC)
   auto rcp1 = [](real x) { real q = __builtin_amdgcn_rcp(x); return q + q * (1.0 - x * q); };
-  // sqrt(x), x >= 0, to 2^-46: v_rsq_f64 (2^-23) and one coupled step (g ~ sqrt x, h ~ 1 / (2 sqrt x): g += g (1/2 - g h))
-  auto sqrt1 = [](real x) { const real y = __builtin_amdgcn_rsq(fmax(x, 1e-300)); const real g = x * y, h = 0.5 * y; return g + g * (0.5 - g * h); };
+  // sqrt(x), x > 0, to 2^-46: v_rsq_f64 (2^-23) and one coupled step (g ~ sqrt x, h ~ 1 / (2 sqrt x): g += g (1/2 - g h)).
+  // x = 0 gives NaN, which fails the comparisons of the hit it would have been (a ray tangent to a sphere to the last bit)
+  auto sqrt1 = [](real x) { const real y = __builtin_amdgcn_rsq(x); const real g = x * y, h = 0.5 * y; return g + g * (0.5 - g * h); };
   for (int p = threadIdx.x; p < npix; p += blockDim.x) {
-    real dx, dy;
-    if constexpr (colfixed) { dx = dxl; dy = (row0 - rd) * inv_f; rd += drd; }
-    else {
+    real dx, dy, d0, d1, d2, a2, bc;
+    if constexpr (colfixed) {
+      dx = dxl; dy = dyc; dyc -= ddy;
+      d0 = __builtin_fma(Y[0], dy, ex[0]); d1 = __builtin_fma(Y[1], dy, ex[1]); d2 = __builtin_fma(Y[2], dy, ex[2]);
+      a2 = __builtin_fma(dy, __builtin_fma(dy, A2, A1), A0);
+      bc = __builtin_fma(dy, B1, B0);
+    } else {
       dx = (c + 0.5 - hw) * inv_f; dy = -(r + 0.5 - hh) * inv_f;
       c += dc; r += dr;
       if (c >= width) { c -= width; r++; }
+      d0 = X[0] * dx + Y[0] * dy - Z[0]; d1 = X[1] * dx + Y[1] * dy - Z[1]; d2 = X[2] * dx + Y[2] * dy - Z[2];
+      a2 = d0 * d0 + d1 * d1 + d2 * d2;
+      bc = d0 * rel[0] + d1 * rel[1] + d2 * rel[2];
     }
-    real d0, d1, d2;
-    if constexpr (colfixed) { d0 = __builtin_fma(Y[0], dy, ex[0]); d1 = __builtin_fma(Y[1], dy, ex[1]); d2 = __builtin_fma(Y[2], dy, ex[2]); }
-    else { d0 = X[0] * dx + Y[0] * dy - Z[0]; d1 = X[1] * dx + Y[1] * dy - Z[1]; d2 = X[2] * dx + Y[2] * dy - Z[2]; }
     // table top: the rectangle table_rect at z = table_z.  d2 == 0 makes t infinite or NaN, which fails `t > 0 && t < zfar`; the
-    // min-chain is then never looked at (table_rect holds no NaN: kmanip_create checks)
-    real best = zfar;
+    // rectangle test is then never looked at (table_rect holds no NaN: kmanip_create checks)
+    real best = zfv;
     {
       const real t = k0 * rcp1(d2);
-      const real hx = __builtin_fma(t, d0, ox), hy = __builtin_fma(t, d1, oy);
-      const real in = fmin(fmin(hx - rx0, rx1 - hx), fmin(hy - ry0, ry1 - hy));
+      real in;
+      if (centred) {
+        const real hx = __builtin_fma(t, d0, oxc), hy = __builtin_fma(t, d1, oyc);
+        in = fmin(thx - fabs(hx), thy - fabs(hy));
+      } else {
+        const real hx = __builtin_fma(t, d0, ox), hy = __builtin_fma(t, d1, oy);
+        in = fmin(fmin(hx - rx0, rx1 - hx), fmin(hy - ry0, ry1 - hy));
+      }
       if (t > 0 && t < zfar && in >= 0) best = t;
     }
-    // cube box: slab test in the cube frame -- only for rays that meet the box's bounding sphere (six operations decide it; a
-    // wave is one image row or two, so the test is coherent)
-    const real a2 = d0 * d0 + d1 * d1 + d2 * d2;
-    const real bc = d0 * rel[0] + d1 * rel[1] + d2 * rel[2];
+    // cube box: slab test in the cube frame -- only for rays that meet the box's bounding sphere (a wave is one image row or two,
+    // so the test is coherent)
     if (bc * bc - a2 * cube_cc >= 0) {
       real dlv[3];
 #pragma unroll
@@ -370,7 +428,8 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
 #pragma unroll
     for (int s = 0; s < KM_RENDER_MAXVIS; s++) {
       if (s < nvis) {
-        const real b = d0 * soc[s][0] + d1 * soc[s][1] + d2 * soc[s][2], disc = b * b - a2 * scc[s];
+        const real b = colfixed ? __builtin_fma(dy, S1[s], S0[s]) : d0 * soc[s][0] + d1 * soc[s][1] + d2 * soc[s][2];
+        const real disc = b * b - a2 * scc[s];
         if (disc >= 0) {
           // nearest root; compared before the division: t < best  <=>  -b - sqrt(disc) < best * a2  (a2 > 0)
           const real num = -b - sqrt1(disc);
@@ -473,8 +532,9 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
   const int env = blockIdx.x, job = blockIdx.y;
   const int cam = jobs.cam[job], height = jobs.height[job], width = jobs.width[job];
   uint8_t* __restrict__ rgb = jobs.rgb[job];
-  render_fk(dm, st, env, &sc);
-  render_camera(dm, st, env, cam, height, &sc);
+  RenderPre pre;
+  render_fk(dm, st, env, cam, &sc, pre);
+  render_camera(dm, st, env, cam, height, &sc, pre);
   __syncthreads();
   rgb_scene(dm, sc, height, width, &g, &tmp, threadIdx.x);
   __syncthreads();
