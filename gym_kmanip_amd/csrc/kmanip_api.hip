@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.28 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.29 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 

@@ -273,7 +273,7 @@ __device__ __forceinline__ void rgb_scene(const KDeviceModel* dm, const RenderSc
 struct DepthScene { real ol[3], DX[3], DY[3], DZ[3]; real oc[KM_RENDER_MAXVIS][3], cc[KM_RENDER_MAXVIS]; int nvis; };
 
 template <bool COLFIXED>      // COLFIXED: blockDim.x is a whole number of image rows (the launcher knows)
-__global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
+__global__ __launch_bounds__(256, 4) void k_render_depth(const KDeviceModel* __restrict__ dm, KDeviceState st, int cam, int height, int width,
                                                       float* __restrict__ depth) {
   __shared__ RenderScene sc;
   __shared__ DepthScene ds;
@@ -370,7 +370,12 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
   // sqrt(x), x > 0, to 2^-46: v_rsq_f64 (2^-23) and one coupled step (g ~ sqrt x, h ~ 1 / (2 sqrt x): g += g (1/2 - g h)).
   // x = 0 gives NaN, which fails the comparisons of the hit it would have been (a ray tangent to a sphere to the last bit)
   auto sqrt1 = [](real x) { const real y = __builtin_amdgcn_rsq(x); const real g = x * y, h = 0.5 * y; return g + g * (0.5 - g * h); };
-  for (int p = threadIdx.x; p < npix; p += blockDim.x) {
+  // (a wave-uniform trip count: the loop control is scalar, the lane's pixel index one add)
+  const int nit = (npix + (int)blockDim.x - 1) / (int)blockDim.x;
+  float* __restrict__ op = out + threadIdx.x;
+  const int pstep = blockDim.x;
+  int p = threadIdx.x;
+  for (int it = 0; it < nit; it++, p += pstep, op += pstep) {
     real dx, dy, d0, d1, d2, a2, bc;
     if constexpr (colfixed) {
       dx = dxl; dy = dyc; dyc -= ddy;
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256) void k_render_depth(const KDeviceModel* __rest
         }
       }
     }
-    out[p] = __builtin_amdgcn_fmed3f((float)best, znf, zff);
+    if (COLFIXED || p < npix) *op = __builtin_amdgcn_fmed3f((float)best, znf, zff);     // (COLFIXED launches: npix is a multiple of the workgroup, checked by the launcher)
   }
 }
 
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(256) void k_render_rgb(const KDeviceModel* __restri
 void kmanip_launch_render_depth(const KDeviceModel* dm, const KDeviceState& st, int cam, int height, int width, float* depth,
                                 hipStream_t stream) {
   // 128 lanes per env: two waves -- 2048 envs x 2 waves fill the chip's 4096 wave slots (120 registers: four waves per SIMD) in one round
-  if (width > 0 && 128 % width == 0) hipLaunchKernelGGL(k_render_depth<true>, dim3(st.num_envs), dim3(128), 0, stream, dm, st, cam, height, width, depth);
+  if (width > 0 && 128 % width == 0 && (height * width) % 128 == 0) hipLaunchKernelGGL(k_render_depth<true>, dim3(st.num_envs), dim3(128), 0, stream, dm, st, cam, height, width, depth);
   else hipLaunchKernelGGL(k_render_depth<false>, dim3(st.num_envs), dim3(128), 0, stream, dm, st, cam, height, width, depth);
 }
 void kmanip_launch_render_rgb(const KDeviceModel* dm, const KDeviceState& st, const KRenderJobs& jobs, hipStream_t stream) {
