@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--rendezvous-timeout", type=float, default=float(os.environ.get("KMANIP_RENDEZVOUS_TIMEOUT", "90")),
                     help="wall-clock bound in seconds on every start-up step that waits for the other ranks (init_process_group, the "
                          "rank-count all-reduce, the direct communicator and its self-test): past it the rank prints one line and exits 6")
+    ap.add_argument("--run-timeout", type=float, default=-1.0,
+                    help="N > 1 only: wall-clock bound in seconds on the warm-up + timed steps (their exchanges, barriers and the max over "
+                         "ranks wait for peers too); past it the rank prints one line and exits 6.  -1 (default): 120 s + 10 ms a step; 0: none")
     ap.add_argument("--gather-depth", type=int, default=0,
                     help="ring of (reward, done) record buffers (dist.RewardDoneGather(depth=...)): a rank may run that many steps ahead "
                          "of the slowest one before it waits.  0: 16 on RCCL across ranks (an IK crawl is up to seven steps long; "
@@ -138,6 +141,14 @@ class Deadline:
         if self._timer is not None:
             self._timer.cancel()
         return False
+
+
+def run_timeout_seconds(args):
+    """The bound on the warm-up + timed region of an N > 1 run: --run-timeout if given (0 = none), else 120 s + 10 ms a step --
+    two hundred times what a healthy step takes, so that only a hang meets it."""
+    if getattr(args, "run_timeout", None) is not None and args.run_timeout >= 0:
+        return float(args.run_timeout)
+    return 120.0 + 0.01 * (args.warmup + args.steps)
 
 
 def kmanip_env_vars():
@@ -715,23 +726,30 @@ def run_rank(args):
     w.lay_out(args.warmup + args.steps)
     if gather is not None:
         gather.bind(env)          # from here on every step writes its packed (reward, done) record itself: one step, one post
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    env.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    if gather is not None:
-        gather.wait()
-    barrier()
-    dt = time.perf_counter() - t0
-    ik_ms, dyn_ms, rnd_ms, nt = env.timing_summary()
-    env.enable_timing(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # N > 1: the steps themselves wait for peers (the per-step exchange, the two barriers, the max over ranks).  A collective that
+    # never completes would sit there until the driver's own timeout; the same watchdog bounds the whole region generously
+    # (run_timeout_seconds: two minutes plus 10 ms a step unless --run-timeout says otherwise) -- it never fires on a healthy run
+    import contextlib
+    run_guard = (Deadline("the warm-up and timed steps (a collective that never completed?)", run_timeout_seconds(args), rank)
+                 if dist is not None else contextlib.nullcontext())
+    with run_guard:
+        for _ in range(args.warmup):
+            one_step()
+        barrier()
+        env.enable_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        if gather is not None:
+            gather.wait()
+        barrier()
+        dt = time.perf_counter() - t0
+        ik_ms, dyn_ms, rnd_ms, nt = env.timing_summary()
+        env.enable_timing(False)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
 
     if rank == 0:
         version = env.L.kmanip_version().decode()

@@ -186,3 +186,21 @@ def test_default_exchange_is_the_mainstream_path_and_the_line_records_the_knobs(
     assert bench.kmanip_env_vars() == {}
     monkeypatch.setenv("KMANIP_EPB", "2"); monkeypatch.setenv("KMANIP_SPREAD", "0"); monkeypatch.setenv("KMANIP_BENCH_SPAWNED", "1")
     assert bench.kmanip_env_vars() == {"KMANIP_EPB": "2", "KMANIP_SPREAD": "0"}
+
+
+def test_run_timeout_bounds_the_timed_region_generously():
+    """N > 1: the warm-up + timed steps run under the same watchdog as the start-up (a collective that never completes must not
+    sit there until the driver's timeout); the automatic bound is far above a healthy run, --run-timeout overrides, 0 disables."""
+    import types
+    import bench
+    a = types.SimpleNamespace(run_timeout=-1.0, warmup=5, steps=20)
+    assert bench.run_timeout_seconds(a) == 120.0 + 0.25
+    a.steps = 100000
+    assert bench.run_timeout_seconds(a) > 1000.0             # 0.6 ms a step: a healthy 100 000-step run takes a minute
+    a.run_timeout = 30.0
+    assert bench.run_timeout_seconds(a) == 30.0
+    a.run_timeout = 0.0
+    assert bench.run_timeout_seconds(a) == 0.0               # Deadline(seconds=0) starts no timer
+    d = bench.Deadline("x", 0.0)
+    with d:
+        assert d._timer is None
