@@ -614,6 +614,10 @@ OTHER_CONFIGS = [   # BASELINE.json configs 3, 4 (one GPU's shard), 5 and the re
 
 
 def run_rank(args):
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # dmabuf IPC (RCCL across processes needs it on this pool); read when the HIP runtime starts, so before torch is imported --
+        # the driver exports it already, spawn_ranks sets it for its children: this covers a bare torch.distributed.run
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
