@@ -143,6 +143,13 @@ class Deadline:
         return False
 
 
+def timing_every(steps):
+    """The library's HIP events (kmanip_enable_timing) around every k-th launch of the timed region: an event pair costs the step's
+    stream about 5 us -- 1 % of a 4096-env step, paid inside `value` -- so long windows sample (>= 128 launches timed, spread evenly
+    over the window; the episode phases are staggered, every step holds the same mix of envs) and short ones time every launch."""
+    return max(1, int(steps) // 128)
+
+
 def run_timeout_seconds(args):
     """The bound on the warm-up + timed region of an N > 1 run: --run-timeout if given (0 = none), else 120 s + 10 ms a step --
     two hundred times what a healthy step takes, so that only a hang meets it."""
@@ -564,7 +571,7 @@ def measure_config(torch, env_id, n, local_rank, steps, warmup, depth=0, solver=
     for _ in range(warmup):
         one()
     torch.cuda.synchronize()
-    env.enable_timing(True)
+    env.enable_timing(timing_every(steps))
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
@@ -601,7 +608,7 @@ def measure_config(torch, env_id, n, local_rank, steps, warmup, depth=0, solver=
             "value": n * steps / dt, "unit": "env steps/s", "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_env_step": bpe, "algorithmic_bytes_per_launch": bpe * n,
-                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launches_timed": nt}}}
+                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launches_timed": nt, "timed_every": timing_every(steps)}}}
 
 
 OTHER_CONFIGS = [   # BASELINE.json configs 3, 4 (one GPU's shard), 5 and the reference's own *Vision observation at config 5's width
@@ -740,7 +747,7 @@ def run_rank(args):
         for _ in range(args.warmup):
             one_step()
         barrier()
-        env.enable_timing(True)
+        env.enable_timing(timing_every(args.steps))
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
@@ -805,8 +812,8 @@ def run_rank(args):
                          "traffic": cc["traffic"], "traffic_source": cc["traffic_source"],
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_env_step": bpe,
-                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launch_gap": max(dt / args.steps * 1e3 - (dyn_ms + rnd_ms + ik_ms) / max(nt, 1), 0.0),   # ms per step outside the timed kernels: launch overhead + the two event records
-                                           "launches_timed": nt},
+                         "kernel_ms_avg": {"k_step": dyn_ms / max(nt, 1), "k_render": rnd_ms / max(nt, 1), "launch_gap": max(dt / args.steps * 1e3 - (dyn_ms + rnd_ms + ik_ms) / max(nt, 1), 0.0),   # ms per step outside the timed kernels: launch overhead (+ the event records of the sampled steps)
+                                           "launches_timed": nt, "timed_every": timing_every(args.steps)},
                          "valu": valu,
                          "note": "latency/FP64-VALU bound by construction (SURVEY 8d): HBM traffic per env-step is ~1.2 KB"},
         }

@@ -14,7 +14,7 @@
 
 #include "kmanip_device.hpp"
 
-#define KM_VERSION "kmanip-hip 0.29 (gfx950, f64)"
+#define KM_VERSION "kmanip-hip 0.30 (gfx950, f64)"
 
 static thread_local std::string g_create_error;
 
@@ -28,6 +28,8 @@ struct KHandle_ {
   std::vector<hipEvent_t> ev;   // 4 events per timed step
   std::vector<char> ev_render;  // the step rendered in the step (its fourth event was recorded)
   bool timing = false;
+  int timing_every = 1;         // events around every timing_every-th step (the argument of kmanip_enable_timing)
+  long timing_count = 0;
   double* rd_rec[2] = {nullptr, nullptr};   // kmanip_bind_reward_done_record: the two record buffers
   int rd_sel = 0;                           // kmanip_select_reward_done_record: the one the next kmanip_step fills
   int timed_steps = 0;
@@ -410,7 +412,7 @@ static int step_impl(KHandle h, int nchunk, const float* act_dev, double* obs_de
   if (!act_dev || !obs_dev || !reward_dev || !done_dev) { h->err = "kmanip_step: null buffer"; return -1; }
   KM_ENTER(h);
   hipStream_t s = (hipStream_t)stream;
-  const bool tm = h->timing && h->timed_steps < KM_TIMING_SLOTS;
+  const bool tm = h->timing && (h->timing_count++ % h->timing_every) == 0 && h->timed_steps < KM_TIMING_SLOTS;
   h->last_step_timed = tm;
   hipEvent_t* ev = tm ? &h->ev[4 * (size_t)h->timed_steps] : nullptr;
   // product path: ONE launch, before_step (decode + IK) fused into k_step so that no device-wide barrier sits between
@@ -564,6 +566,8 @@ int kmanip_enable_timing(KHandle h, int enable) {
     for (auto& e : h->ev) HIPCHK(h, hipEventCreate(&e));
   }
   h->timing = enable != 0;
+  h->timing_every = enable > 1 ? enable : 1;
+  h->timing_count = 0;
   h->timed_steps = 0;
   return 0;
 }

@@ -416,6 +416,8 @@ class KManipEnvHip:
         return res, jac
 
     def enable_timing(self, on=True):
+        """on = True / 1: events around every step; an int k > 1: around every k-th step (the sampled average; an event pair costs
+        the stream about 5 us); False / 0: off."""
         self._check(self.L.kmanip_enable_timing(self.h, int(on)), "kmanip_enable_timing")
 
     def timing_summary(self):

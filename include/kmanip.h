@@ -292,7 +292,9 @@ KMANIP_API int kmanip_get_diag(KHandle h, uint32_t* contact_mask, int32_t* ik_nf
  * path -- one before its stand-alone decode/IK launches (an event record costs the stream about 5 us, so the product path takes
  * the two it needs), into a ring of `KM_TIMING_SLOTS` steps.  kmanip_timing_summary synchronises the device and returns the
  * summed durations in milliseconds of the three legs (stand-alone IK: 0 on the product path; k_step; the step's render:
- * kmanip_bind_step_depth's or the RGB render called after the step, 0 without one) over the recorded steps, then clears the ring.  Any output pointer may be NULL. */
+ * kmanip_bind_step_depth's or the RGB render called after the step, 0 without one) over the recorded steps, then clears the ring.  Any output pointer may be NULL.
+ * `enable` = k > 1 records every k-th step only (the first step after the call, then every k-th): the events' own cost -- the ~5 us
+ * above, 1 % of a 4096-env step -- then falls on one step in k, and the averages are over the sampled steps (`*nsteps` = their count). */
 #define KM_TIMING_SLOTS 1024
 KMANIP_API int kmanip_enable_timing(KHandle h, int enable);
 KMANIP_API int kmanip_timing_summary(KHandle h, double* ik_ms_sum, double* dyn_ms_sum, double* render_ms_sum, int32_t* nsteps);

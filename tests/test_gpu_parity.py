@@ -875,3 +875,26 @@ def test_bound_reward_done_record():
     e.step_flat(e.sample_action())
     assert all(torch.equal(a, b) for a, b in zip(rec, keep))
     e.k_close()
+
+
+def test_sampled_step_timing():
+    """kmanip_enable_timing(k): events around every k-th step only (an event pair costs the stream ~5 us: bench.py samples long
+    windows); the summary counts the sampled steps, their average is a k_step launch's duration, and the steps are the same steps."""
+    torch = _torch()
+    from gym_kmanip_amd import env_hip
+    n = 256
+    a = env_hip.make("KManipSoloArm", num_envs=n, seed=5); b = env_hip.make("KManipSoloArm", num_envs=n, seed=5)
+    a.k_reset(); b.k_reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    acts = [torch.rand((n, a.cm.act_dim), generator=gen, device="cuda") * 2 - 1 for _ in range(16)]
+    a.enable_timing(4); b.enable_timing(True)
+    for act in acts:
+        a.step_flat(act); b.step_flat(act)
+    _, dyn_a, _, nt_a = a.timing_summary(); _, dyn_b, _, nt_b = b.timing_summary()
+    assert (nt_a, nt_b) == (4, 16)
+    assert 0.01 < dyn_a / nt_a < 20.0 and 0.01 < dyn_b / nt_b < 20.0           # milliseconds per launch, both plausible
+    assert all(np.array_equal(x, y) for x, y in zip(a.get_state(), b.get_state()))
+    a.enable_timing(False)
+    a.step_flat(acts[0])
+    assert a.timing_summary()[3] == 0
+    a.k_close(); b.k_close()
