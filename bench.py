@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--rendezvous-timeout", type=float, default=float(os.environ.get("KMANIP_RENDEZVOUS_TIMEOUT", "90")),
                     help="wall-clock bound in seconds on every start-up step that waits for the other ranks (init_process_group, the "
                          "rank-count all-reduce, the direct communicator and its self-test): past it the rank prints one line and exits 6")
+    ap.add_argument("--time-every", type=int, default=0,
+                    help="HIP events around every k-th launch of the timed region (an event pair costs the stream ~5 us).  0 (default): "
+                         "every launch for windows under 256 steps, else steps // 128; 1: every launch (tools/ab.sh: libraries older than 0.30 time every launch whatever k is)")
     ap.add_argument("--run-timeout", type=float, default=-1.0,
                     help="N > 1 only: wall-clock bound in seconds on the warm-up + timed steps (their exchanges, barriers and the max over "
                          "ranks wait for peers too); past it the rank prints one line and exits 6.  -1 (default): 120 s + 10 ms a step; 0: none")
@@ -143,10 +146,16 @@ class Deadline:
         return False
 
 
+TIME_EVERY = 0          # --time-every: 0 = automatic (below); k = events around every k-th launch (1: every launch -- what an A/B against a
+                        # library older than 0.30, which knows only "on", must use for both sides)
+
+
 def timing_every(steps):
     """The library's HIP events (kmanip_enable_timing) around every k-th launch of the timed region: an event pair costs the step's
     stream about 5 us -- 1 % of a 4096-env step, paid inside `value` -- so long windows sample (>= 128 launches timed, spread evenly
     over the window; the episode phases are staggered, every step holds the same mix of envs) and short ones time every launch."""
+    if TIME_EVERY > 0:
+        return TIME_EVERY
     return max(1, int(steps) // 128)
 
 
@@ -896,6 +905,8 @@ def run_rank(args):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    global TIME_EVERY
+    TIME_EVERY = max(0, int(args.time_every))
     if args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args, argv)          # nothing above this line touches the GPU
     return run_rank(args)

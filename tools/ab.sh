@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: same-box A/B of two builds of the library (KMANIP_LIB), alternating, `reps` times each.
 # Usage: bash tools/ab.sh <libA.so> <libB.so> [reps=3] [bench.py args...]      (default args: the headline workload, 1024 timed launches)
 A=$1; B=$2; REPS=${3:-3}; shift 3 2>/dev/null || shift $#
-ARGS=${@:---steps 1024 --warmup 16 --no-variants --no-cpu-baseline}
+ARGS="${@:---steps 1024 --warmup 16 --no-variants --no-cpu-baseline} --time-every 1"      # (events around EVERY launch on both sides: a library older than 0.30 knows no sampling)
 one() {
   KMANIP_LIB=$1 python3 bench.py $ARGS 2>/dev/null | python3 -c "
 import sys, json
