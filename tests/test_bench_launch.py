@@ -204,3 +204,19 @@ def test_run_timeout_bounds_the_timed_region_generously():
     d = bench.Deadline("x", 0.0)
     with d:
         assert d._timer is None
+
+
+def test_timing_events_are_sampled_on_long_windows_only():
+    """An event pair costs the step's stream ~5 us (1 % of a 4096-env step, inside `value`): windows of >= 256 steps time every
+    (steps // 128)-th launch, the driver's 20-step window times every launch; --time-every overrides (tools/ab.sh: 1)."""
+    import bench
+    old = bench.TIME_EVERY
+    try:
+        bench.TIME_EVERY = 0
+        assert [bench.timing_every(s) for s in (1, 20, 128, 255, 256, 1024, 4096)] == [1, 1, 1, 1, 2, 8, 32]
+        assert 1024 // bench.timing_every(1024) == 128                       # the default run still times 128 launches
+        bench.TIME_EVERY = 1
+        assert bench.timing_every(1024) == 1
+        assert bench.parse_args(["--time-every", "4"]).time_every == 4 and bench.parse_args([]).time_every == 0
+    finally:
+        bench.TIME_EVERY = old
